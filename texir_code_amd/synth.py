@@ -1,0 +1,303 @@
+"""Seeded procedural indoor scenes: the reference's dataset is private
+(README.md:21-34), so parity fixtures and the bench run on this generator instead.
+
+scene(T, seed): axis-aligned 8 x 3 x 6 m room with inward faces + ~40 floor-standing boxes,
+every planar patch tessellated into a displaced quad grid so that the mesh has EXACTLY T
+triangles; one UV chart per patch, shelf-packed into [0,1]^2; HDR radiance texture
+(log-normal base x smooth noise + emissive rectangles) stored in the layout the tracer
+consumes (already "flipped + exposed", models/tracer_o3d_irt.py:77-81: texel (row r, col c)
+covers uv = ((c+.5)/W, (r+.5)/H)); texel G-buffers (pos + 1e-2*n, n, valid) produced by
+evaluating the chart parametrisation at texel centres (replaces generate_positions +
+calcute_position_normal_texture, tracer_o3d_irt.py:99-142, for synthetic data).
+"""
+import math
+
+import numpy as np
+
+ROOM = (8.0, 3.0, 6.0)
+GUTTER = 3.0 / 1024.0
+
+
+class Patch:
+    __slots__ = ("o", "eu", "ev", "n", "lu", "lv", "gu", "gv", "rect", "cls", "vbase", "tbase", "ntri", "amp", "phase")
+
+    def __init__(self, o, eu, ev, cls):
+        self.o = np.asarray(o, np.float64)
+        self.eu = np.asarray(eu, np.float64)
+        self.ev = np.asarray(ev, np.float64)
+        n = np.cross(self.eu, self.ev)
+        self.lu = float(np.linalg.norm(self.eu))
+        self.lv = float(np.linalg.norm(self.ev))
+        self.n = n / np.linalg.norm(n)
+        self.cls = cls
+
+
+def _room_and_boxes(rng, n_boxes):
+    X, Y, Z = ROOM
+    P = []
+    # room, normals pointing inward
+    P.append(Patch((0, 0, 0), (0, 0, Z), (X, 0, 0), 46))          # floor   n=+y
+    P.append(Patch((0, Y, 0), (X, 0, 0), (0, 0, Z), 44))          # ceiling n=-y
+    P.append(Patch((0, 0, 0), (X, 0, 0), (0, Y, 0), 45))          # z=0 wall n=+z
+    P.append(Patch((0, 0, Z), (0, Y, 0), (X, 0, 0), 45))          # z=Z wall n=-z
+    P.append(Patch((0, 0, 0), (0, Y, 0), (0, 0, Z), 45))          # x=0 wall n=+x
+    P.append(Patch((X, 0, 0), (0, 0, Z), (0, Y, 0), 45))          # x=X wall n=-x
+    if n_boxes <= 0:
+        return P
+    gx, gz = 8, 5
+    cells = [(i, j) for i in range(gx) for j in range(gz)]
+    order = rng.permutation(len(cells))[:n_boxes]
+    cw, cd = (X - 0.4) / gx, (Z - 0.4) / gz
+    for k, ci in enumerate(order):
+        i, j = cells[ci]
+        w = cw * rng.uniform(0.35, 0.8)
+        d = cd * rng.uniform(0.35, 0.8)
+        h = rng.uniform(0.3, 2.2)
+        x0 = 0.2 + i * cw + rng.uniform(0.05, cw - w - 0.05)
+        z0 = 0.2 + j * cd + rng.uniform(0.05, cd - d - 0.05)
+        cls = int(rng.integers(0, 43))
+        x1, z1 = x0 + w, z0 + d
+        # 5 faces, outward normals (no bottom: it would coincide with the floor)
+        P.append(Patch((x0, h, z0), (0, 0, d), (w, 0, 0), cls))       # top  +y
+        P.append(Patch((x0, 0, z0), (0, h, 0), (w, 0, 0), cls))       # z=z0 -z
+        P.append(Patch((x0, 0, z1), (w, 0, 0), (0, h, 0), cls))       # z=z1 +z
+        P.append(Patch((x0, 0, z0), (0, 0, d), (0, h, 0), cls))       # x=x0 -x
+        P.append(Patch((x1, 0, z0), (0, h, 0), (0, 0, d), cls))       # x=x1 +x
+    return P
+
+
+def _allocate_grids(P, T):
+    """choose (gu, gv) per patch, quads ~ area, 2*sum(gu*gv) <= T (remainder fixed by edge splits)."""
+    if T <= 2 * len(P):
+        for p in P:
+            p.gu = p.gv = 1
+        return
+    area = np.array([p.lu * p.lv for p in P])
+    lo, hi = 1e-3, 1e7
+
+    def total(dens):
+        t = 0
+        for p in P:
+            gu = max(1, int(round(p.lu * math.sqrt(dens))))
+            gv = max(1, int(round(p.lv * math.sqrt(dens))))
+            t += 2 * gu * gv
+        return t
+
+    for _ in range(80):
+        mid = math.sqrt(lo * hi)
+        if total(mid) <= T:
+            lo = mid
+        else:
+            hi = mid
+    for p in P:
+        p.gu = max(1, int(round(p.lu * math.sqrt(lo))))
+        p.gv = max(1, int(round(p.lv * math.sqrt(lo))))
+    del area
+
+
+def _pack(P):
+    """shelf-pack chart rectangles (size ~ physical size) into [0,1]^2 with gutters."""
+    order = sorted(range(len(P)), key=lambda i: -P[i].lv)
+    lo, hi = 1e-4, 1.0
+
+    def try_pack(s, assign):
+        x = y = GUTTER
+        row_h = 0.0
+        for i in order:
+            w, h = P[i].lu * s, P[i].lv * s
+            if x + w + GUTTER > 1.0:
+                x = GUTTER
+                y += row_h + GUTTER
+                row_h = 0.0
+            if x + w + GUTTER > 1.0 or y + h + GUTTER > 1.0:
+                return False
+            if assign:
+                P[i].rect = (x, y, w, h)
+            x += w + GUTTER
+            row_h = max(row_h, h)
+        return True
+
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        if try_pack(mid, False):
+            lo = mid
+        else:
+            hi = mid
+    assert try_pack(lo, True)
+
+
+def _patch_heights(p, rng_phase, gu, gv):
+    """smooth displacement along the normal, zero on the patch border (keeps seams closed)."""
+    a = np.linspace(0.0, 1.0, gu + 1)[:, None]
+    b = np.linspace(0.0, 1.0, gv + 1)[None, :]
+    ph = rng_phase
+    f = (np.sin(2 * np.pi * (3.0 * a * p.lu / 2.0 + ph[0])) * np.cos(2 * np.pi * (2.0 * b * p.lv / 2.0 + ph[1]))
+         + 0.5 * np.sin(2 * np.pi * (7.0 * a * p.lu / 2.0 + 5.0 * b * p.lv / 2.0 + ph[2])))
+    win = np.minimum(1.0, 8.0 * np.minimum(np.minimum(a, 1 - a), np.minimum(b, 1 - b)) * np.ones_like(f))
+    return p.amp * f * win
+
+
+def make_scene(T, seed=666, tex_res=1024, n_boxes=40, amp=3e-3):
+    """returns dict: verts [V,3] f32, tris [T,3] i32, tri_uvs [3T,2] f32, hdr [tex_res,tex_res,3] f32,
+    patches (list of Patch), plus per-chart GT material colours."""
+    rng = np.random.default_rng(seed)
+    if T < 12 or T % 2:
+        raise ValueError("T must be even and >= 12")
+    P = _room_and_boxes(rng, 0 if T < 12 + 40 * 10 else n_boxes)
+    _allocate_grids(P, T)
+    _pack(P)
+    verts, tris, tuvs = [], [], []
+    vbase = 0
+    tcount = 0
+    for p in P:
+        p.amp = amp if (p.gu > 1 and p.gv > 1) else 0.0
+        p.phase = rng.uniform(0, 1, 3)
+        gu, gv = p.gu, p.gv
+        a = np.linspace(0.0, 1.0, gu + 1)
+        b = np.linspace(0.0, 1.0, gv + 1)
+        hgt = _patch_heights(p, p.phase, gu, gv)
+        pos = (p.o[None, None, :] + a[:, None, None] * p.eu[None, None, :] + b[None, :, None] * p.ev[None, None, :]
+               + hgt[:, :, None] * p.n[None, None, :])
+        verts.append(pos.reshape(-1, 3))
+        ii, jj = np.meshgrid(np.arange(gu), np.arange(gv), indexing="ij")
+        v00 = (ii * (gv + 1) + jj).reshape(-1) + vbase
+        v10 = ((ii + 1) * (gv + 1) + jj).reshape(-1) + vbase
+        v01 = (ii * (gv + 1) + jj + 1).reshape(-1) + vbase
+        v11 = ((ii + 1) * (gv + 1) + jj + 1).reshape(-1) + vbase
+        t = np.empty((gu * gv, 2, 3), np.int64)
+        t[:, 0] = np.stack([v00, v10, v01], -1)
+        t[:, 1] = np.stack([v11, v01, v10], -1)
+        tris.append(t.reshape(-1, 3))
+        x, y, w, h = p.rect
+        ua = x + w * a
+        vb = y + h * b
+        uvgrid = np.stack(np.meshgrid(ua, vb, indexing="ij"), -1).reshape(-1, 2)
+        tuvs.append(uvgrid[(t.reshape(-1, 3) - vbase).reshape(-1)].reshape(-1, 2))
+        p.vbase, p.tbase, p.ntri = vbase, tcount, 2 * gu * gv
+        vbase += (gu + 1) * (gv + 1)
+        tcount += 2 * gu * gv
+    verts = np.concatenate(verts).astype(np.float64)
+    tris = np.concatenate(tris)
+    tuvs = np.concatenate(tuvs).reshape(-1, 3, 2)
+    # fix-up to exactly T: split triangles at the midpoint of their first edge (stays on the edge -> no crack)
+    rem = T - tris.shape[0]
+    assert rem >= 0
+    if rem:
+        pick = rng.choice(tris.shape[0], size=rem, replace=False)
+        a_, b_, c_ = tris[pick, 0], tris[pick, 1], tris[pick, 2]
+        m = np.arange(rem) + verts.shape[0]
+        verts = np.concatenate([verts, 0.5 * (verts[a_] + verts[b_])])
+        muv = 0.5 * (tuvs[pick, 0] + tuvs[pick, 1])
+        new_t = np.stack([m, b_, c_], -1)
+        new_uv = np.stack([muv, tuvs[pick, 1], tuvs[pick, 2]], 1)
+        tris[pick, 1] = m
+        tuvs[pick, 1] = muv
+        tris = np.concatenate([tris, new_t])
+        tuvs = np.concatenate([tuvs, new_uv])
+    assert tris.shape[0] == T
+    sc = {
+        "verts": verts.astype(np.float32), "tris": tris.astype(np.int32),
+        "tri_uvs": tuvs.reshape(-1, 2).astype(np.float32), "patches": P, "seed": seed, "T": T,
+    }
+    sc["hdr"] = make_hdr_texture(sc, tex_res, seed)
+    return sc
+
+
+def _chart_texels(p, res):
+    """texel centres strictly inside the chart rect -> (rows, cols, a, b) with a,b in (0,1) chart coords."""
+    x, y, w, h = p.rect
+    c0 = int(math.ceil(x * res - 0.5)); c1 = int(math.floor((x + w) * res - 0.5))
+    r0 = int(math.ceil(y * res - 0.5)); r1 = int(math.floor((y + h) * res - 0.5))
+    if c1 < c0 or r1 < r0:
+        return None
+    cols = np.arange(c0, c1 + 1)
+    rows = np.arange(r0, r1 + 1)
+    a = np.clip(((cols + 0.5) / res - x) / w, 0.0, 1.0)
+    b = np.clip(((rows + 0.5) / res - y) / h, 0.0, 1.0)
+    return rows, cols, a, b
+
+
+def _smooth_noise(rng, n_r, n_c, scale):
+    """cheap band-limited noise in [0,1] on an n_r x n_c grid."""
+    gr = max(2, int(n_r / scale) + 2)
+    gc = max(2, int(n_c / scale) + 2)
+    g = rng.uniform(0, 1, (gr, gc))
+    yr = np.linspace(0, gr - 1.001, n_r)
+    xc = np.linspace(0, gc - 1.001, n_c)
+    y0 = yr.astype(int); x0 = xc.astype(int)
+    fy = (yr - y0)[:, None]; fx = (xc - x0)[None, :]
+    return (g[y0][:, x0] * (1 - fy) * (1 - fx) + g[y0 + 1][:, x0] * fy * (1 - fx)
+            + g[y0][:, x0 + 1] * (1 - fy) * fx + g[y0 + 1][:, x0 + 1] * fy * fx)
+
+
+def make_hdr_texture(sc, res, seed=666):
+    rng = np.random.default_rng(seed + 1)
+    hdr = np.zeros((res, res, 3), np.float32)
+    P = sc["patches"]
+    for k, p in enumerate(P):
+        # fill the rect plus its gutter so bilinear taps at chart borders read sane values
+        x, y, w, h = p.rect
+        c0 = max(0, int(math.floor((x - GUTTER / 2) * res))); c1 = min(res, int(math.ceil((x + w + GUTTER / 2) * res)))
+        r0 = max(0, int(math.floor((y - GUTTER / 2) * res))); r1 = min(res, int(math.ceil((y + h + GUTTER / 2) * res)))
+        base = np.exp(rng.normal(-2.0, 0.5)) * rng.uniform(0.6, 1.0, 3)
+        nz = 0.6 + 0.8 * _smooth_noise(rng, r1 - r0, c1 - c0, max(4.0, res / 64.0))
+        hdr[r0:r1, c0:c1, :] = (base[None, None, :] * nz[:, :, None]).astype(np.float32)
+    # emissive rectangles: 4 ceiling lamps + 2 wall windows
+    lamps = [(1, 0.15, 0.2, 0.1, 0.15), (1, 0.55, 0.2, 0.1, 0.15), (1, 0.15, 0.65, 0.1, 0.15), (1, 0.55, 0.65, 0.1, 0.15),
+             (2, 0.3, 0.45, 0.25, 0.35), (5, 0.35, 0.4, 0.3, 0.4)]
+    for (pi, a0, b0, da, db) in lamps:
+        p = P[pi]
+        x, y, w, h = p.rect
+        c0 = int((x + a0 * w) * res); c1 = max(c0 + 1, int((x + (a0 + da) * w) * res))
+        r0 = int((y + b0 * h) * res); r1 = max(r0 + 1, int((y + (b0 + db) * h) * res))
+        hdr[r0:r1, c0:c1, :] = (rng.uniform(50.0, 500.0) * rng.uniform(0.8, 1.0, 3)).astype(np.float32)
+    return hdr
+
+
+def make_texel_gbuffer(sc, res):
+    """pos [res,res,3] (= surface + 1e-2*n_geo, tracer_o3d_irt.py:110), nrm [res,res,3] (= n_geo),
+    valid [res,res] u8.  Invalid texels are all-zero (seams, tracer_o3d_irt.py:137-139)."""
+    pos = np.zeros((res, res, 3), np.float32)
+    nrm = np.zeros((res, res, 3), np.float32)
+    valid = np.zeros((res, res), np.uint8)
+    V = sc["verts"].astype(np.float64)
+    for p in sc["patches"]:
+        ct = _chart_texels(p, res)
+        if ct is None:
+            continue
+        rows, cols, a, b = ct
+        gu, gv = p.gu, p.gv
+        fa = a * gu; fb = b * gv
+        ia = np.minimum(fa.astype(int), gu - 1); ib = np.minimum(fb.astype(int), gv - 1)
+        la = (fa - ia)[None, :]; lb = (fb - ib)[:, None]      # [1,C], [R,1]
+        IA = np.broadcast_to(ia[None, :], (rows.size, cols.size))
+        IB = np.broadcast_to(ib[:, None], (rows.size, cols.size))
+        grid = V[p.vbase:p.vbase + (gu + 1) * (gv + 1)].reshape(gu + 1, gv + 1, 3)
+        v00 = grid[IA, IB]; v10 = grid[IA + 1, IB]; v01 = grid[IA, IB + 1]; v11 = grid[IA + 1, IB + 1]
+        LA = np.broadcast_to(la, IA.shape)[..., None]; LB = np.broadcast_to(lb, IA.shape)[..., None]
+        lower = (LA + LB) <= 1.0
+        # tri0 = (v00, v10, v01): P = v00 + la*(v10-v00) + lb*(v01-v00)
+        p0 = v00 + LA * (v10 - v00) + LB * (v01 - v00)
+        n0 = np.cross(v10 - v00, v01 - v00)
+        # tri1 = (v11, v01, v10): P = v11 + (1-la)*(v01-v11) + (1-lb)*(v10-v11)
+        p1 = v11 + (1 - LA) * (v01 - v11) + (1 - LB) * (v10 - v11)
+        n1 = np.cross(v01 - v11, v10 - v11)
+        pp = np.where(lower, p0, p1)
+        nn = np.where(lower, n0, n1)
+        nn = nn / np.linalg.norm(nn, axis=-1, keepdims=True)
+        rr = rows[:, None]; cc = cols[None, :]
+        pos[rr, cc] = (pp + 1e-2 * nn).astype(np.float32)
+        nrm[rr, cc] = nn.astype(np.float32)
+        valid[rr, cc] = 1
+    return pos, nrm, valid
+
+
+def make_shifts(nt, seed=666):
+    """Per-texel Cranley-Patterson shifts drawn as the reference does: CPU generator, seed 666
+    (generate_ir_texture.py:45-47), torch.rand(512,1,2) per 512-texel batch in batch order
+    (sample_util.py:102 called from tracer_o3d_irt.py:165-168).  Drawing [nt,2] at once from the
+    same generator yields the same stream (row-major fill)."""
+    import torch
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    return torch.rand(nt, 1, 2, generator=g).reshape(nt, 2).numpy()
