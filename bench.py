@@ -1,0 +1,175 @@
+"""bench.py -- IrT generation throughput (Mrays/s) on MI355X, BASELINE.json's metric.
+
+A "step" is one full pass of the hot path (fused sample + BVH trace + shade + reduce kernel,
+texir_irt_generate) over the workload's valid texels at its spp.  Inputs (BVH, radiance texture, texel
+G-buffers, shifts) are resident in HBM before the timed region.
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload c2|c4|c1|tiny]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Multi-GPU: one process per GPU; the compacted valid-texel list is dealt block-cyclically to the ranks
+(strong scaling of ONE texture), each rank writes its texels into a zero-initialised full texture and a single
+RCCL all_reduce(SUM) assembles it (disjoint support) -- inside the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes/ray (canonical-BVH2 visit counts measured
+by the CPU oracle on a sample of the same rays) x rays per launch / mean kernel time (HIP events).
+`cpu_baseline` = the CPU oracle (a port of the reference algorithm; Open3D/Embree is not installable here) timed
+on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (triangles, texel res, radiance-texture res, spp)
+    "tiny": (20000, 128, 256, 64),
+    "c1": (20000, 512, 512, 64),        # configs[0] sizes (reference's CPU-runnable case)
+    "c2": (200000, 2048, 2048, 2048),   # configs[1]: IrT 2048 spp, 2k x 2k, 200k-tri mesh, 1 MI355X
+    "c4": (1000000, 4096, 4096, 2048),  # configs[3]: 4k x 4k, 1M-tri
+}
+HBM_PEAK_GBS = 8000.0
+BLOCK = 4096  # texels per block of the block-cyclic rank partition
+
+
+def algorithmic_bytes_per_ray(counters, spp):
+    """32*n + 36*t + p_hit*(24 + 48) + (24 + 8 + 1 + 12)/N   (canonical BVH2 of the oracle)"""
+    nodes, tris, rays, hits = (float(x) for x in counters)
+    return 32.0 * nodes / rays + 36.0 * tris / rays + (hits / rays) * 72.0 + 45.0 / spp, nodes / rays, tris / rays, hits / rays
+
+
+def cpu_leg(sc0, pos, nrm, valid, shift, spp, budget_s=15.0):
+    """oracle timed on host cores on a bounded sample; also yields the algorithmic bytes/ray."""
+    from oracle import oracle as O
+    osc = O.Scene(sc0["verts"], sc0["tris"], sc0["tri_uvs"], sc0["hdr"])
+    vid = np.argwhere(valid.reshape(-1) > 0)[:, 0]
+    rng = np.random.default_rng(0)
+
+    def run(n_tex):
+        pick = rng.choice(vid, size=min(n_tex, vid.size), replace=False)
+        v = np.zeros(valid.size, np.uint8)
+        v[pick] = 1
+        # compact so the oracle does not scan the whole texture
+        c = O.new_counters()
+        t0 = time.perf_counter()
+        osc.irt_generate(pos.reshape(-1, 3)[pick], nrm.reshape(-1, 3)[pick], None, shift[pick], spp, "uniform", tracer="bvh", counters=c)
+        return time.perf_counter() - t0, c, pick.size
+
+    cores = O.num_threads()
+    dt, c, n = run(max(cores * 4, 32))
+    rate = n * spp / dt
+    n_big = int(max(n, min(vid.size, budget_s * rate / spp)))
+    dt, c, n = run(n_big)
+    return {"value": n * spp / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "%d random valid texels x %d spp (%.1f s) of the same workload, canonical BVH2 oracle, OpenMP" % (n, spp, dt)}, c
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from texir_code_amd import scene as S, synth, dist_util
+    T, res, tex_res, spp = WORKLOADS[args.workload]
+    if args.spp:
+        spp = args.spp
+    sc0 = synth.make_scene(T, seed=666, tex_res=tex_res)
+    pos, nrm, valid = synth.make_texel_gbuffer(sc0, res)
+    shift = synth.make_shifts(res * res)
+    t0 = time.perf_counter()
+    sc = S.Scene(sc0["verts"], sc0["tris"], sc0["tri_uvs"], sc0["hdr"], device=local)
+    build_s = time.perf_counter() - t0
+    d_pos = torch.from_numpy(pos).to(dev).reshape(-1, 3)
+    d_nrm = torch.from_numpy(nrm).to(dev).reshape(-1, 3)
+    d_shift = torch.from_numpy(shift).to(dev)
+    ids_all = torch.nonzero(torch.from_numpy(valid.reshape(-1)) > 0)[:, 0].to(torch.int32)
+    ids = dist_util.shard_block_cyclic(ids_all, rank, world, BLOCK).to(dev)
+    n_valid = int(ids_all.numel())
+    irr = torch.zeros((res * res, 3), device=dev)
+
+    def step():
+        irr.zero_()
+        sc.irt_generate(d_pos, d_nrm, d_shift, spp, "uniform", texel_ids=ids, out=irr)
+        if world > 1:
+            dist.all_reduce(irr)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        irr.zero_()
+        ev[k][0].record()            # HIP events on the stream the kernel is launched on (torch's current stream)
+        sc.irt_generate(d_pos, d_nrm, d_shift, spp, "uniform", texel_ids=ids, out=irr)
+        ev[k][1].record()
+        if world > 1:
+            dist.all_reduce(irr)
+    barrier()
+    dt = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        rays_per_step = n_valid * spp
+        value = rays_per_step * args.steps / dt / 1e6
+        out = {
+            "metric": "IrT generation throughput", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: IrT %d spp, %dx%d texels (%d valid), %d-tri synthetic indoor mesh, %dx%d RGB32F radiance texture"
+                       % (args.workload, spp, res, res, n_valid, T, tex_res, tex_res),
+                       "parallelism": "texel-sharded x%d (block-cyclic %d) + RCCL all_reduce" % (world, BLOCK) if world > 1 else "single GPU",
+                       "bvh_build_s": round(build_s, 2), "scene": sc.info()},
+        }
+        rays_this_rank = int(ids.numel()) * spp
+        if not args.no_cpu:
+            cpu, counters = cpu_leg(sc0, pos, nrm, valid, shift, spp)
+            bpr, nbar, tbar, phit = algorithmic_bytes_per_ray(counters, spp)
+            achieved = bpr * rays_this_rank / (kern_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.workload)
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "kernel": "irt_kernel", "kernel_ms": round(kern_ms, 3), "bytes_per_ray": round(bpr, 1),
+                               "nodes_per_ray": round(nbar, 2), "tris_per_ray": round(tbar, 2), "p_hit": round(phit, 4),
+                               "rays_per_launch": rays_this_rank}
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

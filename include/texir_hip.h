@@ -1,0 +1,114 @@
+/*
+ * texir_hip.h -- C-ABI of libtexir_hip.so: the MI355X (gfx950) implementation of TexIR's
+ * irradiance-texture + material-estimation hot path.
+ *
+ * The reference (LZleejean/TexIR_code) is pure Python and has no FFI of its own; its seams
+ * on this path are Python-level.  Each entry point below replaces one of those
+ * seams and cites it.  A reference maintainer binds them with ctypes (INTEGRATION.md shows the
+ * stubs).  Conventions:
+ *   - every function returns 0 on success, <0 on error; texir_last_error() gives the
+ *     thread-local message.  Nothing falls back to a CPU path.
+ *   - `const float* x /+dev+/` pointers are caller-owned, contiguous DEVICE pointers
+ *     (tensor.data_ptr()); host pointers are marked /+host+/.
+ *   - launches are asynchronous on the hipStream_t passed as `stream` (void*; 0 = null stream).
+ *   - a texir_scene is immutable after creation (except texir_scene_set_texture) and may be
+ *     shared by host threads; one handle per device.
+ */
+#ifndef TEXIR_HIP_H
+#define TEXIR_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TEXIR_OK 0
+#define TEXIR_ERR_INVALID (-1)
+#define TEXIR_ERR_HIP (-2)
+#define TEXIR_ERR_NOMEM (-3)
+
+/* sampling modes of utils/sample_util.py:115-143 */
+#define TEXIR_MODE_UNIFORM 0
+#define TEXIR_MODE_COSINE 1
+#define TEXIR_MODE_IMPORTANCE 2
+
+#if defined(__GNUC__)
+#define TEXIR_API __attribute__((visibility("default")))
+#else
+#define TEXIR_API
+#endif
+
+typedef struct texir_scene texir_scene;
+
+TEXIR_API const char* texir_last_error(void);
+TEXIR_API int texir_version(void);
+
+/* Replaces TracerO3d.__init__ scene part (models/tracer_o3d_irt.py:75-89) and MaterialModel.__init__
+ * (models/mat_nvdiffrast.py:87-101): o3d.t.geometry.RaycastingScene().add_triangles(mesh) + the CPU-resident
+ * radiance texture.  Builds the BVH on the host and uploads it.
+ *   verts   [V,3]  f32 host      tris [T,3] i32 host (primitive id = row index, as in Open3D)
+ *   tri_uvs [3T,2] f32 host      per-corner uvs = np.asarray(trianglemesh.triangle_uvs)
+ *   hdr_tex [Ht,Wt,3] f32 host   ALREADY BGR->RGB, vertically flipped and scaled by 2^hdr_exposure exactly as
+ *                                tracer_o3d_irt.py:77-81 does. */
+TEXIR_API int texir_scene_create(const float* verts /*host*/, int32_t V, const int32_t* tris /*host*/, int32_t T,
+                       const float* tri_uvs /*host*/, const float* hdr_tex /*host*/, int32_t Ht, int32_t Wt,
+                       int32_t device, texir_scene** out);
+TEXIR_API int texir_scene_destroy(texir_scene* scene);
+
+/* Replaces the temporary `self.texture = torch.where(intensity>=0.5, ...)` swap of stage -1
+ * (models/mat_nvdiffrast.py:141-150).  tex [Ht,Wt,3] f32; is_device selects pointer kind. */
+TEXIR_API int texir_scene_set_texture(texir_scene* scene, const float* tex, int32_t Ht, int32_t Wt, int32_t is_device, void* stream);
+
+/* out[0]=inner nodes, [1]=triangles, [2]=max depth, [3]=node bytes, [4]=triangle bytes, [5]=uv bytes,
+ * [6]=texture bytes, [7]=device */
+TEXIR_API int texir_scene_info(const texir_scene* scene, int64_t out[8]);
+
+/* Replaces query_irf (models/tracer_o3d_irt.py:240-269, models/mat_nvdiffrast.py:292-320):
+ * closest hit (Embree semantics: t>0, t in units of |dir|), hit mask t>t_min (reference: 1e-4) & finite,
+ * barycentric clip, corner-uv interpolation, bilinear/border/align_corners=False fetch of the radiance
+ * texture, misses -> 0.   org,dir [R,3] dev -> radiance [R,3] dev.
+ * Optional raw intersection outputs (the cast_rays dict, tracer_o3d_irt.py:245-251): t_hit [R] (inf on miss),
+ * prim_id [R] (0xFFFFFFFF on miss), prim_uv [R,2]; pass NULL to skip. */
+TEXIR_API int texir_trace_shade(const texir_scene* scene, const float* org /*dev*/, const float* dir /*dev*/, int64_t R,
+                      float t_min, float* radiance /*dev*/, float* t_hit /*dev, nullable*/,
+                      uint32_t* prim_id /*dev, nullable*/, float* prim_uv /*dev, nullable*/, void* stream);
+
+/* Replaces generate_dir (utils/sample_util.py:63-146) with pre_mode='Hammersley'.  The per-point random
+ * shift (torch.rand(b,1,2) on the CPU generator, :102) is an INPUT so that parity is exact.
+ *   normals [b,3] dev, roughness [b] dev (importance only, else NULL), shift [b,2] dev -> L [b,N,3] dev */
+TEXIR_API int texir_generate_dir(const float* normals /*dev*/, const float* roughness /*dev, nullable*/,
+                       const float* shift /*dev*/, int64_t b, int32_t N, int32_t mode, float* L /*dev*/, void* stream);
+
+/* Replaces the hot loop of TracerO3d.forward (models/tracer_o3d_irt.py:156-178): for every listed texel
+ *   E = (2*pi/N) * sum_i L(pos, d_i) * clamp(nrm . d_i, 0, 1),  d_i = generate_dir(nrm, N, mode)[i]
+ * fused in one kernel (sample + trace + shade + reduce).
+ *   pos,nrm [Nt,3] dev (pos already offset by +1e-2*n, :110), shift [Nt,2] dev
+ *   texel_ids [n_ids] i32 dev: the texels to compute (NULL => all Nt, n_ids ignored).  Seam texels
+ *     (index texture all-zero, :137-139,176-178) are simply not listed; irr must be zero-initialised by the caller.
+ *   irr [Nt,3] dev: only listed texels are written.
+ *   stats [4] u64 dev, nullable: += rays, 64-byte node fetches, triangle tests, hits. */
+TEXIR_API int texir_irt_generate(const texir_scene* scene, const float* pos /*dev*/, const float* nrm /*dev*/,
+                       const float* shift /*dev*/, const int32_t* texel_ids /*dev, nullable*/, int64_t n_ids,
+                       int64_t Nt, int32_t N, int32_t mode, float* irr /*dev*/, uint64_t* stats /*dev, nullable*/,
+                       void* stream);
+
+/* Replaces MaterialModel.render + specular_reflectance (models/mat_nvdiffrast.py:201-249, 260-279), forward:
+ *   rgb = irr*albedo/pi + (1/S) sum_i Ls_i * w_i(roughness)        
+ * normal,albedo,points,irr [P,3] dev; rough [P] dev; cam [3] dev; shift [P,2] dev (GGX sample shift, as above)
+ * Ls_ws [P,S,3] dev, nullable: traced radiance saved for texir_spec_backward. */
+TEXIR_API int texir_spec_forward(const texir_scene* scene, const float* normal, const float* albedo, const float* rough,
+                       const float* points, const float* irr, const float* cam, const float* shift, int64_t P,
+                       int32_t S, float* rgb /*dev [P,3]*/, float* Ls_ws /*dev, nullable*/, void* stream);
+
+/* Analytic backward of the above (what autograd computes in the reference): given d_rgb [P,3],
+ *   d_albedo [P,3] = d_rgb*irr/pi ;  d_rough [P] = sum_c d_rgb_c * (1/S) sum_i Ls_ic * dw_i/dr
+ * (gradient through a=r^2 -> cos/sin theta -> h -> vdh -> l -> ndl, ndh and through k=(r+1)^2/8; Ls constant,
+ * torch clamp sub-gradients).  Either output may be NULL. */
+TEXIR_API int texir_spec_backward(const float* normal, const float* rough, const float* points, const float* irr,
+                        const float* cam, const float* shift, const float* Ls_ws, const float* d_rgb, int64_t P,
+                        int32_t S, float* d_albedo /*dev, nullable*/, float* d_rough /*dev, nullable*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

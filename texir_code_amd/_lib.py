@@ -1,0 +1,77 @@
+"""ctypes loader for libtexir_hip.so (C-ABI declared in include/texir_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, a TexirError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtexir_hip.so")
+_LIB = None
+
+EXPORTS = [
+    "texir_last_error", "texir_version", "texir_scene_create", "texir_scene_destroy", "texir_scene_set_texture",
+    "texir_scene_info", "texir_trace_shade", "texir_generate_dir", "texir_irt_generate", "texir_spec_forward",
+    "texir_spec_backward", "texir_loss_forward", "texir_loss_backward", "texir_tex_fetch_forward", "texir_tex_fetch_backward",
+    "texir_adam_step", "texir_raster_cube",
+]
+
+
+class TexirError(RuntimeError):
+    pass
+
+
+def build():
+    """compile libtexir_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc")])
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise TexirError("libtexir_hip.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "-- there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+        L.texir_last_error.restype = C.c_char_p
+        L.texir_version.restype = i32
+        sig = {
+            "texir_scene_create": [vp, i32, vp, i32, vp, vp, i32, i32, i32, C.POINTER(vp)],
+            "texir_scene_destroy": [vp],
+            "texir_scene_set_texture": [vp, vp, i32, i32, i32, vp],
+            "texir_scene_info": [vp, vp],
+            "texir_trace_shade": [vp, vp, vp, i64, f32, vp, vp, vp, vp, vp],
+            "texir_generate_dir": [vp, vp, vp, i64, i32, i32, vp, vp],
+            "texir_irt_generate": [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp, vp, vp],
+            "texir_spec_forward": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp],
+            "texir_spec_backward": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp],
+        }
+        for name, args in sig.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = i32
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise TexirError("libtexir_hip: %s (code %d)" % (lib().texir_last_error().decode(), rc))
+
+
+def ptr(t):
+    """device/host pointer of a contiguous tensor / ndarray, or None"""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        assert t.is_contiguous(), "tensor must be contiguous"
+        return C.c_void_p(t.data_ptr())
+    return t.ctypes.data_as(C.c_void_p)
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,188 @@
+// Binned-SAH BVH2 builder (host, multi-threaded over the top subtrees) emitting the 64-byte
+// two-child-box node layout consumed by the gfx950 traversal kernels (see bvh_build.h).
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <future>
+#include <memory>
+#include <thread>
+
+namespace texir {
+namespace {
+
+struct Box {
+    float mn[3], mx[3];
+    void reset() { for (int a = 0; a < 3; a++) { mn[a] = FLT_MAX; mx[a] = -FLT_MAX; } }
+    void grow(const Box& b) { for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], b.mn[a]); mx[a] = std::max(mx[a], b.mx[a]); } }
+    void grow(const float* p) { for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], p[a]); mx[a] = std::max(mx[a], p[a]); } }
+    float half_area() const {
+        float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Tmp {
+    Box box;
+    int first = 0, count = 0;           // leaf payload
+    std::unique_ptr<Tmp> l, r;
+    int depth_below = 0;
+};
+
+struct Ctx {
+    const std::vector<Box>* tb;
+    const std::vector<float>* cen;      // [T,3]
+    std::vector<int32_t>* order;
+};
+
+constexpr int kBins = 32;
+
+std::unique_ptr<Tmp> build(const Ctx& c, int first, int count, int depth, int par_levels)
+{
+    std::unique_ptr<Tmp> n(new Tmp);
+    Box cb; cb.reset(); n->box.reset();
+    auto& ord = *c.order;
+    for (int i = first; i < first + count; i++) {
+        int p = ord[i];
+        n->box.grow((*c.tb)[p]);
+        cb.grow(&(*c.cen)[3 * (size_t)p]);
+    }
+    if (count <= kMaxLeaf) { n->first = first; n->count = count; return n; }
+
+    int mid = -1;
+    // depth guard: a balanced split always terminates within ceil(log2(count)) further levels
+    bool force_median = depth + (int)std::ceil(std::log2((double)count)) >= kMaxDepth - 2;
+    if (!force_median) {
+        int best_axis = -1, best_split = -1; float best_cost = FLT_MAX;
+        for (int a = 0; a < 3; a++) {
+            float ext = cb.mx[a] - cb.mn[a];
+            if (!(ext > 0.f)) continue;
+            float scale = (float)kBins / ext;
+            int cnt[kBins]; Box bb[kBins];
+            for (int b = 0; b < kBins; b++) { cnt[b] = 0; bb[b].reset(); }
+            for (int i = first; i < first + count; i++) {
+                int p = ord[i];
+                int b = std::min(kBins - 1, std::max(0, (int)(((*c.cen)[3 * (size_t)p + a] - cb.mn[a]) * scale)));
+                cnt[b]++; bb[b].grow((*c.tb)[p]);
+            }
+            float la[kBins]; int lc[kBins];
+            Box acc; acc.reset(); int k = 0;
+            for (int b = 0; b < kBins - 1; b++) { k += cnt[b]; if (cnt[b]) acc.grow(bb[b]); lc[b] = k; la[b] = k ? acc.half_area() : 0.f; }
+            acc.reset(); k = 0;
+            for (int b = kBins - 1; b > 0; b--) {
+                k += cnt[b]; if (cnt[b]) acc.grow(bb[b]);
+                int s = b - 1;
+                if (lc[s] == 0 || k == 0) continue;
+                float cost = la[s] * (float)lc[s] + acc.half_area() * (float)k;
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = s; }
+            }
+        }
+        if (best_axis >= 0) {
+            float scale = (float)kBins / (cb.mx[best_axis] - cb.mn[best_axis]);
+            float base = cb.mn[best_axis];
+            auto it = std::partition(ord.begin() + first, ord.begin() + first + count, [&](int p) {
+                int b = std::min(kBins - 1, std::max(0, (int)(((*c.cen)[3 * (size_t)p + best_axis] - base) * scale)));
+                return b <= best_split;
+            });
+            mid = (int)(it - ord.begin());
+        }
+    }
+    if (mid <= first || mid >= first + count) {
+        // median split along the widest centroid axis
+        int a = 0; float e = -1.f;
+        for (int k = 0; k < 3; k++) { float x = cb.mx[k] - cb.mn[k]; if (x > e) { e = x; a = k; } }
+        mid = first + count / 2;
+        std::nth_element(ord.begin() + first, ord.begin() + mid, ord.begin() + first + count,
+                         [&](int p, int q) { return (*c.cen)[3 * (size_t)p + a] < (*c.cen)[3 * (size_t)q + a]; });
+    }
+    if (par_levels > 0 && count > 50000) {
+        auto fut = std::async(std::launch::async, [&, first, mid, depth, par_levels]() { return build(c, first, mid - first, depth + 1, par_levels - 1); });
+        n->r = build(c, mid, first + count - mid, depth + 1, par_levels - 1);
+        n->l = fut.get();
+    } else {
+        n->l = build(c, first, mid - first, depth + 1, 0);
+        n->r = build(c, mid, first + count - mid, depth + 1, 0);
+    }
+    n->depth_below = 1 + std::max(n->l->depth_below, n->r->depth_below);
+    return n;
+}
+
+inline int32_t leaf_code(const Tmp* t) { return ~(int32_t)(((uint32_t)t->first << 3) | (uint32_t)(t->count - 1)); }
+
+void put_box(GpuNode& g, int slot, const Box& b)
+{
+    float* xy = slot == 0 ? g.n0 : g.n1;
+    xy[0] = b.mn[0]; xy[1] = b.mx[0]; xy[2] = b.mn[1]; xy[3] = b.mx[1];
+    g.n2[2 * slot] = b.mn[2]; g.n2[2 * slot + 1] = b.mx[2];
+}
+
+// depth-first emission: the first child of every inner node directly follows it in memory
+int32_t emit(const Tmp* t, std::vector<GpuNode>& out)
+{
+    int32_t idx = (int32_t)out.size();
+    out.emplace_back();
+    const Tmp* ch[2] = {t->l.get(), t->r.get()};
+    int32_t code[2];
+    for (int s = 0; s < 2; s++) {
+        put_box(out[idx], s, ch[s]->box);
+        code[s] = ch[s]->count ? leaf_code(ch[s]) : emit(ch[s], out);
+    }
+    out[idx].c[0] = code[0]; out[idx].c[1] = code[1]; out[idx].c[2] = out[idx].c[3] = 0;
+    return idx;
+}
+
+}  // namespace
+
+void build_bvh(const float* verts, int V, const int32_t* tris, int T, const float* tri_uvs, BvhHost& out)
+{
+    (void)V;
+    std::vector<Box> tb((size_t)T);
+    std::vector<float> cen(3 * (size_t)T);
+    std::vector<int32_t> order((size_t)T);
+    for (int p = 0; p < T; p++) {
+        tb[p].reset();
+        for (int k = 0; k < 3; k++) tb[p].grow(verts + 3 * (size_t)tris[3 * (size_t)p + k]);
+        for (int a = 0; a < 3; a++) cen[3 * (size_t)p + a] = 0.5f * (tb[p].mn[a] + tb[p].mx[a]);
+        order[p] = p;
+    }
+    Ctx c{&tb, &cen, &order};
+    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    int par_levels = 0;
+    while ((1u << par_levels) < hw && par_levels < 5) par_levels++;
+    std::unique_ptr<Tmp> root = build(c, 0, T, 0, par_levels);
+
+    out.nodes.clear();
+    out.nodes.reserve((size_t)T);
+    if (root->count) {
+        // whole mesh fits one leaf: synthesise a root whose second child can never be entered
+        GpuNode g; std::memset(&g, 0, sizeof(g));
+        put_box(g, 0, root->box);
+        // second slot: a point box far outside any scene; if a ray ever grazed it the (duplicate) leaf is harmless
+        Box far; for (int a = 0; a < 3; a++) far.mn[a] = far.mx[a] = 1e30f;
+        put_box(g, 1, far);
+        g.c[0] = leaf_code(root.get()); g.c[1] = g.c[0];
+        out.nodes.push_back(g);
+        out.max_depth = 1;
+    } else {
+        emit(root.get(), out.nodes);
+        out.max_depth = root->depth_below;
+    }
+    out.tris.resize((size_t)T);
+    out.uvs.resize((size_t)T);
+    for (int i = 0; i < T; i++) {
+        int p = order[i];
+        const float* a = verts + 3 * (size_t)tris[3 * (size_t)p];
+        const float* b = verts + 3 * (size_t)tris[3 * (size_t)p + 1];
+        const float* cc = verts + 3 * (size_t)tris[3 * (size_t)p + 2];
+        GpuTri& g = out.tris[i];
+        for (int k = 0; k < 3; k++) { g.v0[k] = a[k]; g.e1[k] = b[k] - a[k]; g.e2[k] = cc[k] - a[k]; }
+        g.prim = (uint32_t)p; g.pad1 = g.pad2 = 0.f;
+        GpuTriUV& u = out.uvs[i];
+        std::memcpy(u.uv, tri_uvs + 6 * (size_t)p, sizeof(float) * 6);
+        u.uv[6] = u.uv[7] = 0.f;
+    }
+}
+
+}  // namespace texir

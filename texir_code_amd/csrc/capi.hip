@@ -1,0 +1,153 @@
+// C-ABI of libtexir_hip.so (include/texir_hip.h).  Thin: argument checks, handle ownership, launches.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/texir_hip.h"
+#include "bvh_build.h"
+#include "kernels.h"
+
+using namespace texir;
+
+struct texir_scene {
+    int device = 0;
+    SceneDev dev{};
+    void* d_nodes = nullptr; void* d_tris = nullptr; void* d_uvs = nullptr; float* d_tex = nullptr;
+    int64_t n_nodes = 0, n_tris = 0, max_depth = 0;
+    size_t tex_bytes = 0;
+};
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                    \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return fail(TEXIR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" {
+
+const char* texir_last_error(void) { return g_err.c_str(); }
+int texir_version(void) { return 100; }
+
+int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32_t T, const float* tri_uvs, const float* hdr_tex,
+                       int32_t Ht, int32_t Wt, int32_t device, texir_scene** out)
+{
+    if (!verts || !tris || !tri_uvs || !hdr_tex || !out) return fail(TEXIR_ERR_INVALID, "texir_scene_create: null argument");
+    if (V <= 0 || T <= 0 || Ht <= 0 || Wt <= 0) return fail(TEXIR_ERR_INVALID, "texir_scene_create: empty mesh or texture");
+    if (T >= (1 << 28)) return fail(TEXIR_ERR_INVALID, "texir_scene_create: too many triangles");
+    for (int64_t i = 0; i < 3 * (int64_t)T; i++)
+        if (tris[i] < 0 || tris[i] >= V) return fail(TEXIR_ERR_INVALID, "texir_scene_create: triangle index %d out of range", (int)tris[i]);
+    HIP_TRY(hipSetDevice(device));
+    BvhHost h;
+    try { build_bvh(verts, V, tris, T, tri_uvs, h); } catch (const std::bad_alloc&) { return fail(TEXIR_ERR_NOMEM, "BVH build: out of host memory"); }
+    texir_scene* s = new (std::nothrow) texir_scene;
+    if (!s) return fail(TEXIR_ERR_NOMEM, "out of host memory");
+    s->device = device; s->n_nodes = (int64_t)h.nodes.size(); s->n_tris = T; s->max_depth = h.max_depth;
+    s->tex_bytes = sizeof(float) * 3 * (size_t)Ht * Wt;
+    auto bail = [&](hipError_t e, const char* what) { texir_scene_destroy(s); return fail(TEXIR_ERR_HIP, "%s: %s", what, hipGetErrorString(e)); };
+    hipError_t e;
+    if ((e = hipMalloc(&s->d_nodes, h.nodes.size() * sizeof(GpuNode))) != hipSuccess) return bail(e, "hipMalloc nodes");
+    if ((e = hipMalloc(&s->d_tris, h.tris.size() * sizeof(GpuTri))) != hipSuccess) return bail(e, "hipMalloc tris");
+    if ((e = hipMalloc(&s->d_uvs, h.uvs.size() * sizeof(GpuTriUV))) != hipSuccess) return bail(e, "hipMalloc uvs");
+    if ((e = hipMalloc((void**)&s->d_tex, s->tex_bytes)) != hipSuccess) return bail(e, "hipMalloc texture");
+    if ((e = hipMemcpy(s->d_nodes, h.nodes.data(), h.nodes.size() * sizeof(GpuNode), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload nodes");
+    if ((e = hipMemcpy(s->d_tris, h.tris.data(), h.tris.size() * sizeof(GpuTri), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload tris");
+    if ((e = hipMemcpy(s->d_uvs, h.uvs.data(), h.uvs.size() * sizeof(GpuTriUV), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload uvs");
+    if ((e = hipMemcpy(s->d_tex, hdr_tex, s->tex_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload texture");
+    s->dev.nodes = (const float4*)s->d_nodes; s->dev.tris = (const float4*)s->d_tris; s->dev.uvs = (const float4*)s->d_uvs;
+    s->dev.tex = s->d_tex; s->dev.Ht = Ht; s->dev.Wt = Wt;
+    *out = s;
+    return TEXIR_OK;
+}
+
+int texir_scene_destroy(texir_scene* s)
+{
+    if (!s) return TEXIR_OK;
+    (void)hipSetDevice(s->device);
+    if (s->d_nodes) (void)hipFree(s->d_nodes);
+    if (s->d_tris) (void)hipFree(s->d_tris);
+    if (s->d_uvs) (void)hipFree(s->d_uvs);
+    if (s->d_tex) (void)hipFree(s->d_tex);
+    delete s;
+    return TEXIR_OK;
+}
+
+int texir_scene_set_texture(texir_scene* s, const float* tex, int32_t Ht, int32_t Wt, int32_t is_device, void* stream)
+{
+    if (!s || !tex) return fail(TEXIR_ERR_INVALID, "texir_scene_set_texture: null argument");
+    if (Ht != s->dev.Ht || Wt != s->dev.Wt) return fail(TEXIR_ERR_INVALID, "texir_scene_set_texture: size %dx%d != scene texture %dx%d", Ht, Wt, s->dev.Ht, s->dev.Wt);
+    HIP_TRY(hipMemcpyAsync(s->d_tex, tex, s->tex_bytes, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
+int texir_scene_info(const texir_scene* s, int64_t out[8])
+{
+    if (!s || !out) return fail(TEXIR_ERR_INVALID, "texir_scene_info: null argument");
+    out[0] = s->n_nodes; out[1] = s->n_tris; out[2] = s->max_depth; out[3] = s->n_nodes * (int64_t)sizeof(GpuNode);
+    out[4] = s->n_tris * (int64_t)sizeof(GpuTri); out[5] = s->n_tris * (int64_t)sizeof(GpuTriUV); out[6] = (int64_t)s->tex_bytes; out[7] = s->device;
+    return TEXIR_OK;
+}
+
+int texir_trace_shade(const texir_scene* s, const float* org, const float* dir, int64_t R, float t_min, float* radiance, float* t_hit,
+                      uint32_t* prim_id, float* prim_uv, void* stream)
+{
+    if (!s || !org || !dir || !radiance) return fail(TEXIR_ERR_INVALID, "texir_trace_shade: null argument");
+    if (R < 0) return fail(TEXIR_ERR_INVALID, "texir_trace_shade: negative ray count");
+    HIP_TRY(launch_trace_shade(s->dev, org, dir, R, t_min, radiance, t_hit, prim_id, prim_uv, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
+int texir_generate_dir(const float* normals, const float* roughness, const float* shift, int64_t b, int32_t N, int32_t mode, float* L, void* stream)
+{
+    if (!normals || !shift || !L) return fail(TEXIR_ERR_INVALID, "texir_generate_dir: null argument");
+    if (mode < 0 || mode > 2) return fail(TEXIR_ERR_INVALID, "texir_generate_dir: unknown mode %d", mode);
+    if (mode == TEXIR_MODE_IMPORTANCE && !roughness) return fail(TEXIR_ERR_INVALID, "texir_generate_dir: importance mode needs roughness");
+    if (b < 0 || N < 0) return fail(TEXIR_ERR_INVALID, "texir_generate_dir: negative size");
+    HIP_TRY(launch_gen_dir(normals, roughness, shift, b, N, mode, L, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
+int texir_irt_generate(const texir_scene* s, const float* pos, const float* nrm, const float* shift, const int32_t* texel_ids, int64_t n_ids,
+                       int64_t Nt, int32_t N, int32_t mode, float* irr, uint64_t* stats, void* stream)
+{
+    if (!s || !pos || !nrm || !shift || !irr) return fail(TEXIR_ERR_INVALID, "texir_irt_generate: null argument");
+    if (mode < 0 || mode > 1) return fail(TEXIR_ERR_INVALID, "texir_irt_generate: mode must be uniform(0) or cosine(1), got %d", mode);
+    if (N <= 0 || Nt < 0 || n_ids < 0) return fail(TEXIR_ERR_INVALID, "texir_irt_generate: bad sizes N=%d Nt=%lld n_ids=%lld", N, (long long)Nt, (long long)n_ids);
+    if (Nt >= (1ll << 31)) return fail(TEXIR_ERR_INVALID, "texir_irt_generate: Nt too large");
+    int64_t n = texel_ids ? n_ids : Nt;
+    HIP_TRY(launch_irt(s->dev, pos, nrm, shift, texel_ids, n, N, mode, irr, (unsigned long long*)stats, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
+int texir_spec_forward(const texir_scene* s, const float* normal, const float* albedo, const float* rough, const float* points, const float* irr,
+                       const float* cam, const float* shift, int64_t P, int32_t S, float* rgb, float* Ls_ws, void* stream)
+{
+    if (!s || !normal || !albedo || !rough || !points || !irr || !cam || !shift || !rgb) return fail(TEXIR_ERR_INVALID, "texir_spec_forward: null argument");
+    if (P < 0 || S <= 0) return fail(TEXIR_ERR_INVALID, "texir_spec_forward: bad sizes P=%lld S=%d", (long long)P, S);
+    HIP_TRY(launch_spec_fwd(s->dev, normal, albedo, rough, points, irr, cam, shift, P, S, rgb, Ls_ws, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
+int texir_spec_backward(const float* normal, const float* rough, const float* points, const float* irr, const float* cam, const float* shift,
+                        const float* Ls_ws, const float* d_rgb, int64_t P, int32_t S, float* d_albedo, float* d_rough, void* stream)
+{
+    if (!normal || !rough || !points || !irr || !cam || !shift || !Ls_ws || !d_rgb) return fail(TEXIR_ERR_INVALID, "texir_spec_backward: null argument");
+    if (P < 0 || S <= 0) return fail(TEXIR_ERR_INVALID, "texir_spec_backward: bad sizes P=%lld S=%d", (long long)P, S);
+    HIP_TRY(launch_spec_bwd(normal, rough, points, irr, cam, shift, Ls_ws, d_rgb, P, S, d_albedo, d_rough, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
+}  // extern "C"

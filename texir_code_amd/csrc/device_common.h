@@ -1,0 +1,201 @@
+// Device-side building blocks shared by the gfx950 kernels: Hammersley/Cranley-Patterson sampling,
+// local frames, hemisphere/GGX directions (utils/sample_util.py:28-146), per-lane BVH2 traversal
+// with an LDS-resident stack, and the query_irf hit shader (models/tracer_o3d_irt.py:248-267).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bvh_build.h"
+
+namespace texir {
+
+struct SceneDev {
+    const float4* nodes;   // GpuNode as 4 x float4
+    const float4* tris;    // GpuTri as 3 x float4
+    const float4* uvs;     // GpuTriUV as 2 x float4
+    const float* tex;      // [Ht,Wt,3]
+    int Ht, Wt;
+};
+
+constexpr int kBlock = 256;          // 4 waves
+constexpr int kLdsStack = 24;        // entries per lane kept in LDS (24 KiB per block)
+constexpr int kOvfStack = kMaxDepth + 4 - kLdsStack;
+constexpr int kSentinel = 0x7FFFFFFF;
+
+// ------------------------------------------------------------------------------------------------
+// sampling -- kept free of fused multiply-adds so that it tracks the reference's separately rounded
+// float32 torch ops (utils/sample_util.py) as closely as the libm differences allow
+// ------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ float ham0(uint32_t i, uint32_t N) { return (float)((double)i / (double)N); }   // sample_util.py:41
+__device__ __forceinline__ float ham1(uint32_t i) { return (float)((double)__brev(i) * 2.3283064365386963e-10); }  // :28-38
+
+__device__ __forceinline__ float shift_wrap_clamp(float s, float shift)
+{
+    s = s + shift;                       // :103
+    if (s > 1.f) s = s - 1.f;            // :104-105 (strict >)
+    if (s < 0.f) s = s + 1.f;            // :106-107
+    return fminf(fmaxf(s, 1e-6f), (float)(1.0 - 1e-6));   // :108
+}
+
+struct Frame { float n[3], U[3], V[3]; };
+
+__device__ __forceinline__ Frame make_frame(float nx, float ny, float nz)
+{
+    Frame f;
+    // :84 axis choice on the RAW normal; :86-91 x/(|x|+1e-6)
+    float ax = 1.f, ay = 0.f;
+    if (fabsf(nx) > 0.99f) { ax = 0.f; ay = 1.f; }
+    float ln = sqrtf(nx * nx + ny * ny + nz * nz) + 1e-6f;
+    f.n[0] = nx / ln; f.n[1] = ny / ln; f.n[2] = nz / ln;
+    float c0 = ay * f.n[2] - 0.f * f.n[1], c1 = 0.f * f.n[0] - ax * f.n[2], c2 = ax * f.n[1] - ay * f.n[0];
+    float lc = sqrtf(c0 * c0 + c1 * c1 + c2 * c2) + 1e-6f;
+    f.U[0] = c0 / lc; f.U[1] = c1 / lc; f.U[2] = c2 / lc;
+    float e0 = f.n[1] * f.U[2] - f.n[2] * f.U[1], e1 = f.n[2] * f.U[0] - f.n[0] * f.U[2], e2 = f.n[0] * f.U[1] - f.n[1] * f.U[0];
+    float le = sqrtf(e0 * e0 + e1 * e1 + e2 * e2) + 1e-6f;
+    f.V[0] = e0 / le; f.V[1] = e1 / le; f.V[2] = e2 / le;
+    return f;
+}
+
+// cos/sin of the polar angle for the three modes (:115-143)
+__device__ __forceinline__ void polar(int mode, float s0, float rough, float& ct, float& st)
+{
+    if (mode == 0) { ct = 1.0f - s0; st = sqrtf(1.0f - ct * ct); }
+    else if (mode == 1) { ct = sqrtf(1.0f - s0); st = sqrtf(1.0f - ct * ct); }
+    else {
+        float a = rough * rough;
+        ct = sqrtf((1.0f - s0) / (1.0f + (a * a - 1.f) * s0));
+        ct = fminf(fmaxf(ct, -1.0f + 1e-6f), 1.0f - 1e-6f);
+        st = fminf(fmaxf(sqrtf(1.0f - ct * ct), -1.0f + 1e-6f), 1.0f - 1e-6f);
+    }
+}
+
+__device__ __forceinline__ void sample_dir(int mode, float s0, float s1, float rough, const Frame& f, float* L)
+{
+    float phi = 6.283185307179586f * s1 - 3.141592653589793f;
+    float ct, st;
+    polar(mode, s0, rough, ct, st);
+    float sp, cp;
+    sincosf(phi, &sp, &cp);
+    sp = sp * st; cp = -(cp * st);
+    for (int a = 0; a < 3; a++) L[a] = f.V[a] * sp + f.n[a] * ct + f.U[a] * cp;
+}
+
+// ------------------------------------------------------------------------------------------------
+// hit shader: query_irf post-intersection math (tracer_o3d_irt.py:248-267)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void shade_hit(const SceneDev& sc, int tri_slot, float bu, float bv, float* rgb)
+{
+    float u = fminf(fmaxf(bu, 0.f), 1.f), v = fminf(fmaxf(bv, 0.f), 1.f);      // :250 np.clip
+    float4 a = sc.uvs[2 * (size_t)tri_slot], b = sc.uvs[2 * (size_t)tri_slot + 1];
+    float w = 1.0f - u - v;
+    // :260 (float64 in the reference; float32 here -- <=1e-7 in uv, far below a texel)
+    float gx = a.x * w + a.z * u + b.x * v;
+    float gy = a.y * w + a.w * u + b.y * v;
+    gx = gx * 2.f - 1.f;                  // :262
+    gy = -(1.f - gy * 2.f);               // :263
+    // F.grid_sample(bilinear, border, align_corners=False) (:265)
+    float x = ((gx + 1.f) * (float)sc.Wt - 1.f) * 0.5f, y = ((gy + 1.f) * (float)sc.Ht - 1.f) * 0.5f;
+    x = fminf(fmaxf(x, 0.f), (float)(sc.Wt - 1)); y = fminf(fmaxf(y, 0.f), (float)(sc.Ht - 1));
+    float x0f = floorf(x), y0f = floorf(y);
+    int x0 = (int)x0f, y0 = (int)y0f;
+    float wx1 = x - x0f, wx0 = 1.f - wx1, wy1 = y - y0f, wy0 = 1.f - wy1;
+    int x1 = min(x0 + 1, sc.Wt - 1), y1 = min(y0 + 1, sc.Ht - 1);
+    // out-of-range neighbours carry weight exactly 0 after the border clamp, so clamping their index is exact
+    float w00 = wx0 * wy0, w10 = (x0 + 1 < sc.Wt) ? wx1 * wy0 : 0.f, w01 = (y0 + 1 < sc.Ht) ? wx0 * wy1 : 0.f,
+          w11 = (x0 + 1 < sc.Wt && y0 + 1 < sc.Ht) ? wx1 * wy1 : 0.f;
+    const float* p00 = sc.tex + ((size_t)y0 * sc.Wt + x0) * 3;
+    const float* p10 = sc.tex + ((size_t)y0 * sc.Wt + x1) * 3;
+    const float* p01 = sc.tex + ((size_t)y1 * sc.Wt + x0) * 3;
+    const float* p11 = sc.tex + ((size_t)y1 * sc.Wt + x1) * 3;
+    for (int c = 0; c < 3; c++) {
+        float acc = p00[c] * w00;
+        acc += p10[c] * w10;
+        acc += p01[c] * w01;
+        acc += p11[c] * w11;
+        rgb[c] = acc;
+    }
+}
+
+#pragma clang fp contract(fast)
+
+// ------------------------------------------------------------------------------------------------
+// closest-hit traversal, one ray per lane.  Stack: kLdsStack entries per lane in LDS laid out
+// [entry][thread] (conflict-free ds_read/write_b32), deeper entries in a private overflow array.
+// Returns hit triangle slot (leaf order) or -1; t in units of |dir| (Embree semantics: t > 0).
+// ------------------------------------------------------------------------------------------------
+struct Hit { float t, u, v; int slot; };
+
+template <bool STATS>
+__device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float oy, float oz, float dx, float dy, float dz,
+                                             int* lds_stack /* this thread's column: lds_stack[e * kBlock] */,
+                                             uint32_t& n_nodes, uint32_t& n_tris)
+{
+    const float ooeps = 8.271806e-25f;  // 2^-80
+    float idx = __builtin_amdgcn_rcpf(fabsf(dx) > ooeps ? dx : copysignf(ooeps, dx));
+    float idy = __builtin_amdgcn_rcpf(fabsf(dy) > ooeps ? dy : copysignf(ooeps, dy));
+    float idz = __builtin_amdgcn_rcpf(fabsf(dz) > ooeps ? dz : copysignf(ooeps, dz));
+    float oodx = ox * idx, oody = oy * idy, oodz = oz * idz;
+    Hit h; h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f; h.slot = -1;
+    int ovf[kOvfStack];
+    int sp = 0;
+    int node = 0;
+    auto push = [&](int x) { if (sp < kLdsStack) lds_stack[sp * kBlock] = x; else ovf[sp - kLdsStack] = x; sp++; };
+    auto pop = [&]() -> int { if (sp == 0) return kSentinel; sp--; return sp < kLdsStack ? lds_stack[sp * kBlock] : ovf[sp - kLdsStack]; };
+    while (node != kSentinel) {
+        while (node >= 0 && node != kSentinel) {
+            const float4* np = sc.nodes + 4 * (size_t)node;
+            float4 n0 = np[0], n1 = np[1], n2 = np[2];
+            int2 ch = *reinterpret_cast<const int2*>(np + 3);
+            if (STATS) n_nodes++;
+            float c0lox = n0.x * idx - oodx, c0hix = n0.y * idx - oodx, c0loy = n0.z * idy - oody, c0hiy = n0.w * idy - oody;
+            float c0loz = n2.x * idz - oodz, c0hiz = n2.y * idz - oodz;
+            float c1lox = n1.x * idx - oodx, c1hix = n1.y * idx - oodx, c1loy = n1.z * idy - oody, c1hiy = n1.w * idy - oody;
+            float c1loz = n2.z * idz - oodz, c1hiz = n2.w * idz - oodz;
+            float t0n = fmaxf(fmaxf(fminf(c0lox, c0hix), fminf(c0loy, c0hiy)), fmaxf(fminf(c0loz, c0hiz), 0.f));
+            float t0f = fminf(fminf(fmaxf(c0lox, c0hix), fmaxf(c0loy, c0hiy)), fminf(fmaxf(c0loz, c0hiz), h.t));
+            float t1n = fmaxf(fmaxf(fminf(c1lox, c1hix), fminf(c1loy, c1hiy)), fmaxf(fminf(c1loz, c1hiz), 0.f));
+            float t1f = fminf(fminf(fmaxf(c1lox, c1hix), fmaxf(c1loy, c1hiy)), fminf(fmaxf(c1loz, c1hiz), h.t));
+            bool h0 = t0n <= t0f, h1 = t1n <= t1f;
+            if (h0 && h1) {
+                bool swp = t1n < t0n;
+                int nearc = swp ? ch.y : ch.x, farc = swp ? ch.x : ch.y;
+                push(farc);
+                node = nearc;
+            } else if (h0) node = ch.x;
+            else if (h1) node = ch.y;
+            else node = pop();
+        }
+        while (node < 0) {
+            uint32_t code = ~(uint32_t)node;
+            int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
+            for (int i = first; i < first + cnt; i++) {
+                const float4* tp = sc.tris + 3 * (size_t)i;
+                float4 v0 = tp[0], e1 = tp[1], e2 = tp[2];
+                if (STATS) n_tris++;
+                // Moeller-Trumbore, same operation order as the oracle
+                float px = dy * e2.z - dz * e2.y, py = dz * e2.x - dx * e2.z, pz = dx * e2.y - dy * e2.x;
+                float det = e1.x * px + e1.y * py + e1.z * pz;
+                float inv = __builtin_amdgcn_rcpf(det);
+                float tx = ox - v0.x, ty = oy - v0.y, tz = oz - v0.z;
+                float u = (tx * px + ty * py + tz * pz) * inv;
+                float qx = ty * e1.z - tz * e1.y, qy = tz * e1.x - tx * e1.z, qz = tx * e1.y - ty * e1.x;
+                float v = (dx * qx + dy * qy + dz * qz) * inv;
+                float t = (e2.x * qx + e2.y * qy + e2.z * qz) * inv;
+                bool ok = (det != 0.f) & (u >= 0.f) & (u <= 1.f) & (v >= 0.f) & (u + v <= 1.f) & (t > 0.f) & (t < h.t);
+                if (ok) { h.t = t; h.u = u; h.v = v; h.slot = i; }
+            }
+            node = pop();
+        }
+    }
+    return h;
+}
+
+__device__ __forceinline__ float wave_sum(float x)
+{
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+}  // namespace texir

@@ -1,0 +1,19 @@
+// launchers of the gfx950 kernels (kernels.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_common.h"
+
+namespace texir {
+hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, const float* shift, const int32_t* ids, int64_t n_ids,
+                      int N, int mode, float* irr, unsigned long long* stats, hipStream_t st);
+hipError_t launch_trace_shade(const SceneDev& sc, const float* org, const float* dir, int64_t R, float t_min, float* rad, float* t_hit,
+                              uint32_t* prim, float* puv, hipStream_t st);
+hipError_t launch_gen_dir(const float* normals, const float* rough, const float* shift, int64_t b, int N, int mode, float* L, hipStream_t st);
+hipError_t launch_spec_fwd(const SceneDev& sc, const float* normal, const float* albedo, const float* rough, const float* points,
+                           const float* irr, const float* cam, const float* shift, int64_t P, int S, float* rgb, float* Ls_ws, hipStream_t st);
+hipError_t launch_spec_bwd(const float* normal, const float* rough, const float* points, const float* irr, const float* cam,
+                           const float* shift, const float* Ls_ws, const float* d_rgb, int64_t P, int S, float* d_albedo, float* d_rough,
+                           hipStream_t st);
+}  // namespace texir

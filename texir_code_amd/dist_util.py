@@ -1,0 +1,26 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, texels / pixels partitioned across ranks,
+BVH + radiance texture replicated, one RCCL all_reduce(SUM) to assemble (IrT) or to sum gradients (Mat)."""
+import torch
+
+
+def shard_block_cyclic(ids, rank, world, block=4096):
+    """rank's share of the compacted valid-texel list: blocks of `block` consecutive entries, block b -> rank b % world.
+    Interleaving balances load (occupancy and ray cost vary over the atlas).  The shares are disjoint and cover ids."""
+    if world == 1:
+        return ids
+    n = ids.numel()
+    b = torch.arange(n, device=ids.device) // block
+    return ids[(b % world) == rank]
+
+
+def world_info():
+    import os
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def assemble_sum(t):
+    """all_reduce(SUM) across ranks when a process group is up (disjoint supports => a gather); no-op otherwise."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t)
+    return t

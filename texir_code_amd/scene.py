@@ -1,0 +1,149 @@
+"""Scene handle: the MI355X replacement of the Open3D RaycastingScene + CPU radiance texture that
+TracerO3d.__init__ / MaterialModel.__init__ build (models/tracer_o3d_irt.py:75-89, models/mat_nvdiffrast.py:87-101)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+MODES = {"uniform": 0, "cosine": 1, "importance": 2}
+
+
+def _dev_f32(t, device):
+    if not torch.is_tensor(t):
+        t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32))
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class Scene:
+    """verts [V,3], tris [T,3] (primitive id = row, Open3D order), tri_uvs [3T,2] (= np.asarray(mesh.triangle_uvs)),
+    hdr_texture [Ht,Wt,3] float32 ALREADY RGB + vertically flipped + exposure-scaled (tracer_o3d_irt.py:77-81)."""
+
+    def __init__(self, verts, tris, tri_uvs, hdr_texture, device=None):
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+        tris = np.ascontiguousarray(tris, np.int32).reshape(-1, 3)
+        tri_uvs = np.ascontiguousarray(tri_uvs, np.float32).reshape(-1, 2)
+        hdr = np.ascontiguousarray(hdr_texture, np.float32)
+        if tri_uvs.shape[0] != 3 * tris.shape[0]:
+            raise ValueError("tri_uvs must be [3T,2]")
+        if hdr.ndim != 3 or hdr.shape[2] != 3:
+            raise ValueError("hdr_texture must be [Ht,Wt,3]")
+        self.n_tris = tris.shape[0]
+        self.tex_shape = hdr.shape
+        h = C.c_void_p()
+        _lib.check(_lib.lib().texir_scene_create(_lib.ptr(verts), verts.shape[0], _lib.ptr(tris), tris.shape[0], _lib.ptr(tri_uvs),
+                                                 _lib.ptr(hdr), hdr.shape[0], hdr.shape[1], self.device.index, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h and _lib._LIB is not None:
+            try:
+                _lib._LIB.texir_scene_destroy(h)
+            except Exception:
+                pass
+            self.h = None
+
+    def info(self):
+        out = np.zeros(8, np.int64)
+        _lib.check(_lib.lib().texir_scene_info(self.h, _lib.ptr(out)))
+        keys = ["inner_nodes", "triangles", "max_depth", "node_bytes", "tri_bytes", "uv_bytes", "tex_bytes", "device"]
+        return dict(zip(keys, (int(x) for x in out)))
+
+    def set_texture(self, tex):
+        """tex [Ht,Wt,3] tensor (device or host) -- stage -1's temporary light-source-only texture (mat_nvdiffrast.py:141-150)"""
+        if torch.is_tensor(tex) and tex.is_cuda:
+            tex = tex.to(torch.float32).contiguous()
+            _lib.check(_lib.lib().texir_scene_set_texture(self.h, _lib.ptr(tex), tex.shape[0], tex.shape[1], 1, _lib.stream_ptr()))
+            torch.cuda.current_stream().synchronize()
+        else:
+            a = np.ascontiguousarray(tex.numpy() if torch.is_tensor(tex) else tex, np.float32)
+            _lib.check(_lib.lib().texir_scene_set_texture(self.h, _lib.ptr(a), a.shape[0], a.shape[1], 0, _lib.stream_ptr()))
+            torch.cuda.current_stream().synchronize()
+
+    # -- query_irf (tracer_o3d_irt.py:240-269) ----------------------------------------------------------
+    def trace_shade(self, org, dir, t_min=1e-4, return_hits=False):
+        org = _dev_f32(org, self.device).reshape(-1, 3)
+        dir = _dev_f32(dir, self.device).reshape(-1, 3)
+        R = org.shape[0]
+        rad = torch.empty((R, 3), device=self.device, dtype=torch.float32)
+        t = pid = uv = None
+        if return_hits:
+            t = torch.empty(R, device=self.device, dtype=torch.float32)
+            pid = torch.empty(R, device=self.device, dtype=torch.int32)
+            uv = torch.empty((R, 2), device=self.device, dtype=torch.float32)
+        _lib.check(_lib.lib().texir_trace_shade(self.h, _lib.ptr(org), _lib.ptr(dir), R, float(t_min), _lib.ptr(rad), _lib.ptr(t),
+                                                _lib.ptr(pid), _lib.ptr(uv), _lib.stream_ptr()))
+        return (rad, t, pid, uv) if return_hits else rad
+
+    # -- TracerO3d.forward hot loop (tracer_o3d_irt.py:156-178) -------------------------------------------
+    def irt_generate(self, pos, nrm, shift, n_samples, mode="uniform", texel_ids=None, out=None, stats=False):
+        pos = _dev_f32(pos, self.device).reshape(-1, 3)
+        nrm = _dev_f32(nrm, self.device).reshape(-1, 3)
+        Nt = pos.shape[0]
+        shift = _dev_f32(shift, self.device).reshape(Nt, 2)
+        if out is None:
+            out = torch.zeros((Nt, 3), device=self.device, dtype=torch.float32)
+        ids = None
+        n_ids = 0
+        if texel_ids is not None:
+            ids = texel_ids.to(device=self.device, dtype=torch.int32).contiguous()
+            n_ids = ids.numel()
+        st = torch.zeros(4, device=self.device, dtype=torch.int64) if stats else None
+        _lib.check(_lib.lib().texir_irt_generate(self.h, _lib.ptr(pos), _lib.ptr(nrm), _lib.ptr(shift), _lib.ptr(ids), n_ids, Nt,
+                                                 int(n_samples), MODES[mode], _lib.ptr(out), _lib.ptr(st), _lib.stream_ptr()))
+        return (out, st) if stats else out
+
+
+def generate_dir(normals, num_sample_dir, shift, mode="uniform", roughness=None):
+    """utils/sample_util.py:63-146 on the GPU; `shift` [b,2] is the torch.rand(b,1,2) of :102 made explicit."""
+    dev = normals.device
+    normals = normals.to(torch.float32).contiguous().reshape(-1, 3)
+    b = normals.shape[0]
+    shift = _dev_f32(shift, dev).reshape(b, 2)
+    r = None if roughness is None else roughness.to(torch.float32).contiguous().reshape(b)
+    L = torch.empty((b, num_sample_dir, 3), device=dev, dtype=torch.float32)
+    _lib.check(_lib.lib().texir_generate_dir(_lib.ptr(normals), _lib.ptr(r), _lib.ptr(shift), b, int(num_sample_dir), MODES[mode],
+                                             _lib.ptr(L), _lib.stream_ptr()))
+    return L
+
+
+class _SpecRender(torch.autograd.Function):
+    """render + specular_reflectance (mat_nvdiffrast.py:201-249,260-279) with its analytic backward."""
+
+    @staticmethod
+    def forward(ctx, scene, normal, albedo, rough, points, irr, cam, shift, S):
+        P = normal.shape[0]
+        rgb = torch.empty((P, 3), device=normal.device, dtype=torch.float32)
+        Ls = torch.empty((P, S, 3), device=normal.device, dtype=torch.float32)
+        _lib.check(_lib.lib().texir_spec_forward(scene.h, _lib.ptr(normal), _lib.ptr(albedo), _lib.ptr(rough), _lib.ptr(points), _lib.ptr(irr),
+                                                 _lib.ptr(cam), _lib.ptr(shift), P, S, _lib.ptr(rgb), _lib.ptr(Ls), _lib.stream_ptr()))
+        ctx.save_for_backward(normal, rough, points, irr, cam, shift, Ls)
+        ctx.S = S
+        return rgb
+
+    @staticmethod
+    def backward(ctx, d_rgb):
+        normal, rough, points, irr, cam, shift, Ls = ctx.saved_tensors
+        P = normal.shape[0]
+        d_rgb = d_rgb.contiguous()
+        need_a, need_r = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        d_a = torch.empty((P, 3), device=normal.device, dtype=torch.float32) if need_a else None
+        d_r = torch.empty((P,), device=normal.device, dtype=torch.float32) if need_r else None
+        _lib.check(_lib.lib().texir_spec_backward(_lib.ptr(normal), _lib.ptr(rough), _lib.ptr(points), _lib.ptr(irr), _lib.ptr(cam),
+                                                  _lib.ptr(shift), _lib.ptr(Ls), _lib.ptr(d_rgb), P, ctx.S, _lib.ptr(d_a), _lib.ptr(d_r),
+                                                  _lib.stream_ptr()))
+        return None, None, d_a, d_r, None, None, None, None, None
+
+
+def spec_render(scene, normal, albedo, roughness, points, irr, cam_position, shift, num_samples):
+    """rgb [P,3] = irr*albedo/pi + GGX specular; differentiable wrt albedo [P,3] and roughness [P] / [P,1]."""
+    dev = scene.device
+    P = normal.reshape(-1, 3).shape[0]
+    f = lambda t, s: t.to(device=dev, dtype=torch.float32).reshape(*s).contiguous()
+    return _SpecRender.apply(scene, f(normal, (P, 3)), f(albedo, (P, 3)), f(roughness, (P,)), f(points, (P, 3)), f(irr, (P, 3)),
+                             f(cam_position, (3,)), f(shift, (P, 2)), int(num_samples))
