@@ -63,9 +63,10 @@ def cpu_leg(sc0, pos, nrm, valid, shift, spp, budget_s=15.0):
         return time.perf_counter() - t0, c, pick.size
 
     cores = O.num_threads()
-    dt, c, n = run(max(cores * 4, 32))
+    run(cores)                                   # warm the thread pool / page in the BVH
+    dt, c, n = run(max(cores * 8, 64))           # calibration sample (dynamic schedule needs >> cores texels)
     rate = n * spp / dt
-    n_big = int(max(n, min(vid.size, budget_s * rate / spp)))
+    n_big = int(max(n, min(vid.size, 0.6 * budget_s * rate / spp)))
     dt, c, n = run(n_big)
     return {"value": n * spp / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": "%d random valid texels x %d spp (%.1f s) of the same workload, canonical BVH2 oracle, OpenMP" % (n, spp, dt)}, c
@@ -76,7 +77,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()

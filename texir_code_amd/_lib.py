@@ -34,6 +34,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise TexirError("libtexir_hip.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
                              "-- there is no CPU fallback" % LIB_PATH)
+        # Device pointers and streams come from PyTorch-ROCm, so the kernels must be launched through the SAME HIP
+        # runtime instance torch uses: torch bundles its own libamdhip64.so (soname libamdhip64.so.7, the soname our
+        # library needs), so load torch -- and pin its runtime -- before dlopen()ing ours.
+        import torch
+        tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(tl):
+            C.CDLL(tl, mode=C.RTLD_GLOBAL)
         L = C.CDLL(LIB_PATH)
         vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
         L.texir_last_error.restype = C.c_char_p
