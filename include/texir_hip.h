@@ -108,6 +108,24 @@ TEXIR_API int texir_spec_backward(const float* normal, const float* rough, const
                         const float* cam, const float* shift, const float* Ls_ws, const float* d_rgb, int64_t P,
                         int32_t S, float* d_albedo /*dev, nullable*/, float* d_rough /*dev, nullable*/, void* stream);
 
+/* Replaces RenderLoss.forward + SegLoss.forward + hdr_scale (models/loss.py:81-115, 214-295; utils/general.py:61-66),
+ * value AND gradient in one call.  The reference's one-hot mask tensors (seg_mask/floor_max_mask [C,6,h,w,1],
+ * room_seg_mask [R,6,h,w,1], built at trainer/train_material.py:255-296) are passed in their compact form:
+ *   seg_id [P] u8: class of the pixel (255 = none); hl [P] u8: floor_max_mask of the pixel's own class;
+ *   room_id [P] u8 (255 = none; stage 2 only, else NULL).
+ * stage 0/1/2 as in RenderLoss.forward; loss_type 0 = 'L1', 1 = 'L2' (applies to the rendered-radiance term only).
+ * gt,rgb,albedo [P,3]; rough,rough_womip,empty_mask,gt_mask [P] (all dev; inputs a stage does not read may be NULL).
+ * out [2] dev: (total loss, seg term) = the reference's (loss, seg_loss.item()).
+ * d_rgb [P,3], d_albedo [P,3] (stage 0), d_rough [P] (stages 1,2): d loss / d input for an upstream gradient of 1
+ *   (the means of stages 0 and 2 are differentiated through, the stage-1 quantile target is detached, as in the reference).
+ * workspace: texir_loss_workspace_bytes(P, C, R) bytes of device scratch. hw = h*w (the stage-1 scale, loss.py:101). */
+TEXIR_API int64_t texir_loss_workspace_bytes(int64_t P, int32_t C, int32_t R);
+TEXIR_API int texir_loss_forward(int32_t stage, int32_t loss_type, const float* gt, const float* rgb, const float* albedo,
+                       const float* rough, const float* rough_womip, const float* empty_mask, const float* gt_mask,
+                       const uint8_t* seg_id, const uint8_t* hl, const uint8_t* room_id, int64_t P, int32_t C, int32_t R,
+                       int32_t hw, void* workspace, float* out /*dev [2]*/, float* d_rgb, float* d_albedo, float* d_rough,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,9 @@ def lib():
             "texir_spec_forward": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp],
             "texir_spec_backward": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp],
         }
+        sig["texir_loss_forward"] = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+        L.texir_loss_workspace_bytes.argtypes = [i64, i32, i32]
+        L.texir_loss_workspace_bytes.restype = i64
         for name, args in sig.items():
             fn = getattr(L, name)
             fn.argtypes = args

@@ -150,4 +150,23 @@ int texir_spec_backward(const float* normal, const float* rough, const float* po
     return TEXIR_OK;
 }
 
+int64_t texir_loss_workspace_bytes(int64_t P, int32_t C, int32_t R) { return (int64_t)loss_workspace_bytes(P, C, R); }
+
+int texir_loss_forward(int32_t stage, int32_t loss_type, const float* gt, const float* rgb, const float* albedo, const float* rough,
+                       const float* rough_womip, const float* empty_mask, const float* gt_mask, const uint8_t* seg_id, const uint8_t* hl,
+                       const uint8_t* room_id, int64_t P, int32_t C, int32_t R, int32_t hw, void* workspace, float* out, float* d_rgb,
+                       float* d_albedo, float* d_rough, void* stream)
+{
+    if (stage < 0 || stage > 2) return fail(TEXIR_ERR_INVALID, "texir_loss_forward: stage must be 0, 1 or 2 (got %d)", stage);
+    if (loss_type < 0 || loss_type > 1) return fail(TEXIR_ERR_INVALID, "texir_loss_forward: loss_type must be 0 (L1) or 1 (L2)");
+    if (!gt || !rgb || !empty_mask || !seg_id || !workspace || !out || !d_rgb) return fail(TEXIR_ERR_INVALID, "texir_loss_forward: null argument");
+    if (P <= 0 || C <= 0 || C > 255) return fail(TEXIR_ERR_INVALID, "texir_loss_forward: bad sizes P=%lld C=%d", (long long)P, C);
+    if (stage == 0 && (!albedo || !gt_mask || !d_albedo)) return fail(TEXIR_ERR_INVALID, "texir_loss_forward: stage 0 needs albedo, gt_mask, d_albedo");
+    if (stage == 1 && (!rough || !rough_womip || !hl || !d_rough)) return fail(TEXIR_ERR_INVALID, "texir_loss_forward: stage 1 needs rough, rough_womip, hl, d_rough");
+    if (stage == 2 && (!rough || !room_id || !d_rough || R <= 0 || R > 255)) return fail(TEXIR_ERR_INVALID, "texir_loss_forward: stage 2 needs rough, room_id, d_rough, 0<R<256");
+    HIP_TRY(launch_loss(stage, loss_type, gt, rgb, albedo, rough, rough_womip, empty_mask, gt_mask, seg_id, hl, room_id, P, C, R, hw, workspace, out,
+                        d_rgb, d_albedo, d_rough, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
 }  // extern "C"

@@ -16,4 +16,8 @@ hipError_t launch_spec_fwd(const SceneDev& sc, const float* normal, const float*
 hipError_t launch_spec_bwd(const float* normal, const float* rough, const float* points, const float* irr, const float* cam,
                            const float* shift, const float* Ls_ws, const float* d_rgb, int64_t P, int S, float* d_albedo, float* d_rough,
                            hipStream_t st);
+size_t loss_workspace_bytes(int64_t P, int C, int R);
+hipError_t launch_loss(int stage, int l2, const float* gt, const float* rgb, const float* albedo, const float* rough, const float* rough_womip,
+                       const float* empty, const float* gtm, const uint8_t* seg, const uint8_t* hl, const uint8_t* room, int64_t P, int C, int R,
+                       int hw, void* workspace, float* out, float* d_rgb, float* d_albedo, float* d_rough, hipStream_t st);
 }  // namespace texir

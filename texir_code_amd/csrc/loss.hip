@@ -1,0 +1,328 @@
+// Fused RenderLoss + SegLoss forward AND gradient (models/loss.py:81-115, 214-295; hdr_scale utils/general.py:61-66).
+//
+// The reference materialises [49,6,h,w,{1,3}] broadcast tensors and loops over the 49 classes in Python with .item()
+// syncs and torch.quantile.  Its masks are one-hot by construction (trainer/train_material.py:255,286-296:
+// seg_mask = (tag == segs), floor_max_mask = seg_mask * (intensity > 0), room mask = (room_img == unique)), so the
+// whole loss is a function of ONE class id, ONE highlight flag and ONE room id per pixel.  These kernels stream
+// 1-byte ids + the per-pixel images once (stats), once more (loss + direct gradient) and, for the stages whose class
+// means are differentiated through, a third time (mean-gradient term).  The scalar loss only ever receives a scalar
+// upstream gradient, so the gradient images are produced in the same call (for d_loss = 1).
+//
+// Notation: P = 6*h*w pixels, C classes, R rooms, H(x) = ln(1+x); every L1/L2 is a mean over the FULL
+// broadcast shape (masked-out entries add 0 to the sum but count in the denominator).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace texir {
+
+constexpr int kLB = 256;
+constexpr uint8_t kNoClass = 255;
+
+struct LossWs {            // layout of the caller-provided workspace (all zero-initialised by the launcher)
+    double* sums;          // [R*C*3]   per-(room,)class channel sums
+    double* cnt;           // [R*C]     per-(room,)class pixel counts
+    double* sgn;           // [R*C*3]   per-class sum of sign(x - mean)
+    double* acc;           // [2]       direct-loss sum, seg-loss sum
+    uint32_t* hcnt;        // [C]       highlight pixels per class (stage 1)
+    uint32_t* hoff;        // [C+1]     exclusive scan
+    uint32_t* hcur;        // [C]       scatter cursors
+    float* tau;            // [C]       per-class target roughness (stage 1)
+    float* hval;           // [P]       highlight roughness values grouped by class
+};
+
+__device__ __forceinline__ double block_sum(double v, double* sh)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0;
+    if (threadIdx.x == 0) for (int i = 0; i < kLB / 64; i++) r += sh[i];
+    return r;   // valid on thread 0
+}
+
+__device__ __forceinline__ float sgnf(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+
+// ---- pass 1: per-class statistics -----------------------------------------------------------------------------
+// mode 0: sums of albedo (3 ch) per class;  mode 2: sums of roughness per (room, class);  mode 1: highlight counts
+__global__ __launch_bounds__(kLB) void loss_stats_kernel(int mode, const float* __restrict__ img, const uint8_t* __restrict__ seg,
+                                                         const uint8_t* __restrict__ hl, const uint8_t* __restrict__ room, int64_t P,
+                                                         int C, int R, LossWs ws)
+{
+    // per-block LDS accumulators, flushed once: [rc*3] sums, [rc] counts
+    extern __shared__ __attribute__((aligned(16))) double lacc[];
+    const int rc = (mode == 2 ? R : 1) * C;
+    for (int i = threadIdx.x; i < rc * 4; i += kLB) lacc[i] = 0.0;
+    __syncthreads();
+    double* lsum = lacc; double* lcnt = lacc + rc * 3;
+    for (int64_t p = (int64_t)blockIdx.x * kLB + threadIdx.x; p < P; p += (int64_t)gridDim.x * kLB) {
+        uint8_t c = seg[p];
+        if (c == kNoClass) continue;
+        if (mode == 0) {
+            atomicAdd(&lcnt[c], 1.0);
+            for (int k = 0; k < 3; k++) atomicAdd(&lsum[3 * c + k], (double)img[3 * p + k]);
+        } else if (mode == 1) {
+            if (hl[p]) atomicAdd(&lcnt[c], 1.0);
+        } else {
+            uint8_t q = room[p];
+            if (q == kNoClass) continue;
+            int s = (int)q * C + c;
+            atomicAdd(&lcnt[s], 1.0);
+            atomicAdd(&lsum[s], (double)img[p]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < rc; i += kLB) {
+        if (lcnt[i] != 0.0) {
+            if (mode == 1) atomicAdd(&ws.hcnt[i], (uint32_t)lcnt[i]);
+            else atomicAdd(&ws.cnt[i], lcnt[i]);
+        }
+    }
+    if (mode != 1) for (int i = threadIdx.x; i < rc * 3; i += kLB) if (lsum[i] != 0.0) atomicAdd(&ws.sums[i], lsum[i]);
+}
+
+__global__ void loss_scan_kernel(int C, LossWs ws)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t a = 0;
+        for (int c = 0; c < C; c++) { ws.hoff[c] = a; a += ws.hcnt[c]; }
+        ws.hoff[C] = a;
+    }
+}
+
+__global__ __launch_bounds__(kLB) void loss_scatter_kernel(const float* __restrict__ rw, const uint8_t* __restrict__ seg,
+                                                           const uint8_t* __restrict__ hl, int64_t P, LossWs ws)
+{
+    for (int64_t p = (int64_t)blockIdx.x * kLB + threadIdx.x; p < P; p += (int64_t)gridDim.x * kLB) {
+        uint8_t c = seg[p];
+        if (c == kNoClass || !hl[p]) continue;
+        uint32_t slot = ws.hoff[c] + atomicAdd(&ws.hcur[c], 1u);
+        ws.hval[slot] = rw[p];
+    }
+}
+
+__device__ __forceinline__ uint32_t fkey(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float fkey_inv(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+
+// k-th smallest (0-based) of v[0..n) by 4 x 8-bit radix select; whole block cooperates; result valid on all threads
+__device__ float block_select(const float* v, uint32_t n, uint32_t k, uint32_t* hist /* LDS [256] */, uint32_t* bcast /* LDS [2] */)
+{
+    uint32_t prefix = 0, mask = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = threadIdx.x; i < 256; i += kLB) hist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += kLB) {
+            uint32_t key = fkey(v[i]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t a = 0; int d = 0;
+            for (; d < 256; d++) { if (a + hist[d] > k) break; a += hist[d]; }
+            bcast[0] = (uint32_t)d; bcast[1] = a;
+        }
+        __syncthreads();
+        prefix |= bcast[0] << shift; mask |= 255u << shift; k -= bcast[1];
+        __syncthreads();
+    }
+    return fkey_inv(prefix);
+}
+
+// SegLoss mode 1 target (loss.py:256-272): tau_c = 0.4-quantile (torch.quantile, linear interpolation) of the
+// detached no-mip roughness over the class's highlight pixels; 0 if the class has none; class 43 -> 0.8.
+__global__ __launch_bounds__(kLB) void loss_quantile_kernel(int C, LossWs ws)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t bc[2];
+    int c = blockIdx.x;
+    uint32_t n = ws.hcnt[c];
+    if (n == 0) { if (threadIdx.x == 0) ws.tau[c] = 0.f; return; }
+    const float* v = ws.hval + ws.hoff[c];
+    float rank = 0.4f * (float)(n - 1);
+    float lo = floorf(rank);
+    float w = rank - lo;
+    uint32_t k0 = (uint32_t)lo, k1 = min(k0 + 1u, n - 1u);
+    float a = block_select(v, n, k0, hist, bc);
+    float b = (w > 0.f) ? block_select(v, n, k1, hist, bc) : a;
+    if (threadIdx.x == 0) {
+        // at::lerp
+        float r = (w < 0.5f) ? a + w * (b - a) : b - (b - a) * (1.f - w);
+        ws.tau[c] = (c == 43) ? 0.8f : r;
+    }
+}
+
+// ---- pass 2: loss sums + direct gradients -----------------------------------------------------------------------
+struct LossArgs {
+    const float *gt, *rgb, *albedo, *rough, *empty, *gtm;
+    const uint8_t *seg, *hl, *room;
+    int64_t P; int C, R, hw, stage, l2;
+    float *d_rgb, *d_albedo, *d_rough;
+};
+
+__global__ __launch_bounds__(kLB) void loss_main_kernel(LossArgs a, LossWs ws)
+{
+    __shared__ double sh[kLB / 64];
+    extern __shared__ __attribute__((aligned(16))) double lsgn[];       // [rc*3] per-block sum of sign(x - mean)
+    const int rc3 = (a.stage == 2 ? a.R : 1) * a.C * 3;
+    for (int i = threadIdx.x; i < rc3; i += kLB) lsgn[i] = 0.0;
+    __syncthreads();
+    double direct = 0.0, segl = 0.0;
+    const double P = (double)a.P;
+    // scale of the direct term's per-element gradient
+    float kd;
+    if (a.stage == 0) kd = (float)(1.0 / (3.0 * P));
+    else if (a.stage == 1) kd = (float)((double)a.hw / ((double)a.C * P * 3.0));
+    else kd = (float)(1.0 / ((double)a.C * P * 3.0));
+    const float ks0 = (float)(20.0 / ((double)a.C * P * 3.0));              // stage 0 seg weight per element
+    const float ks1 = (float)(1.0 / ((double)a.C * P));                      // stage 1
+    const float ks2 = (float)(0.2 / ((double)a.R * (double)a.C * P));        // stage 2
+    for (int64_t p = (int64_t)blockIdx.x * kLB + threadIdx.x; p < a.P; p += (int64_t)gridDim.x * kLB) {
+        const uint8_t c = a.seg[p];
+        const bool has = c != kNoClass;
+        const float e = a.empty[p];
+        // which pixels enter the direct term, and with which gt-side mask
+        float m;
+        if (a.stage == 0) m = a.gtm[p];
+        else if (a.stage == 1) m = (has && a.hl[p]) ? 1.f : 0.f;
+        else m = has ? 1.f : 0.f;
+        for (int k = 0; k < 3; k++) {
+            float g = 0.f;
+            if (m != 0.f) {
+                float x = a.rgb[3 * p + k] * e * m, y = a.gt[3 * p + k] * m;
+                float d = logf(x + 1.f) - logf(y + 1.f);
+                if (a.l2) { direct += (double)(d * d); g = 2.f * d * kd * e * m / (x + 1.f); }
+                else { direct += (double)fabsf(d); g = sgnf(d) * kd * e * m / (x + 1.f); }
+            }
+            a.d_rgb[3 * p + k] = g;
+        }
+        if (a.stage == 0) {
+            for (int k = 0; k < 3; k++) {
+                float g = 0.f;
+                if (has) {
+                    float mean = (float)(ws.sums[3 * c + k] / (ws.cnt[c] + 1e-6));
+                    float d = a.albedo[3 * p + k] - mean;
+                    segl += (double)fabsf(d);
+                    float s = sgnf(d);
+                    g = ks0 * s;
+                    if (s != 0.f) atomicAdd(&lsgn[3 * c + k], (double)s);
+                }
+                a.d_albedo[3 * p + k] = g;
+            }
+        } else if (a.stage == 1) {
+            float g = 0.f;
+            if (has && !a.hl[p]) {
+                float n = (float)ws.hcnt[c];
+                float gc = n / (n + 1e-6f);
+                float tau = ws.tau[c];
+                float r = a.rough[p];
+                float d = r * gc - tau * gc;
+                segl += (double)fabsf(d);
+                g = ks1 * sgnf(d) * gc;
+            }
+            a.d_rough[p] = g;
+        } else {
+            float g = 0.f;
+            const uint8_t q = a.room[p];
+            if (has && q != kNoClass) {
+                int s = (int)q * a.C + c;
+                float mean = (float)(ws.sums[s] / (ws.cnt[s] + 1e-6));
+                float d = a.rough[p] - mean;
+                segl += (double)fabsf(d);
+                float sg = sgnf(d);
+                g = ks2 * sg;
+                if (sg != 0.f) atomicAdd(&lsgn[s], (double)sg);
+            }
+            a.d_rough[p] = g;
+        }
+    }
+    __syncthreads();
+    if (a.stage != 1) for (int i = threadIdx.x; i < rc3; i += kLB) if (lsgn[i] != 0.0) atomicAdd(&ws.sgn[i], lsgn[i]);
+    double d0 = block_sum(direct, sh);
+    double d1 = block_sum(segl, sh);
+    if (threadIdx.x == 0) { if (d0 != 0.0) atomicAdd(&ws.acc[0], d0); if (d1 != 0.0) atomicAdd(&ws.acc[1], d1); }
+}
+
+// ---- pass 3: gradient through the (non-detached) class means (loss.py:283,290) ----------------------------------
+__global__ __launch_bounds__(kLB) void loss_meangrad_kernel(LossArgs a, LossWs ws)
+{
+    const double P = (double)a.P;
+    const float ks0 = (float)(20.0 / ((double)a.C * P * 3.0));
+    const float ks2 = (float)(0.2 / ((double)a.R * (double)a.C * P));
+    for (int64_t p = (int64_t)blockIdx.x * kLB + threadIdx.x; p < a.P; p += (int64_t)gridDim.x * kLB) {
+        const uint8_t c = a.seg[p];
+        if (c == kNoClass) continue;
+        if (a.stage == 0) {
+            for (int k = 0; k < 3; k++) a.d_albedo[3 * p + k] -= ks0 * (float)(ws.sgn[3 * c + k] / (ws.cnt[c] + 1e-6));
+        } else {
+            const uint8_t q = a.room[p];
+            if (q == kNoClass) continue;
+            int s = (int)q * a.C + c;
+            a.d_rough[p] -= ks2 * (float)(ws.sgn[s] / (ws.cnt[s] + 1e-6));
+        }
+    }
+}
+
+__global__ void loss_final_kernel(LossArgs a, LossWs ws, float* out /* [2]: total, seg */)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    const double P = (double)a.P;
+    double direct, seg;
+    if (a.stage == 0) { direct = ws.acc[0] / (3.0 * P); seg = 20.0 * ws.acc[1] / ((double)a.C * P * 3.0); }
+    else if (a.stage == 1) { direct = ws.acc[0] / ((double)a.C * P * 3.0) * (double)a.hw; seg = ws.acc[1] / ((double)a.C * P); }
+    else { direct = ws.acc[0] / ((double)a.C * P * 3.0); seg = 0.2 * ws.acc[1] / ((double)a.R * (double)a.C * P); }
+    out[0] = (float)(direct + seg); out[1] = (float)seg;
+}
+
+size_t loss_workspace_bytes(int64_t P, int C, int R)
+{
+    size_t rc = (size_t)(R > 0 ? R : 1) * C;
+    size_t b = sizeof(double) * (rc * 3 + rc + rc * 3 + 2) + sizeof(uint32_t) * (C + (C + 1) + C) + sizeof(float) * C;
+    b = (b + 255) & ~(size_t)255;
+    return b + sizeof(float) * (size_t)P;
+}
+
+hipError_t launch_loss(int stage, int l2, const float* gt, const float* rgb, const float* albedo, const float* rough, const float* rough_womip,
+                       const float* empty, const float* gtm, const uint8_t* seg, const uint8_t* hl, const uint8_t* room, int64_t P, int C, int R,
+                       int hw, void* workspace, float* out, float* d_rgb, float* d_albedo, float* d_rough, hipStream_t st)
+{
+    size_t rc = (size_t)(R > 0 ? R : 1) * C;
+    LossWs ws;
+    char* w = (char*)workspace;
+    ws.sums = (double*)w; w += sizeof(double) * rc * 3;
+    ws.cnt = (double*)w; w += sizeof(double) * rc;
+    ws.sgn = (double*)w; w += sizeof(double) * rc * 3;
+    ws.acc = (double*)w; w += sizeof(double) * 2;
+    ws.hcnt = (uint32_t*)w; w += sizeof(uint32_t) * C;
+    ws.hoff = (uint32_t*)w; w += sizeof(uint32_t) * (C + 1);
+    ws.hcur = (uint32_t*)w; w += sizeof(uint32_t) * C;
+    ws.tau = (float*)w; w += sizeof(float) * C;
+    size_t head = (size_t)(w - (char*)workspace);
+    head = (head + 255) & ~(size_t)255;
+    ws.hval = (float*)((char*)workspace + head);
+    hipError_t e = hipMemsetAsync(workspace, 0, head, st);
+    if (e != hipSuccess) return e;
+    int64_t nb = (P + kLB - 1) / kLB;
+    int grid = (int)(nb > 2048 ? 2048 : (nb < 1 ? 1 : nb));
+    size_t lds_stats = sizeof(double) * rc * 4;
+    if (lds_stats > 60000) return hipErrorInvalidValue;     // R*C too large for the per-block LDS accumulators
+    LossArgs a{gt, rgb, albedo, rough, empty, gtm, seg, hl, room, P, C, R > 0 ? R : 1, hw, stage, l2, d_rgb, d_albedo, d_rough};
+    if (stage == 0) {
+        hipLaunchKernelGGL(loss_stats_kernel, dim3(grid), dim3(kLB), lds_stats, st, 0, albedo, seg, hl, room, P, C, R, ws);
+    } else if (stage == 1) {
+        hipLaunchKernelGGL(loss_stats_kernel, dim3(grid), dim3(kLB), lds_stats, st, 1, rough_womip, seg, hl, room, P, C, R, ws);
+        hipLaunchKernelGGL(loss_scan_kernel, dim3(1), dim3(64), 0, st, C, ws);
+        hipLaunchKernelGGL(loss_scatter_kernel, dim3(grid), dim3(kLB), 0, st, rough_womip, seg, hl, P, ws);
+        hipLaunchKernelGGL(loss_quantile_kernel, dim3(C), dim3(kLB), 0, st, C, ws);
+    } else {
+        hipLaunchKernelGGL(loss_stats_kernel, dim3(grid), dim3(kLB), lds_stats, st, 2, rough, seg, hl, room, P, C, a.R, ws);
+    }
+    hipLaunchKernelGGL(loss_main_kernel, dim3(grid), dim3(kLB), sizeof(double) * rc * 3, st, a, ws);
+    if (stage != 1) hipLaunchKernelGGL(loss_meangrad_kernel, dim3(grid), dim3(kLB), 0, st, a, ws);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, a, ws, out);
+    return hipGetLastError();
+}
+
+}  // namespace texir

@@ -1,0 +1,114 @@
+"""Drop-in for models.loss.RenderLoss (+ SegLoss, hdr_scale) -- models/loss.py:55-115, 214-295, utils/general.py:61-66.
+
+Same constructor and forward signature/return tuple as the reference class; the arithmetic runs in the fused HIP
+kernels behind texir_loss_forward.  The reference's [C,6,h,w,1] one-hot mask tensors are accepted as-is and
+compacted (once per mask tensor, cached) to 1-byte class / highlight / room ids.
+"""
+import torch
+from torch import nn
+
+from . import _lib
+
+NO_CLASS = 255
+_LOSS_TYPES = {"L1": 0, "L2": 1}
+
+
+def compact_masks(seg_mask, floor_max_mask=None, room_seg_mask=None):
+    """[C,...,1] one-hot float masks -> (seg_id u8 [P], hl u8 [P] | None, room_id u8 [P] | None, C, R).
+    Raises if the masks are not what trainer/train_material.py:255-296 constructs (one-hot seg / room masks,
+    floor_max_mask a subset of seg_mask): the compact kernels would silently compute something else."""
+    C = seg_mask.shape[0]
+    s = seg_mask.reshape(C, -1)
+    cnt = s.sum(0)
+    if not bool(((s == 0) | (s == 1)).all()) or float(cnt.max()) > 1:
+        raise ValueError("seg_mask must be a one-hot {0,1} mask over the class dimension")
+    seg_id = torch.where(cnt > 0, s.argmax(0), torch.full_like(cnt, NO_CLASS, dtype=torch.long)).to(torch.uint8)
+    hl = None
+    if floor_max_mask is not None:
+        f = floor_max_mask.reshape(C, -1)
+        if not bool(((f == 0) | (f == 1)).all()) or bool((f * (1 - s)).any()):
+            raise ValueError("floor_max_mask must be a {0,1} subset of seg_mask")
+        hl = (f.sum(0) > 0).to(torch.uint8)
+    room_id, R = None, 0
+    if room_seg_mask is not None:
+        R = room_seg_mask.shape[0]
+        r = room_seg_mask.reshape(R, -1)
+        rc = r.sum(0)
+        if not bool(((r == 0) | (r == 1)).all()) or float(rc.max()) > 1:
+            raise ValueError("room_seg_mask must be a one-hot {0,1} mask over the room dimension")
+        room_id = torch.where(rc > 0, r.argmax(0), torch.full_like(rc, NO_CLASS, dtype=torch.long)).to(torch.uint8)
+    return seg_id.contiguous(), hl, room_id, C, R
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb, albedo, rough, rough_womip, gt, empty, gtm, seg_id, hl, room_id, stage, loss_type, C, R, hw):
+        dev = rgb.device
+        P = seg_id.numel()
+        f = lambda t, n: None if t is None else t.detach().to(device=dev, dtype=torch.float32).reshape(P, n).contiguous()
+        rgb_, alb_, gt_ = f(rgb, 3), f(albedo, 3), f(gt, 3)
+        r_, rw_, e_, m_ = f(rough, 1), f(rough_womip, 1), f(empty, 1), f(gtm, 1)
+        L = _lib.lib()
+        ws = torch.empty(int(L.texir_loss_workspace_bytes(P, C, R)), device=dev, dtype=torch.uint8)
+        out = torch.empty(2, device=dev, dtype=torch.float32)
+        d_rgb = torch.empty((P, 3), device=dev, dtype=torch.float32)
+        d_alb = torch.empty((P, 3), device=dev, dtype=torch.float32) if stage == 0 else None
+        d_r = torch.empty((P,), device=dev, dtype=torch.float32) if stage != 0 else None
+        _lib.check(L.texir_loss_forward(stage, loss_type, _lib.ptr(gt_), _lib.ptr(rgb_), _lib.ptr(alb_), _lib.ptr(r_), _lib.ptr(rw_), _lib.ptr(e_),
+                                        _lib.ptr(m_), _lib.ptr(seg_id), _lib.ptr(hl), _lib.ptr(room_id), P, C, R, hw, _lib.ptr(ws), _lib.ptr(out),
+                                        _lib.ptr(d_rgb), _lib.ptr(d_alb), _lib.ptr(d_r), _lib.stream_ptr()))
+        ctx.grads = (d_rgb, d_alb, d_r)
+        ctx.shapes = (rgb.shape, None if albedo is None else albedo.shape, None if rough is None else rough.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        d_rgb, d_alb, d_r = ctx.grads
+        s_rgb, s_alb, s_r = ctx.shapes
+        g0 = g[0]      # only out[0] (total loss) is differentiable; out[1] is the detached .item() value
+        grgb = (d_rgb * g0).reshape(s_rgb) if ctx.needs_input_grad[0] else None
+        galb = (d_alb * g0).reshape(s_alb) if (d_alb is not None and ctx.needs_input_grad[1]) else None
+        gr = (d_r * g0).reshape(s_r) if (d_r is not None and ctx.needs_input_grad[2]) else None
+        return (grgb, galb, gr) + (None,) * 12
+
+
+class RenderLoss(nn.Module):
+    """models.loss.RenderLoss(loss_type='L1', w_gradient=0).forward(gt_img, preds, gt_mask, floor_max_mask, seg_mask,
+    stage, room_seg_mask) -> (loss, seg_loss_item[, 0])  (loss.py:56,81-115)."""
+
+    def __init__(self, loss_type="L1", w_gradient=0):
+        super().__init__()
+        if loss_type not in _LOSS_TYPES:
+            # psnr / ssim / msssim variants (loss.py:67-75) are evaluation-side options, outside the hot path
+            raise NotImplementedError("RenderLoss loss_type %r is out of scope; use 'L1' or 'L2'" % (loss_type,))
+        print("Using %s loss for comparing re-rendered radiance!" % loss_type)
+        self.loss_type = loss_type
+        self.w_gradient = w_gradient
+        self._cache = {}
+
+    def _compact(self, seg_mask, floor_max_mask, room_seg_mask, dev):
+        key = tuple((t.data_ptr(), tuple(t.shape), t._version) if t is not None else None for t in (seg_mask, floor_max_mask, room_seg_mask))
+        hit = self._cache.get(key)
+        if hit is None:
+            if len(self._cache) > 256:
+                self._cache.clear()
+            seg_id, hl, room_id, C, R = compact_masks(seg_mask, floor_max_mask, room_seg_mask)
+            mv = lambda t: None if t is None else t.to(dev).contiguous()
+            hit = (mv(seg_id), mv(hl), mv(room_id), C, R)
+            self._cache[key] = hit
+        return hit
+
+    def forward(self, gt_img, preds, gt_mask, floor_max_mask, seg_mask, stage=0, room_seg_mask=None):
+        if stage not in (0, 1, 2):
+            raise ValueError("RenderLoss: stage must be 0, 1 or 2")
+        rgb = preds["rgb"]
+        dev = rgb.device
+        seg_id, hl, room_id, C, R = self._compact(seg_mask, floor_max_mask, room_seg_mask if stage == 2 else None, dev)
+        hw = int(rgb.shape[1] * rgb.shape[2])
+        out = _LossFn.apply(rgb, preds["albedo"] if stage == 0 else None, preds["roughness"] if stage != 0 else None,
+                            preds["roughness_womipmap"] if stage == 1 else None, gt_img, preds["empty_mask"], gt_mask if stage == 0 else None,
+                            seg_id, hl, room_id if stage == 2 else None, stage, _LOSS_TYPES[self.loss_type], C, R if stage == 2 else 0, hw)
+        loss, seg_item = out[0], out[1].item()
+        if stage == 0:
+            return loss, seg_item
+        return loss, seg_item, (0. if stage == 1 else 0)
