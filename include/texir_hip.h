@@ -126,6 +126,42 @@ TEXIR_API int texir_loss_forward(int32_t stage, int32_t loss_type, const float* 
                        int32_t hw, void* workspace, float* out /*dev [2]*/, float* d_rgb, float* d_albedo, float* d_rough,
                        void* stream);
 
+/* ---- G-buffer production: replaces nvdiffrast rasterize + interpolate (models/mat_nvdiffrast.py:119-128,
+ * models/tracer_o3d_irt.py:102-108) by casting one primary ray per cube-map pixel through the scene's BVH.
+ * Geometry and cameras never change (optim_cam=False, configs/syn.conf:20), so hosts cache the result per view. */
+
+/* per-corner shading normals [3T,3] host (normals[indices] of pyredner.load_obj, tracer_o3d_irt.py:61,105);
+ * without them the G-buffer carries geometric normals. */
+TEXIR_API int texir_scene_set_corner_normals(texir_scene* scene, const float* corner_normals /*host*/);
+
+/* mvp [6,4,4] f32 HOST: the reference's per-face mvp as passed to MaterialModel.forward (row-vector convention
+ * clip = [x,y,z,1] @ mvp, datasets/dataset.py:464-465); inverted in double inside the library.  Pixel (row i, col j) is at ndc ((j+.5)/c*2-1, (i+.5)/c*2-1), i.e. nvdiffrast's layout.
+ * Outputs, P = 6*c*c, all dev: pos [P,3] (interpolated vertex position; empty -> (1,0,0)), nrm [P,3] (interpolated
+ * corner normals; empty -> (1,0,0)), mask [P] (1 where rast[...,3] > 0), uv [P,2] (= texc), uv_da [P,4]
+ * (= texd: du/dX, du/dY, dv/dX, dv/dY per pixel), tri_id [P] (primitive id + 1, 0 = empty; nvdiffrast rast[...,3]).
+ * flip_v: 1 -> uv.v := 1 - v (pyredner's OBJ convention for the nvdiffrast-side textures). */
+TEXIR_API int texir_gbuffer_cast(const texir_scene* scene, const float* mvp /*host*/, int32_t cube_res, int32_t flip_v,
+                       float* pos, float* nrm, float* mask, float* uv, float* uv_da, int32_t* tri_id, void* stream);
+
+/* ---- nvdiffrast `texture` restated (models/mat_nvdiffrast.py:131-139).  A texture [H,W,C] (C <= 4) lives at the
+ * head of a mip buffer of texir_mip_elems() floats; texir_mip_build fills levels 1.. by 2x2 box filtering.
+ * filter_mode 0 = 'linear' (bilinear, level 0), 1 = 'linear-mipmap-linear' (trilinear, LOD from uv_da); wrap boundary. */
+TEXIR_API int32_t texir_mip_levels(int32_t H, int32_t W, int32_t max_mip_level);
+TEXIR_API int64_t texir_mip_elems(int32_t H, int32_t W, int32_t C, int32_t levels);
+TEXIR_API int texir_mip_build(float* mips /*dev*/, int32_t H, int32_t W, int32_t C, int32_t levels, void* stream);
+TEXIR_API int texir_tex_fetch_forward(const float* mips /*dev*/, int32_t H, int32_t W, int32_t C, int32_t levels,
+                       const float* uv /*dev [P,2]*/, const float* uv_da /*dev [P,4], nullable for mode 0*/,
+                       int32_t filter_mode, int64_t P, float* out /*dev [P,C]*/, void* stream);
+/* grad_mips [texir_mip_elems] dev must be zero on entry; on return its first H*W*C floats hold d loss / d texture. */
+TEXIR_API int texir_tex_fetch_backward(float* grad_mips /*dev*/, int32_t H, int32_t W, int32_t C, int32_t levels,
+                       const float* uv, const float* uv_da, int32_t filter_mode, int64_t P,
+                       const float* d_out /*dev [P,C]*/, void* stream);
+
+/* ---- optimiser step of the material textures: torch.optim.Adam(lr, betas, eps) (trainer/train_material.py:122-123,448-450)
+ * fused with the clamp the trainer applies right after it (:458, :592-593).  step >= 1; lo/hi = clamp range (+-inf = none). */
+TEXIR_API int texir_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                       float beta1, float beta2, float eps, int32_t step, float clamp_lo, float clamp_hi, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

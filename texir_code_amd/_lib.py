@@ -57,6 +57,16 @@ def lib():
             "texir_spec_backward": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp],
         }
         sig["texir_loss_forward"] = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+        sig["texir_scene_set_corner_normals"] = [vp, vp]
+        sig["texir_gbuffer_cast"] = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+        sig["texir_mip_build"] = [vp, i32, i32, i32, i32, vp]
+        sig["texir_tex_fetch_forward"] = [vp, i32, i32, i32, i32, vp, vp, i32, i64, vp, vp]
+        sig["texir_tex_fetch_backward"] = [vp, i32, i32, i32, i32, vp, vp, i32, i64, vp, vp]
+        sig["texir_adam_step"] = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, f32, vp]
+        L.texir_mip_levels.argtypes = [i32, i32, i32]
+        L.texir_mip_levels.restype = i32
+        L.texir_mip_elems.argtypes = [i32, i32, i32, i32]
+        L.texir_mip_elems.restype = i64
         L.texir_loss_workspace_bytes.argtypes = [i64, i32, i32]
         L.texir_loss_workspace_bytes.restype = i64
         for name, args in sig.items():

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/texir_hip.h"
 #include "bvh_build.h"
@@ -19,6 +20,8 @@ struct texir_scene {
     void* d_nodes = nullptr; void* d_tris = nullptr; void* d_uvs = nullptr; float* d_tex = nullptr;
     int64_t n_nodes = 0, n_tris = 0, max_depth = 0;
     size_t tex_bytes = 0;
+    std::vector<uint32_t> slot_prim;     // leaf slot -> primitive id (host copy, for per-corner attribute uploads)
+    void* d_cnrm = nullptr;              // leaf-ordered corner normals, 3 x float4 per triangle
 };
 
 static thread_local std::string g_err;
@@ -55,6 +58,8 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
     try { build_bvh(verts, V, tris, T, tri_uvs, h); } catch (const std::bad_alloc&) { return fail(TEXIR_ERR_NOMEM, "BVH build: out of host memory"); }
     texir_scene* s = new (std::nothrow) texir_scene;
     if (!s) return fail(TEXIR_ERR_NOMEM, "out of host memory");
+    s->slot_prim.resize((size_t)T);
+    for (int i = 0; i < T; i++) s->slot_prim[i] = h.tris[i].prim;
     s->device = device; s->n_nodes = (int64_t)h.nodes.size(); s->n_tris = T; s->max_depth = h.max_depth;
     s->tex_bytes = sizeof(float) * 3 * (size_t)Ht * Wt;
     auto bail = [&](hipError_t e, const char* what) { texir_scene_destroy(s); return fail(TEXIR_ERR_HIP, "%s: %s", what, hipGetErrorString(e)); };
@@ -81,6 +86,7 @@ int texir_scene_destroy(texir_scene* s)
     if (s->d_tris) (void)hipFree(s->d_tris);
     if (s->d_uvs) (void)hipFree(s->d_uvs);
     if (s->d_tex) (void)hipFree(s->d_tex);
+    if (s->d_cnrm) (void)hipFree(s->d_cnrm);
     delete s;
     return TEXIR_OK;
 }
@@ -147,6 +153,76 @@ int texir_spec_backward(const float* normal, const float* rough, const float* po
     if (!normal || !rough || !points || !irr || !cam || !shift || !Ls_ws || !d_rgb) return fail(TEXIR_ERR_INVALID, "texir_spec_backward: null argument");
     if (P < 0 || S <= 0) return fail(TEXIR_ERR_INVALID, "texir_spec_backward: bad sizes P=%lld S=%d", (long long)P, S);
     HIP_TRY(launch_spec_bwd(normal, rough, points, irr, cam, shift, Ls_ws, d_rgb, P, S, d_albedo, d_rough, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
+int texir_scene_set_corner_normals(texir_scene* s, const float* cn)
+{
+    if (!s || !cn) return fail(TEXIR_ERR_INVALID, "texir_scene_set_corner_normals: null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    std::vector<float> buf((size_t)s->n_tris * 12);
+    for (int64_t i = 0; i < s->n_tris; i++) {
+        const float* src = cn + 9 * (size_t)s->slot_prim[i];
+        for (int k = 0; k < 3; k++) { buf[12 * i + 4 * k] = src[3 * k]; buf[12 * i + 4 * k + 1] = src[3 * k + 1]; buf[12 * i + 4 * k + 2] = src[3 * k + 2]; buf[12 * i + 4 * k + 3] = 0.f; }
+    }
+    if (!s->d_cnrm) HIP_TRY(hipMalloc(&s->d_cnrm, buf.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(s->d_cnrm, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice));
+    return TEXIR_OK;
+}
+
+int texir_gbuffer_cast(const texir_scene* s, const float* mvp, int32_t c, int32_t flip_v, float* pos, float* nrm, float* mask, float* uv,
+                       float* uv_da, int32_t* tri_id, void* stream)
+{
+    if (!s || !mvp || !pos || !nrm || !mask || !uv || !uv_da || !tri_id) return fail(TEXIR_ERR_INVALID, "texir_gbuffer_cast: null argument");
+    if (c <= 0 || c > 16384) return fail(TEXIR_ERR_INVALID, "texir_gbuffer_cast: bad cube_res %d", c);
+    HIP_TRY(launch_gbuffer(s->dev, mvp, (const float4*)s->d_cnrm, c, flip_v, pos, nrm, mask, uv, uv_da, tri_id, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
+int32_t texir_mip_levels(int32_t H, int32_t W, int32_t max_mip_level) { return mip_levels(H, W, max_mip_level); }
+int64_t texir_mip_elems(int32_t H, int32_t W, int32_t C, int32_t levels) { return mip_total_elems(H, W, C, levels); }
+
+static int check_tex(const char* fn, int H, int W, int C, int levels)
+{
+    if (H <= 0 || W <= 0 || C <= 0 || C > 4 || levels < 1 || levels > 16) return fail(TEXIR_ERR_INVALID, "%s: bad texture H=%d W=%d C=%d levels=%d", fn, H, W, C, levels);
+    if (levels > mip_levels(H, W, 15)) return fail(TEXIR_ERR_INVALID, "%s: %d mip levels not available for %dx%d", fn, levels, H, W);
+    return 0;
+}
+
+int texir_mip_build(float* mips, int32_t H, int32_t W, int32_t C, int32_t levels, void* stream)
+{
+    if (!mips) return fail(TEXIR_ERR_INVALID, "texir_mip_build: null argument");
+    if (int rc = check_tex("texir_mip_build", H, W, C, levels)) return rc;
+    HIP_TRY(launch_mip_build(mips, H, W, C, levels, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
+int texir_tex_fetch_forward(const float* mips, int32_t H, int32_t W, int32_t C, int32_t levels, const float* uv, const float* uv_da,
+                            int32_t filter_mode, int64_t P, float* out, void* stream)
+{
+    if (!mips || !uv || !out || (filter_mode == 1 && !uv_da)) return fail(TEXIR_ERR_INVALID, "texir_tex_fetch_forward: null argument");
+    if (filter_mode < 0 || filter_mode > 1 || P < 0) return fail(TEXIR_ERR_INVALID, "texir_tex_fetch_forward: bad filter_mode/P");
+    if (int rc = check_tex("texir_tex_fetch_forward", H, W, C, levels)) return rc;
+    HIP_TRY(launch_tex_fetch(mips, H, W, C, levels, uv, uv_da, filter_mode, P, out, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
+int texir_tex_fetch_backward(float* grad_mips, int32_t H, int32_t W, int32_t C, int32_t levels, const float* uv, const float* uv_da,
+                             int32_t filter_mode, int64_t P, const float* d_out, void* stream)
+{
+    if (!grad_mips || !uv || !d_out || (filter_mode == 1 && !uv_da)) return fail(TEXIR_ERR_INVALID, "texir_tex_fetch_backward: null argument");
+    if (filter_mode < 0 || filter_mode > 1 || P < 0) return fail(TEXIR_ERR_INVALID, "texir_tex_fetch_backward: bad filter_mode/P");
+    if (int rc = check_tex("texir_tex_fetch_backward", H, W, C, levels)) return rc;
+    HIP_TRY(launch_tex_fetch_bwd(grad_mips, H, W, C, levels, uv, uv_da, filter_mode, P, d_out, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
+int texir_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
+                    int32_t step, float clamp_lo, float clamp_hi, void* stream)
+{
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return fail(TEXIR_ERR_INVALID, "texir_adam_step: null argument");
+    if (n < 0 || step < 1) return fail(TEXIR_ERR_INVALID, "texir_adam_step: bad n/step");
+    HIP_TRY(launch_adam(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, clamp_lo, clamp_hi, (hipStream_t)stream));
     return TEXIR_OK;
 }
 

@@ -20,4 +20,15 @@ size_t loss_workspace_bytes(int64_t P, int C, int R);
 hipError_t launch_loss(int stage, int l2, const float* gt, const float* rgb, const float* albedo, const float* rough, const float* rough_womip,
                        const float* empty, const float* gtm, const uint8_t* seg, const uint8_t* hl, const uint8_t* room, int64_t P, int C, int R,
                        int hw, void* workspace, float* out, float* d_rgb, float* d_albedo, float* d_rough, hipStream_t st);
+hipError_t launch_gbuffer(const SceneDev& sc, const float* mvp_host, const float4* cnrm, int c, int flip_v, float* pos, float* nrm, float* mask,
+                          float* uv, float* uvda, int32_t* tri, hipStream_t st);
+int mip_levels(int H, int W, int max_mip_level);
+int64_t mip_total_elems(int H, int W, int C, int levels);
+hipError_t launch_mip_build(float* mips, int H, int W, int C, int levels, hipStream_t st);
+hipError_t launch_tex_fetch(const float* mips, int H, int W, int C, int levels, const float* uv, const float* uvda, int trilinear, int64_t P,
+                            float* out, hipStream_t st);
+hipError_t launch_tex_fetch_bwd(float* grad_mips, int H, int W, int C, int levels, const float* uv, const float* uvda, int trilinear, int64_t P,
+                                const float* d_out, hipStream_t st);
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step,
+                       float lo, float hi, hipStream_t st);
 }  // namespace texir

@@ -1,0 +1,327 @@
+// Material-side kernels of libtexir_hip.so:
+//   gbuffer_kernel     cube-map G-buffer (position, normal, uv, uv pixel-differentials, mask) by PRIMARY-RAY CASTING through
+//                      the same BVH -- replaces nvdiffrast rasterize + interpolate (models/mat_nvdiffrast.py:119-128,
+//                      models/tracer_o3d_irt.py:102-108).  Geometry and cameras are constant, so a view's G-buffer is
+//                      computed once and cached by the host.
+//   mip_build / tex_fetch_fwd / tex_fetch_bwd / mip_fold
+//                      nvdiffrast `texture` semantics restated (mat_nvdiffrast.py:131-139): 'linear' = bilinear with wrap,
+//                      'linear-mipmap-linear' = 2x2-box mip stack, LOD = log2 of the major axis of the uv_da footprint in
+//                      texels, clamped to [0, max level], trilinear; backward scatters into every touched mip and folds
+//                      the stack down to level 0.   (nvdiffrast is un-vendored: parity unpinned, see DESIGN.md.)
+//   adam_kernel        torch.optim.Adam step fused with the trainer's post-step clamp (train_material.py:448-458).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_common.h"
+#include "kernels.h"
+
+namespace texir {
+
+// ------------------------------------------------------------------------------------------------------------------
+// G-buffer by ray casting.  Row-vector convention of the reference: clip = [x,y,z,1] @ mvp (datasets/dataset.py:464-465).
+// Pixel (row i, col j) of a face has ndc = ((j+.5)/c*2-1, (i+.5)/c*2-1) (nvdiffrast: row 0 is clip y = -1).
+// The ray direction is LINEAR in (x,y) (see launch_gbuffer), which gives exact analytic pixel derivatives of the
+// barycentrics -- what nvdiffrast's rast_db / interpolate(diff_attrs='all') provide.
+// ------------------------------------------------------------------------------------------------------------------
+struct FaceBasis { float eye[3], d0[3], dx[3], dy[3]; };   // dir(ndc x, y) = d0 + x*dx + y*dy, from `eye`
+struct GbufArgs {
+    FaceBasis face[6];
+    const float4* cnrm;     // leaf-ordered corner normals, 3 x float4 per triangle (may be null -> geometric normal)
+    int c; int flip_v;
+    float *pos, *nrm, *mask, *uv, *uvda; int32_t* tri;
+};
+
+__global__ __launch_bounds__(kBlock) void gbuffer_kernel(SceneDev sc, GbufArgs g)
+{
+    __shared__ int lds_stack[kLdsStack * kBlock];
+    int* my_stack = lds_stack + threadIdx.x;
+    const int64_t P = (int64_t)6 * g.c * g.c;
+    uint32_t cn = 0, ct = 0;
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < P; p += (int64_t)gridDim.x * kBlock) {
+        const int face = (int)(p / ((int64_t)g.c * g.c));
+        const int rem = (int)(p - (int64_t)face * g.c * g.c);
+        const int i = rem / g.c, j = rem - i * g.c;
+        const FaceBasis& fb = g.face[face];
+        const float x = ((float)j + 0.5f) / (float)g.c * 2.f - 1.f, y = ((float)i + 0.5f) / (float)g.c * 2.f - 1.f;
+        const float ex = fb.eye[0], ey = fb.eye[1], ez = fb.eye[2];
+        float dx = fb.d0[0] + x * fb.dx[0] + y * fb.dy[0], dy = fb.d0[1] + x * fb.dx[1] + y * fb.dy[1], dz = fb.d0[2] + x * fb.dx[2] + y * fb.dy[2];
+        // d(dir)/dX, d(dir)/dY in PIXEL units (d ndc / d pixel = 2/c)
+        const float s2 = 2.f / (float)g.c;
+        float dXx = s2 * fb.dx[0], dXy = s2 * fb.dx[1], dXz = s2 * fb.dx[2];
+        float dYx = s2 * fb.dy[0], dYy = s2 * fb.dy[1], dYz = s2 * fb.dy[2];
+        Hit h = trace_closest<false>(sc, ex, ey, ez, dx, dy, dz, my_stack, cn, ct);
+        float o_pos[3] = {1.f, 0.f, 0.f}, o_n[3] = {1.f, 0.f, 0.f}, o_uv[2] = {0.f, 0.f}, o_da[4] = {0.f, 0.f, 0.f, 0.f};   // bg (mat_nvdiffrast.py:125)
+        float m = 0.f; int32_t tri = 0;
+        if (h.slot >= 0) {
+            const float4* tp = sc.tris + 3 * (size_t)h.slot;
+            float4 v0 = tp[0], e1 = tp[1], e2 = tp[2];
+            m = 1.f; tri = (int32_t)__float_as_uint(v0.w) + 1;
+            const float u = h.u, v = h.v, w = 1.f - u - v;
+            o_pos[0] = v0.x + u * e1.x + v * e2.x; o_pos[1] = v0.y + u * e1.y + v * e2.y; o_pos[2] = v0.z + u * e1.z + v * e2.z;
+            if (g.cnrm) {
+                float4 n0 = g.cnrm[3 * (size_t)h.slot], n1 = g.cnrm[3 * (size_t)h.slot + 1], n2 = g.cnrm[3 * (size_t)h.slot + 2];
+                o_n[0] = n0.x * w + n1.x * u + n2.x * v; o_n[1] = n0.y * w + n1.y * u + n2.y * v; o_n[2] = n0.z * w + n1.z * u + n2.z * v;
+            } else {
+                float nx = e1.y * e2.z - e1.z * e2.y, ny = e1.z * e2.x - e1.x * e2.z, nz = e1.x * e2.y - e1.y * e2.x;
+                float il = rsqrtf(nx * nx + ny * ny + nz * nz);
+                o_n[0] = nx * il; o_n[1] = ny * il; o_n[2] = nz * il;
+            }
+            // analytic d(u,v)/d(pixel): [e1 e2 -d] [u' v' t']^T = t * d'  (same Moeller-Trumbore solve, rhs b = t*d')
+            float px = dy * e2.z - dz * e2.y, py = dz * e2.x - dx * e2.z, pz = dx * e2.y - dy * e2.x;
+            float det = e1.x * px + e1.y * py + e1.z * pz;
+            float inv = 1.f / det;
+            float du[2], dv[2];
+            const float bx[2] = {h.t * dXx, h.t * dYx}, by[2] = {h.t * dXy, h.t * dYy}, bz[2] = {h.t * dXz, h.t * dYz};
+            for (int k = 0; k < 2; k++) {
+                du[k] = (bx[k] * px + by[k] * py + bz[k] * pz) * inv;
+                float qx = by[k] * e1.z - bz[k] * e1.y, qy = bz[k] * e1.x - bx[k] * e1.z, qz = bx[k] * e1.y - by[k] * e1.x;
+                dv[k] = (dx * qx + dy * qy + dz * qz) * inv;
+            }
+            float4 a = sc.uvs[2 * (size_t)h.slot], b = sc.uvs[2 * (size_t)h.slot + 1];
+            float a1x = a.z - a.x, a1y = a.w - a.y, a2x = b.x - a.x, a2y = b.y - a.y;
+            o_uv[0] = a.x * w + a.z * u + b.x * v; o_uv[1] = a.y * w + a.w * u + b.y * v;
+            o_da[0] = a1x * du[0] + a2x * dv[0]; o_da[1] = a1x * du[1] + a2x * dv[1];        // du/dX, du/dY
+            o_da[2] = a1y * du[0] + a2y * dv[0]; o_da[3] = a1y * du[1] + a2y * dv[1];        // dv/dX, dv/dY
+            if (g.flip_v) { o_uv[1] = 1.f - o_uv[1]; o_da[2] = -o_da[2]; o_da[3] = -o_da[3]; }
+        }
+        for (int k = 0; k < 3; k++) { g.pos[3 * p + k] = o_pos[k]; g.nrm[3 * p + k] = o_n[k]; }
+        g.mask[p] = m; g.tri[p] = tri;
+        g.uv[2 * p] = o_uv[0]; g.uv[2 * p + 1] = o_uv[1];
+        for (int k = 0; k < 4; k++) g.uvda[4 * p + k] = o_da[k];
+    }
+}
+
+static bool invert4(const double* m, double* out)
+{
+    double a[4][8];
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { a[r][c] = m[4 * r + c]; a[r][4 + c] = (r == c) ? 1.0 : 0.0; }
+    for (int col = 0; col < 4; col++) {
+        int piv = col; double best = fabs(a[col][col]);
+        for (int r = col + 1; r < 4; r++) if (fabs(a[r][col]) > best) { best = fabs(a[r][col]); piv = r; }
+        if (best == 0.0) return false;
+        if (piv != col) for (int c = 0; c < 8; c++) { double t = a[col][c]; a[col][c] = a[piv][c]; a[piv][c] = t; }
+        double d = a[col][col];
+        for (int c = 0; c < 8; c++) a[col][c] /= d;
+        for (int r = 0; r < 4; r++) if (r != col) { double f = a[r][col]; if (f != 0.0) for (int c = 0; c < 8; c++) a[r][c] -= f * a[col][c]; }
+    }
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) out[4 * r + c] = a[r][4 + c];
+    return true;
+}
+
+// mvp [6,4,4] HOST, row-vector convention.  With Minv = inverse(mvp) (rows r0..r3): eye_h = r2 (the pre-image of clip
+// (0,0,1,0)), and for a pixel at ndc (x,y) the world point at ANY depth z is X_h = x r0 + y r1 + z r2 + r3, so
+//   dir(x,y) = X_h.xyz - eye * X_h.w = x A0 + y A1 + A3,   Ak = rk.xyz - eye * rk.w     (the z term cancels exactly).
+// Evaluated in double on the host: in float32 X_h.w suffers catastrophic cancellation for n = 1e-4, f = 100.
+hipError_t launch_gbuffer(const SceneDev& sc, const float* mvp_host, const float4* cnrm, int c, int flip_v, float* pos, float* nrm, float* mask,
+                          float* uv, float* uvda, int32_t* tri, hipStream_t st)
+{
+    GbufArgs g;
+    for (int f = 0; f < 6; f++) {
+        double m[16], mi[16];
+        for (int k = 0; k < 16; k++) m[k] = (double)mvp_host[16 * f + k];
+        if (!invert4(m, mi)) return hipErrorInvalidValue;
+        const double* r0 = mi, *r1 = mi + 4, *r2 = mi + 8, *r3 = mi + 12;
+        if (r2[3] == 0.0) return hipErrorInvalidValue;               // not a perspective camera
+        double eye[3] = {r2[0] / r2[3], r2[1] / r2[3], r2[2] / r2[3]};
+        double wfar = r2[3] + r3[3];                                 // X_h.w of the face centre on the far plane
+        double sgn = wfar < 0.0 ? -1.0 : 1.0;
+        for (int k = 0; k < 3; k++) {
+            g.face[f].eye[k] = (float)eye[k];
+            g.face[f].dx[k] = (float)(sgn * (r0[k] - eye[k] * r0[3]));
+            g.face[f].dy[k] = (float)(sgn * (r1[k] - eye[k] * r1[3]));
+            g.face[f].d0[k] = (float)(sgn * (r3[k] - eye[k] * r3[3]));
+        }
+        // normalise the scale of the basis (direction length is irrelevant; keeps t in sane float range)
+        double len = sqrt((double)g.face[f].d0[0] * g.face[f].d0[0] + (double)g.face[f].d0[1] * g.face[f].d0[1] + (double)g.face[f].d0[2] * g.face[f].d0[2]);
+        if (len > 0.0) for (int k = 0; k < 3; k++) { g.face[f].d0[k] = (float)(g.face[f].d0[k] / len); g.face[f].dx[k] = (float)(g.face[f].dx[k] / len); g.face[f].dy[k] = (float)(g.face[f].dy[k] / len); }
+    }
+    g.cnrm = cnrm; g.c = c; g.flip_v = flip_v; g.pos = pos; g.nrm = nrm; g.mask = mask; g.uv = uv; g.uvda = uvda; g.tri = tri;
+    int64_t P = (int64_t)6 * c * c;
+    int64_t nb = (P + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(gbuffer_kernel, dim3((int)(nb > 2048 ? 2048 : nb)), dim3(kBlock), 0, st, sc, g);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// mip stack + texture fetch
+// ------------------------------------------------------------------------------------------------------------------
+struct MipDesc { int H, W, C, levels; int64_t off[16]; };     // level l: [H>>l, W>>l, C] at base + off[l]
+
+static MipDesc make_desc(int H, int W, int C, int levels)
+{
+    MipDesc d; d.H = H; d.W = W; d.C = C; d.levels = levels;
+    int64_t o = 0;
+    for (int l = 0; l < 16; l++) { d.off[l] = o; if (l < levels) o += (int64_t)(H >> l) * (W >> l) * C; }
+    return d;
+}
+
+int mip_levels(int H, int W, int max_mip_level)
+{
+    int l = 1;   // level 0
+    while (l <= max_mip_level && l < 16 && ((H >> (l - 1)) % 2 == 0) && ((W >> (l - 1)) % 2 == 0) && (H >> l) >= 1 && (W >> l) >= 1) l++;
+    return l;
+}
+
+int64_t mip_total_elems(int H, int W, int C, int levels)
+{
+    int64_t o = 0;
+    for (int l = 0; l < levels; l++) o += (int64_t)(H >> l) * (W >> l) * C;
+    return o;
+}
+
+__global__ __launch_bounds__(256) void mip_down_kernel(const float* __restrict__ src, float* __restrict__ dst, int Hd, int Wd, int C)
+{
+    int64_t n = (int64_t)Hd * Wd * C;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < n; g += (int64_t)gridDim.x * 256) {
+        int ch = (int)(g % C); int64_t t = g / C; int x = (int)(t % Wd), y = (int)(t / Wd);
+        const int Ws = Wd * 2;
+        const float* s = src + ((int64_t)(2 * y) * Ws + 2 * x) * C + ch;
+        dst[g] = 0.25f * (s[0] + s[C] + s[(int64_t)Ws * C] + s[(int64_t)Ws * C + C]);
+    }
+}
+
+// fold: grad[l-1][2y+a][2x+b] += 0.25 * grad[l][y][x]
+__global__ __launch_bounds__(256) void mip_fold_kernel(float* __restrict__ fine, const float* __restrict__ coarse, int Hf, int Wf, int C)
+{
+    int64_t n = (int64_t)Hf * Wf * C;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < n; g += (int64_t)gridDim.x * 256) {
+        int ch = (int)(g % C); int64_t t = g / C; int x = (int)(t % Wf), y = (int)(t / Wf);
+        fine[g] += 0.25f * coarse[((int64_t)(y >> 1) * (Wf >> 1) + (x >> 1)) * C + ch];
+    }
+}
+
+__device__ __forceinline__ float mip_level_from_da(float4 da, int W, int H, int maxl)
+{
+    float dsdx = da.x * (float)W, dsdy = da.y * (float)W, dtdx = da.z * (float)H, dtdy = da.w * (float)H;
+    float A = dsdx * dsdx + dtdx * dtdx, B = dsdy * dsdy + dtdy * dtdy, Cc = dsdx * dsdy + dtdx * dtdy;
+    float l2b = 0.5f * (A + B), l2n = 0.25f * (A - B) * (A - B) + Cc * Cc;
+    float major = l2b + sqrtf(l2n);
+    float lv = 0.5f * log2f(major);
+    return fminf(fmaxf(lv, 0.f), (float)maxl);       // log2(0) = -inf clamps to 0
+}
+
+struct Tap { int64_t i00, i10, i01, i11; float w00, w10, w01, w11; };
+
+__device__ __forceinline__ Tap bilinear_wrap(float u, float v, int W, int H)
+{
+    u = u - floorf(u); v = v - floorf(v);                      // boundary_mode='wrap'
+    float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    float x0f = floorf(x), y0f = floorf(y);
+    float fx = x - x0f, fy = y - y0f;
+    int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    if (x0 < 0) x0 += W;
+    if (y0 < 0) y0 += H;
+    if (x1 >= W) x1 -= W;
+    if (y1 >= H) y1 -= H;
+    Tap t;
+    t.i00 = (int64_t)y0 * W + x0; t.i10 = (int64_t)y0 * W + x1; t.i01 = (int64_t)y1 * W + x0; t.i11 = (int64_t)y1 * W + x1;
+    t.w00 = (1.f - fx) * (1.f - fy); t.w10 = fx * (1.f - fy); t.w01 = (1.f - fx) * fy; t.w11 = fx * fy;
+    return t;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void tex_fetch_kernel(float* __restrict__ mips, MipDesc d, const float* __restrict__ uv,
+                                                        const float* __restrict__ uvda, int trilinear, int64_t P, float* __restrict__ io)
+{
+    const int C = d.C;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
+        const float u = uv[2 * p], v = uv[2 * p + 1];
+        int l0 = 0, l1 = 0; float f = 0.f;
+        if (trilinear && d.levels > 1) {
+            float4 da = *reinterpret_cast<const float4*>(uvda + 4 * p);
+            float lv = mip_level_from_da(da, d.W, d.H, d.levels - 1);
+            l0 = (int)floorf(lv); l1 = min(l0 + 1, d.levels - 1); f = lv - (float)l0;
+        }
+        float out[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int pass = 0; pass < 2; pass++) {
+            const int l = pass ? l1 : l0;
+            const float wl = pass ? f : 1.f - f;
+            if (wl == 0.f) continue;
+            Tap t = bilinear_wrap(u, v, d.W >> l, d.H >> l);
+            float* base = mips + d.off[l];
+            for (int ch = 0; ch < C; ch++) {
+                if (BWD) {
+                    float g = io[(int64_t)C * p + ch] * wl;
+                    if (g != 0.f) {
+                        atomicAdd(base + t.i00 * C + ch, g * t.w00); atomicAdd(base + t.i10 * C + ch, g * t.w10);
+                        atomicAdd(base + t.i01 * C + ch, g * t.w01); atomicAdd(base + t.i11 * C + ch, g * t.w11);
+                    }
+                } else {
+                    out[ch] += wl * (base[t.i00 * C + ch] * t.w00 + base[t.i10 * C + ch] * t.w10 + base[t.i01 * C + ch] * t.w01 + base[t.i11 * C + ch] * t.w11);
+                }
+            }
+        }
+        if (!BWD) for (int ch = 0; ch < C; ch++) io[(int64_t)C * p + ch] = out[ch];
+    }
+}
+
+static int grid1d(int64_t n, int bs) { int64_t nb = (n + bs - 1) / bs; return (int)(nb > 4096 ? 4096 : (nb < 1 ? 1 : nb)); }
+
+// mips[0 : H*W*C] already holds level 0 (the caller copies / aliases the parameter there); builds levels 1..levels-1
+hipError_t launch_mip_build(float* mips, int H, int W, int C, int levels, hipStream_t st)
+{
+    MipDesc d = make_desc(H, W, C, levels);
+    for (int l = 1; l < levels; l++) {
+        int Hd = H >> l, Wd = W >> l;
+        hipLaunchKernelGGL(mip_down_kernel, dim3(grid1d((int64_t)Hd * Wd * C, 256)), dim3(256), 0, st, mips + d.off[l - 1], mips + d.off[l], Hd, Wd, C);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_tex_fetch(const float* mips, int H, int W, int C, int levels, const float* uv, const float* uvda, int trilinear, int64_t P,
+                            float* out, hipStream_t st)
+{
+    if (P <= 0) return hipSuccess;
+    MipDesc d = make_desc(H, W, C, levels);
+    hipLaunchKernelGGL(tex_fetch_kernel<false>, dim3(grid1d(P, 256)), dim3(256), 0, st, const_cast<float*>(mips), d, uv, uvda, trilinear, P, out);
+    return hipGetLastError();
+}
+
+// grad_mips must be zero-initialised [mip_total_elems]; after the scatter the stack is folded into level 0 (= d tex)
+hipError_t launch_tex_fetch_bwd(float* grad_mips, int H, int W, int C, int levels, const float* uv, const float* uvda, int trilinear, int64_t P,
+                                const float* d_out, hipStream_t st)
+{
+    MipDesc d = make_desc(H, W, C, levels);
+    if (P > 0)
+        hipLaunchKernelGGL(tex_fetch_kernel<true>, dim3(grid1d(P, 256)), dim3(256), 0, st, grad_mips, d, uv, uvda, trilinear, P, const_cast<float*>(d_out));
+    if (trilinear)
+        for (int l = levels - 1; l >= 1; l--) {
+            int Hf = H >> (l - 1), Wf = W >> (l - 1);
+            hipLaunchKernelGGL(mip_fold_kernel, dim3(grid1d((int64_t)Hf * Wf * C, 256)), dim3(256), 0, st, grad_mips + d.off[l - 1], grad_mips + d.off[l], Hf, Wf, C);
+        }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// torch.optim.Adam (no amsgrad / weight decay / maximize), same operation order as torch's single-tensor path, fused
+// with the trainer's clamp (materials_r in [1e-2, 0.8], materials_a >= 0; train_material.py:458,592-593)
+// ------------------------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   int64_t n, float beta1, float beta2, float eps, float step_size, float bc2_sqrt,
+                                                   float lo, float hi)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float gi = g[i];
+        float mi = m[i] + (gi - m[i]) * (1.f - beta1);                 // exp_avg.lerp_(grad, 1 - beta1)
+        float vi = v[i] * beta2 + (gi * gi) * (1.f - beta2);            // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+        float denom = sqrtf(vi) / bc2_sqrt + eps;
+        float pi = p[i] + (mi / denom) * (-step_size);                  // param.addcdiv_(exp_avg, denom, value=-step_size)
+        pi = fminf(fmaxf(pi, lo), hi);
+        m[i] = mi; v[i] = vi; p[i] = pi;
+    }
+}
+#pragma clang fp contract(fast)
+
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step,
+                       float lo, float hi, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    float step_size = (float)((double)lr / bc1);
+    float bc2_sqrt = (float)sqrt(bc2);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n, 256 * 4)), dim3(256), 0, st, p, g, m, v, n, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+    return hipGetLastError();
+}
+
+}  // namespace texir
