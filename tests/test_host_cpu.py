@@ -1,0 +1,97 @@
+"""CPU tests of host-side logic: conf parser, Cube2Pano restatement (golden), cameras."""
+import numpy as np
+import pytest
+import torch
+
+# a conf shaped like the reference's configs/syn.conf (re-typed, not copied)
+CONF = """
+train{
+    expname = default
+    dataset_class = datasets.dataset.ImageCubeSyn
+    model_class = models.mat_nvdiffrast.MaterialModel
+    irf_loss_class = models.loss.RenderLoss
+    plot_freq = 10          # iterations
+    alpha_milestones = [25000,50000,75000]  # iterations
+    mat_epoch = 40
+    mat_learning_rate = 3e-2
+    mat_sched_step = 20
+    mat_sched_factor = 0.8
+    optim_cam = False
+    pano_img_res = [256,512]
+    sample_light = [32, 16]
+    hdr_exposure = 5
+    batch_size = 1
+    path_mesh_open3d = ../data/inverse/customHouse/vrproc/hdr_texture/out1.obj
+}
+val{
+    dataset_class = datasets.dataset.ImageMeshPoint
+}
+render_loss
+{
+    loss_type = L1
+    w_gradient = 1
+}
+models{
+    feature_vector_size = 256
+    tracer{
+
+    }
+    render{
+        sample_type = [ uniform, importance]
+    }
+    irrf_network
+    {
+        dims = [ 512, 512, 512, 512]
+        p_input_dim = 3
+    }
+}
+"""
+
+
+def test_conf_parser_reads_reference_shaped_conf():
+    from texir_code_amd.conf import parse_string, ConfigMissing
+    c = parse_string(CONF)
+    assert c.get_string("train.model_class") == "models.mat_nvdiffrast.MaterialModel"
+    assert c.get_string("train.dataset_class") == "datasets.dataset.ImageCubeSyn"
+    assert c.get_int("train.mat_epoch") == 40 and c.get_int("train.batch_size") == 1
+    assert abs(c.get_float("train.mat_learning_rate") - 3e-2) < 1e-12 and c.get_float("train.hdr_exposure") == 5.0
+    assert c.get_bool("train.optim_cam") is False
+    assert c.get_list("train.pano_img_res") == [256, 512] and c.get_list("train.sample_light") == [32, 16]
+    assert c.get_list("models.render.sample_type") == ["uniform", "importance"]
+    assert c.get_list("train.env_res", default=[8, 16]) == [8, 16]
+    assert dict(c.get_config("render_loss")) == {"loss_type": "L1", "w_gradient": 1}
+    assert c.get_config("models.tracer") == {}
+    assert c.get_string("train.path_mesh_open3d").endswith("hdr_texture/out1.obj")
+    assert c.get_int("train.mat_sched_step", default=100) == 20
+    with pytest.raises(ConfigMissing):
+        c.get_string("train.nope")
+
+
+def test_cube2pano_matches_reference(golden):
+    from texir_code_amd.cube2pano import Cube2Pano
+    g = golden("cube2pano.npz")
+    c2p = Cube2Pano(pano_width=64, pano_height=32, cube_lenth=16, cube_channel=6, is_cuda=False)
+    assert np.array_equal(np.nan_to_num(c2p.grid.numpy(), nan=7.0), np.nan_to_num(g["grid"], nan=7.0))
+    assert np.array_equal(c2p.mask.numpy(), g["mask"])
+    pano = c2p.ToPano(torch.from_numpy(g["cube"]).reshape(1, -1, 16, 16))
+    assert np.allclose(pano.numpy(), g["pano"], atol=1e-6)
+
+
+def test_cube_mvps_structure():
+    from texir_code_amd import cameras
+    E = np.eye(4, dtype=np.float32)
+    E[:3, 3] = [1.0, 2.0, 3.0]
+    mvp, cam = cameras.cube_mvps(E)
+    assert mvp.shape == (6, 4, 4) and torch.allclose(cam, torch.tensor([1.0, 2.0, 3.0]))
+    # a point straight ahead (+z) of the camera projects to the centre of face 1 with w = depth
+    p = torch.tensor([1.0, 2.0, 8.0, 1.0])
+    clip = p @ mvp[1]
+    assert abs(clip[0]) < 1e-6 and abs(clip[1]) < 1e-6 and abs(clip[3] - 5.0) < 1e-5
+    # each axis direction is the centre of exactly one face
+    hits = []
+    for d in ([1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]):
+        q = torch.tensor([1.0 + d[0], 2.0 + d[1], 3.0 + d[2], 1.0])
+        f = [i for i in range(6) if (q @ mvp[i])[3] > 0.5 and abs((q @ mvp[i])[0]) < 1e-5 and abs((q @ mvp[i])[1]) < 1e-5]
+        assert len(f) == 1
+        hits.append(f[0])
+    assert sorted(hits) == [0, 1, 2, 3, 4, 5]

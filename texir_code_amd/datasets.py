@@ -1,0 +1,163 @@
+"""Dataset side of the hot path.
+
+SynCubeDataset exposes what the runners read from datasets.dataset.ImageCubeDerived / ImageCubeSyn
+(datasets/dataset.py:352-549, 669-893): .ids, .extrinsics_list (per-view [6,4,4] mvp), .cam_position_list, .images_items
+and the __getitem__ dict keys -- for dataset directories in the layout write_synthetic_dataset() produces (the reference's
+own dataset is private, README.md:21-34).  ids / extrinsics use the reference's text formats (info/aligned.txt,
+info/final_extrinsics.txt); per-view cube-face images are stored as cube/<id>.npz.
+"""
+import os
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from . import cameras, io_formats as IO
+
+
+class SynCubeDataset(Dataset):
+    def __init__(self, path_mesh, resolution=[1000, 2000], hdr_exposure=1.0):
+        super().__init__()
+        self.path_mesh = path_mesh
+        self.path_root = os.path.dirname(os.path.dirname(os.path.dirname(path_mesh)))     # <root>/vrproc/hdr_texture/out1.obj
+        self.resolution = resolution
+        self.cube_res = int(resolution[1] / 4)
+        self.hdr_exposure = hdr_exposure
+        self.ids = self.read_id()
+        self.extrinsics_list, self.cam_position_list = self.read_extrinsic()
+        self.images_items = self.read_images(self.ids)
+
+    def __len__(self):
+        return len(self.ids)
+
+    def __getitem__(self, index):
+        it = self.images_items[index]
+        return {"color": it["color"], "mask": it["mask"], "segs": it["segs"], "cam_to_world": self.extrinsics_list[index],
+                "id": self.ids[index], "cam_position": self.cam_position_list[index]}
+
+    def read_id(self, txt_name="aligned.txt"):
+        with open(os.path.join(self.path_root, "info", txt_name), "r") as f:
+            return [l.strip() for l in f.readlines() if l.strip()]
+
+    def read_extrinsic(self, txt_name="final_extrinsics.txt"):
+        with open(os.path.join(self.path_root, "info", txt_name), "r") as f:
+            lines = [l.replace(" \n", "\n") for l in f.readlines()]
+        ext = np.loadtxt(lines[1:], delimiter=" ").reshape(-1, 4, 4)             # first line is a header (dataset.py:409)
+        mvps, cams = [], []
+        for E in ext:
+            mvp, cam = cameras.cube_mvps(E.astype(np.float32))
+            mvps.append(mvp)
+            cams.append(cam)
+        return mvps, cams
+
+    def read_images(self, ids):
+        items = []
+        for i in ids:
+            p = os.path.join(self.path_root, "cube", "%s.npz" % i)
+            if not os.path.exists(p):
+                items.append(None)
+                continue
+            z = np.load(p)
+            c = z["color"].shape[1]
+            if c != self.cube_res:
+                raise ValueError("%s holds %d^2 cube faces but train.pano_img_res implies %d^2" % (p, c, self.cube_res))
+            items.append({"color": torch.from_numpy(z["color"]) * (2 ** self.hdr_exposure), "mask": torch.from_numpy(z["mask"]),
+                          "segs": torch.from_numpy(z["segs"])})
+        return items
+
+
+def parse_roomseg(path):
+    """utils/general.py:115-125"""
+    with open(os.path.join(path, "originOccupancyGrid_f0.meta"), "r") as f:
+        s, w, h, xmin, zmin = f.readline().strip().split(" ")
+    img = IO.read_png(os.path.join(path, "roomSegs_uchar_f0.png")).astype(np.float32)
+    room = torch.from_numpy(img)[:, :, 0:1].unsqueeze(0).permute(0, 3, 1, 2)
+    return float(s), float(w), float(h), float(xmin), float(zmin), room
+
+
+def write_synthetic_dataset(root, T=20000, texel_res=256, tex_res=256, n_side=2, seed=666):
+    """mesh + radiance texture + index texture + exact texel G-buffer + cameras (no GT images: see render_gt_views)"""
+    from . import synth
+    sc = synth.make_scene(T, seed=seed, tex_res=tex_res)
+    d = os.path.join(root, "vrproc", "hdr_texture")
+    os.makedirs(d, exist_ok=True)
+    os.makedirs(os.path.join(root, "info"), exist_ok=True)
+    os.makedirs(os.path.join(root, "cube"), exist_ok=True)
+    os.makedirs(os.path.join(root, "roomseg"), exist_ok=True)
+    IO.write_obj(os.path.join(d, "out1.obj"), sc["verts"], sc["tris"], sc["tri_uvs"])
+    IO.write_hdr(os.path.join(d, "hdr_texture.hdr"), sc["hdr"][::-1])             # file orientation = un-flipped
+    pos, nrm, valid = synth.make_texel_gbuffer(sc, texel_res)
+    np.savez_compressed(os.path.join(d, "texel_gbuffer.npz"), position=pos[::-1].copy(), normal=nrm[::-1].copy())
+    idx = np.zeros((texel_res, texel_res, 3), np.uint16)
+    idx[valid[::-1] > 0] = (1, 1, 0)                                               # non-zero code: not a seam; codes unused with texel_gbuffer
+    IO.write_png(os.path.join(d, "0.png"), idx[..., ::-1])                        # cv2 stores BGR
+    cams = cameras.grid_cameras(n_side)
+    with open(os.path.join(root, "info", "aligned.txt"), "w") as f:
+        f.write("\n".join("view%03d" % i for i in range(len(cams))) + "\n")
+    with open(os.path.join(root, "info", "final_extrinsics.txt"), "w") as f:
+        f.write("%d\n" % len(cams))
+        for E in cams:
+            for r in E:
+                f.write(" ".join("%.9g" % x for x in r) + "\n")
+    with open(os.path.join(root, "roomseg", "originOccupancyGrid_f0.meta"), "w") as f:
+        f.write("0.05 200 200 -1 -1\n")
+    IO.write_png(os.path.join(root, "roomseg", "roomSegs_uchar_f0.png"), np.ones((200, 200, 3), np.uint8))
+    return sc
+
+
+def write_conf(path, root, cube_res=32, spp=(64, 16), albedo_res=256, rough_res=256, epochs=1, model="mat"):
+    txt = """train{
+    expname = synthetic
+    dataset_class = datasets.dataset.ImageCubeSyn
+    model_class = %s
+    irf_loss_class = models.loss.RenderLoss
+    plot_freq = 1000
+    ckpt_freq = 1000
+    mat_epoch = %d
+    mat_learning_rate = 3e-2
+    mat_sched_step = 20
+    mat_sched_factor = 0.8
+    optim_cam = False
+    pano_img_res = [%d,%d]
+    sample_light = [%d, %d]
+    hdr_exposure = 0
+    env_res = [8,16]
+    batch_size = 1
+    albedo_res = %d
+    roughness_res = %d
+    path_mesh_open3d = %s
+}
+render_loss
+{
+    loss_type = L1
+    w_gradient = 1
+}
+models{
+    render{
+        sample_type = [ uniform, importance]
+    }
+}
+""" % ("models.mat_nvdiffrast.MaterialModel" if model == "mat" else "models.tracer_o3d_irt.TracerO3d", epochs, cube_res * 2, cube_res * 4,
+       spp[0], spp[1], albedo_res, rough_res, os.path.join(root, "vrproc", "hdr_texture", "out1.obj"))
+    with open(path, "w") as f:
+        f.write(txt)
+
+
+def render_gt_views(root, conf, sc, albedo_res, rough_res, seed=666):
+    """GT cube images rendered by our own forward from ground-truth materials; seg ids = chart class"""
+    from . import synth
+    from .models import MaterialModel
+    ds = SynCubeDataset(conf.get_string("train.path_mesh_open3d"), conf.get_list("train.pano_img_res"), conf.get_float("train.hdr_exposure"))
+    model = MaterialModel(conf, ds.ids, ds.extrinsics_list).cuda()
+    alb, rgh = synth.make_gt_materials(sc, albedo_res, rough_res, seed)
+    with torch.no_grad():
+        model.materials_a.copy_(torch.from_numpy(alb))
+        model.materials_r.copy_(torch.from_numpy(rgh))
+        tri_class = torch.from_numpy(sc["tri_class"]).cuda()
+        for i, vid in enumerate(ds.ids):
+            res = model(ds.extrinsics_list[i], vid, ds.cam_position_list[i], 2)
+            tri = model._gbuffer(ds.extrinsics_list[i], vid)["tri_id"].long()
+            segs = torch.where(tri > 0, tri_class[(tri - 1).clamp(min=0)].long(), torch.zeros_like(tri)).float().unsqueeze(-1)
+            np.savez_compressed(os.path.join(root, "cube", "%s.npz" % vid), color=res["rgb"].cpu().numpy(),
+                                mask=res["empty_mask"].cpu().numpy(), segs=segs.cpu().numpy())
+    return alb, rgh

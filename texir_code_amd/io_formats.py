@@ -1,0 +1,232 @@
+"""On-disk formats around the hot path, replacing cv2 / pyredner / Open3D loaders:
+Radiance .hdr (RGBE, flat + new-style RLE), 8/16-bit PNG (index texture "0.png", tracer_o3d_irt.py:91), Wavefront OBJ with
+the conventions the reference relies on (Open3D per-corner triangle_uvs un-flipped, tracer_o3d_irt.py:85; pyredner uvs
+with V flipped)."""
+import struct
+import zlib
+
+import numpy as np
+
+
+# ------------------------------------------------------------------------------------------------- Radiance RGBE
+def rgbe_encode(rgb):
+    rgb = np.asarray(rgb, np.float32)
+    mx = rgb.max(axis=-1)
+    out = np.zeros(rgb.shape[:-1] + (4,), np.uint8)
+    ok = mx > 1e-32
+    m, e = np.frexp(mx[ok])
+    scale = (m * 256.0 / mx[ok]).astype(np.float32)
+    out[ok, 0:3] = np.clip(rgb[ok] * scale[:, None], 0, 255).astype(np.uint8)
+    out[ok, 3] = (e + 128).astype(np.uint8)
+    return out
+
+
+def rgbe_decode(rgbe):
+    e = rgbe[..., 3].astype(np.int32)
+    f = np.where(e > 0, np.ldexp(1.0, e - (128 + 8)), 0.0).astype(np.float32)
+    return rgbe[..., 0:3].astype(np.float32) * f[..., None]
+
+
+def write_hdr(path, rgb):
+    """rgb [H,W,3] float32, RGB order, row 0 = top.  Flat (un-compressed) scanlines."""
+    rgb = np.asarray(rgb, np.float32)
+    H, W, _ = rgb.shape
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n")
+        f.write(("-Y %d +X %d\n" % (H, W)).encode())
+        f.write(rgbe_encode(rgb).tobytes())
+
+
+def read_hdr(path):
+    """-> [H,W,3] float32 in RGB order (cv2.imread(...,-1)[:,:,::-1] of the reference), row 0 = top"""
+    with open(path, "rb") as f:
+        data = f.read()
+    pos = data.index(b"\n\n") + 2 if b"\n\n" in data[:4096] else None
+    if pos is None or not data.startswith(b"#?"):
+        raise ValueError("%s: not a Radiance HDR file" % path)
+    end = data.index(b"\n", pos)
+    dims = data[pos:end].split()
+    if len(dims) != 4 or dims[0] != b"-Y" or dims[2] != b"+X":
+        raise ValueError("%s: unsupported resolution line %r" % (path, data[pos:end]))
+    H, W = int(dims[1]), int(dims[3])
+    buf = np.frombuffer(data, np.uint8, offset=end + 1)
+    if buf.size == H * W * 4 and not (W >= 8 and W < 32768 and buf[0] == 2 and buf[1] == 2):
+        return rgbe_decode(buf.reshape(H, W, 4))
+    out = np.empty((H, W, 4), np.uint8)
+    p = 0
+    for y in range(H):
+        if W < 8 or W >= 32768 or buf[p] != 2 or buf[p + 1] != 2 or (buf[p + 2] & 0x80):
+            out[y] = buf[p:p + 4 * W].reshape(W, 4)      # flat scanline
+            p += 4 * W
+            continue
+        if ((int(buf[p + 2]) << 8) | int(buf[p + 3])) != W:
+            raise ValueError("%s: bad RLE scanline width" % path)
+        p += 4
+        for c in range(4):
+            x = 0
+            while x < W:
+                n = int(buf[p]); p += 1
+                if n > 128:
+                    n -= 128
+                    out[y, x:x + n, c] = buf[p]; p += 1
+                else:
+                    out[y, x:x + n, c] = buf[p:p + n]; p += n
+                x += n
+    return rgbe_decode(out)
+
+
+# ------------------------------------------------------------------------------------------------- PNG (8/16 bit)
+def write_png(path, img):
+    """img [H,W,C] uint8 or uint16, C in {1,3,4}, channel order as stored (RGB)"""
+    img = np.ascontiguousarray(img)
+    if img.ndim == 2:
+        img = img[..., None]
+    H, W, C = img.shape
+    depth = 16 if img.dtype == np.uint16 else 8
+    ctype = {1: 0, 3: 2, 4: 6}[C]
+    raw = img.astype(">u2" if depth == 16 else np.uint8).tobytes()
+    stride = W * C * depth // 8
+    lines = b"".join(b"\x00" + raw[y * stride:(y + 1) * stride] for y in range(H))
+
+    def chunk(tag, payload):
+        return struct.pack(">I", len(payload)) + tag + payload + struct.pack(">I", zlib.crc32(tag + payload) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, depth, ctype, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(lines, 3)) + chunk(b"IEND", b""))
+
+
+def read_png(path):
+    """-> [H,W,C] uint8/uint16 in the file's channel order (RGB[A]); non-interlaced, colour types 0/2/6, depth 8/16"""
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError("%s: not a PNG" % path)
+    p, idat, hdr = 8, [], None
+    while p < len(data):
+        n, tag = struct.unpack(">I4s", data[p:p + 8])
+        body = data[p + 8:p + 8 + n]
+        if tag == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif tag == b"IDAT":
+            idat.append(body)
+        elif tag == b"IEND":
+            break
+        p += 12 + n
+    W, H, depth, ctype, _, _, interlace = hdr
+    if interlace or depth not in (8, 16) or ctype not in (0, 2, 6):
+        raise ValueError("%s: unsupported PNG flavour (depth %d, colour type %d, interlace %d)" % (path, depth, ctype, interlace))
+    C = {0: 1, 2: 3, 6: 4}[ctype]
+    bpp = C * depth // 8
+    stride = W * bpp
+    raw = np.frombuffer(zlib.decompress(b"".join(idat)), np.uint8).reshape(H, stride + 1)
+    out = np.zeros((H, stride), np.uint8)
+    prev = np.zeros(stride, np.int32)
+    for y in range(H):
+        ft = int(raw[y, 0])
+        line = raw[y, 1:].astype(np.int32)
+        if ft == 0:
+            cur = line
+        elif ft == 2:
+            cur = (line + prev) & 255
+        elif ft == 1:
+            cur = line.copy()
+            for b in range(bpp):               # per byte lane prefix sums mod 256
+                cur[b::bpp] = np.cumsum(line[b::bpp]) & 255
+        else:
+            cur = np.zeros(stride, np.int32)
+            for x in range(stride):
+                a = cur[x - bpp] if x >= bpp else 0
+                b_ = prev[x]
+                c = prev[x - bpp] if x >= bpp else 0
+                if ft == 3:
+                    pred = (a + b_) >> 1
+                else:
+                    pa, pb, pc = abs(b_ - c), abs(a - c), abs(a + b_ - 2 * c)
+                    pred = a if (pa <= pb and pa <= pc) else (b_ if pb <= pc else c)
+                cur[x] = (line[x] + pred) & 255
+        out[y] = cur
+        prev = cur
+    if depth == 16:
+        return out.view(">u2").astype(np.uint16).reshape(H, W, C)
+    return out.reshape(H, W, C)
+
+
+def read_index_texture(path):
+    """"0.png" as cv2.imread(path, -1) returns it (BGR channel order): ch0 = row code, ch1 = col code, ch2 = panorama id
+    (models/tracer_o3d_irt.py:91,119-135)."""
+    img = read_png(path)
+    return np.ascontiguousarray(img[..., :3][..., ::-1])
+
+
+# ------------------------------------------------------------------------------------------------- Wavefront OBJ
+def load_obj(path):
+    """-> dict(vertices [V,3], indices [T,3], uvs [Vt,2] (as written in the file), uv_indices [T,3], normals [Vn,3] | None,
+    normal_indices [T,3] | None).  Faces with more than 3 corners are fan-triangulated; negative indices resolved."""
+    v, vt, vn, fi, ft, fn = [], [], [], [], [], []
+    with open(path, "r") as f:
+        for line in f:
+            if line.startswith("v "):
+                v.append([float(x) for x in line.split()[1:4]])
+            elif line.startswith("vt "):
+                vt.append([float(x) for x in line.split()[1:3]])
+            elif line.startswith("vn "):
+                vn.append([float(x) for x in line.split()[1:4]])
+            elif line.startswith("f "):
+                corners = []
+                for tok in line.split()[1:]:
+                    parts = tok.split("/")
+                    a = int(parts[0]); a = a - 1 if a > 0 else len(v) + a
+                    b = -1
+                    if len(parts) > 1 and parts[1]:
+                        b = int(parts[1]); b = b - 1 if b > 0 else len(vt) + b
+                    c = -1
+                    if len(parts) > 2 and parts[2]:
+                        c = int(parts[2]); c = c - 1 if c > 0 else len(vn) + c
+                    corners.append((a, b, c))
+                for k in range(1, len(corners) - 1):
+                    tri = (corners[0], corners[k], corners[k + 1])
+                    fi.append([t[0] for t in tri]); ft.append([t[1] for t in tri]); fn.append([t[2] for t in tri])
+    out = {"vertices": np.asarray(v, np.float32).reshape(-1, 3), "indices": np.asarray(fi, np.int32).reshape(-1, 3),
+           "uvs": np.asarray(vt, np.float32).reshape(-1, 2), "uv_indices": np.asarray(ft, np.int32).reshape(-1, 3),
+           "normals": np.asarray(vn, np.float32).reshape(-1, 3) if vn else None,
+           "normal_indices": np.asarray(fn, np.int32).reshape(-1, 3) if vn else None}
+    return out
+
+
+def triangle_uvs_open3d(obj):
+    """np.asarray(o3d.io.read_triangle_mesh(path).triangle_uvs): per-corner [3T,2], V NOT flipped (tracer_o3d_irt.py:85)"""
+    if obj["uvs"].shape[0] == 0:
+        raise ValueError("mesh has no texture coordinates")
+    return obj["uvs"][obj["uv_indices"].reshape(-1)].astype(np.float32)
+
+
+def corner_normals(obj):
+    """[3T,3] shading normals per corner; geometric normals when the file has no vn"""
+    if obj["normals"] is not None and (obj["normal_indices"] >= 0).all():
+        return obj["normals"][obj["normal_indices"].reshape(-1)].astype(np.float32)
+    vtx, idx = obj["vertices"], obj["indices"]
+    n = np.cross(vtx[idx[:, 1]] - vtx[idx[:, 0]], vtx[idx[:, 2]] - vtx[idx[:, 0]])
+    n = n / np.maximum(np.linalg.norm(n, axis=-1, keepdims=True), 1e-20)
+    return np.repeat(n, 3, axis=0).astype(np.float32)
+
+
+def write_obj(path, vertices, indices, tri_uvs, tri_normals=None):
+    """per-corner uvs [3T,2] (and optional per-corner normals [3T,3]) written un-indexed"""
+    T = indices.shape[0]
+    with open(path, "w") as f:
+        f.write("mtllib out1.mtl\nusemtl material_0\n")
+        for p in vertices:
+            f.write("v %.9g %.9g %.9g\n" % tuple(p))
+        for t in tri_uvs:
+            f.write("vt %.9g %.9g\n" % tuple(t))
+        if tri_normals is not None:
+            for n in tri_normals:
+                f.write("vn %.9g %.9g %.9g\n" % tuple(n))
+        for i in range(T):
+            a, b, c = indices[i] + 1
+            k = 3 * i + 1
+            if tri_normals is not None:
+                f.write("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (a, k, k, b, k + 1, k + 1, c, k + 2, k + 2))
+            else:
+                f.write("f %d/%d %d/%d %d/%d\n" % (a, k, b, k + 1, c, k + 2))

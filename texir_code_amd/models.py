@@ -1,0 +1,253 @@
+"""Drop-in model classes for the reference's class-name plugin seam (utils/general.py:12-18 get_class):
+
+  models.tracer_o3d_irt.TracerO3d      -> TracerO3d      (models/tracer_o3d_irt.py:35-180)
+  models.mat_nvdiffrast.MaterialModel  -> MaterialModel  (models/mat_nvdiffrast.py:35-320)
+
+Same constructor arguments, attributes the trainers touch (materials_a, materials_r, sample_l, texture) and forward()
+contracts; all arithmetic runs in libtexir_hip.so.  Open3D/Embree, nvdiffrast, pyredner and cv2 are replaced by the BVH
+scene handle, the ray-cast G-buffer + texture kernels and the loaders in io_formats.py.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import dist_util, gbuffer as GB, io_formats as IO
+from .cube2pano import Cube2Pano
+from .scene import Scene, generate_dir, spec_render
+from .texture import texture as tex_fetch
+
+TINY_NUMBER = 1e-6
+
+
+def get_mip_level(n):
+    """utils/general.py:88-93"""
+    count = 0
+    while not (n & 1 or n == 1):
+        n >>= 1
+        count += 1
+    return count
+
+
+def rgb_to_intensity(t, dim=-1):
+    """utils/general.py:95-112"""
+    r, g, b = t.unbind(dim)
+    return (0.29900 * r + 0.58700 * g + 0.11400 * b).unsqueeze(dim)
+
+
+def hdr_scale(img, base=math.e):
+    """utils/general.py:61-66"""
+    return torch.log(img + 1) / math.log(base)
+
+
+def _sibling(path_mesh, name):
+    # the reference derives every asset path with str.replace("out1.obj", name)
+    return path_mesh.replace("out1.obj", name) if "out1.obj" in path_mesh else os.path.join(os.path.dirname(path_mesh), name)
+
+
+def _load_scene(conf, device):
+    """mesh + radiance texture -> Scene (tracer_o3d_irt.py:75-89 / mat_nvdiffrast.py:87-101)"""
+    path_mesh = conf.get_string("train.path_mesh_open3d")
+    obj = IO.load_obj(path_mesh)
+    tri_uvs = IO.triangle_uvs_open3d(obj)
+    tex = IO.read_hdr(_sibling(path_mesh, "hdr_texture.hdr"))           # RGB
+    tex = np.ascontiguousarray(tex[::-1])                                # cv2.flip(texture, 0)
+    tex = tex * np.float32(2 ** conf.get_float("train.hdr_exposure"))
+    scene = Scene(obj["vertices"], obj["indices"], tri_uvs, tex, device=device)
+    GB.set_corner_normals(scene, IO.corner_normals(obj))
+    return scene, obj, torch.from_numpy(tex)
+
+
+class TracerO3d(nn.Module):
+    """Irradiance-texture model: forward() -> [H,W,3] irradiance (cuda tensor)."""
+
+    def __init__(self, conf, ids, extrinsics, optim_cam=False, gt_irf=True):
+        super().__init__()
+        self.resolution = conf.get_list("train.env_res", default=[8, 16])
+        self.path_traced_mesh = conf.get_string("train.path_mesh_open3d")
+        self.pano_res = conf.get_list("train.pano_img_res", default=[1000, 2000])
+        self.sample_l = conf.get_list("train.sample_light", default=[64, 64])
+        self.sample_type = conf.get_list("models.render.sample_type", default=["uniform", "importance"])
+        self.optim_cam, self.ids, self.extrinsics, self.conf = optim_cam, ids, extrinsics, conf
+        self.cube_res = 256
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.scene, self.obj, self.texture = _load_scene(conf, self.device.index)
+        # index texture at NATIVE resolution by default; the reference resizes to 1024^2 (tracer_o3d_irt.py:95).
+        # Optional key train.irt_res picks a nearest-neighbour resize.
+        idx = IO.read_index_texture(_sibling(self.path_traced_mesh, "0.png"))
+        res = conf.get("train.irt_res", None)
+        if res:
+            res = int(res)
+            ry = (np.arange(res) * idx.shape[0] // res)
+            rx = (np.arange(res) * idx.shape[1] // res)
+            idx = idx[ry][:, rx]
+        self.index_texture = np.ascontiguousarray(idx)
+        # optional exact texel G-buffer written by the synthetic generator (bypasses the panorama gather)
+        self.texel_gbuffer_path = _sibling(self.path_traced_mesh, "texel_gbuffer.npz")
+        self.use_texel_gbuffer = conf.get("train.texel_gbuffer", "auto")
+
+    # -- tracer_o3d_irt.py:99-112 -----------------------------------------------------------------------------------
+    def generate_positions(self):
+        self.position_normal_list = []
+        c2p = Cube2Pano(pano_width=1024, pano_height=512, cube_lenth=self.cube_res, cube_channel=6, is_cuda=True)
+        for i in range(len(self.ids)):
+            gb = GB.cast_gbuffer(self.scene, self.extrinsics[i], self.cube_res, flip_v=False)
+            g = torch.cat([gb["position"], gb["normal"]], dim=-1)              # bg already (1,0,0,1,0,0)
+            g = torch.cat([g[..., 0:3] + 1e-2 * g[..., 3:6], g[..., 3:6]], dim=-1)
+            res = c2p.ToPano(g.permute(0, 3, 1, 2).reshape(1, -1, self.cube_res, self.cube_res))[0].permute(1, 2, 0)
+            self.position_normal_list.append(res)
+
+    # -- tracer_o3d_irt.py:115-142 (host numpy in the reference; same integer arithmetic on the device) ------------
+    def calcute_position_normal_texture(self):
+        idx = torch.from_numpy(self.index_texture.astype(np.int64)).to(self.device)       # [H,W,3] (row code, col code, pano id)
+        H, W, _ = idx.shape
+        pos = torch.zeros((H, W, 3), device=self.device)
+        nrm = torch.zeros((H, W, 3), device=self.device)
+        for hdr_id in torch.unique(idx[..., 2]).tolist():
+            if hdr_id >= len(self.position_normal_list):
+                raise ValueError("index texture references panorama %d but only %d views exist" % (hdr_id, len(self.position_normal_list)))
+            sel = idx[..., 2] == hdr_id
+            pano = self.position_normal_list[hdr_id]
+            h, w, _ = pano.shape
+            col = torch.clamp((idx[..., 1][sel].double() / 50000 * w).long(), 0, w - 1)
+            row = torch.clamp((idx[..., 0][sel].double() / 50000 * h).long(), 0, h - 1)
+            pos[sel] = pano[row, col, 0:3]
+            nrm[sel] = pano[row, col, 3:6]
+        seam = idx.sum(-1) == 0
+        pos[seam] = 0
+        nrm[seam] = 0
+        self.position_texture, self.normal_texture = pos, nrm
+
+    def _load_texel_gbuffer(self):
+        z = np.load(self.texel_gbuffer_path)
+        self.position_texture = torch.from_numpy(z["position"]).to(self.device)
+        self.normal_texture = torch.from_numpy(z["normal"]).to(self.device)
+
+    # -- tracer_o3d_irt.py:145-180 ----------------------------------------------------------------------------------
+    def forward(self):
+        use_file = self.use_texel_gbuffer in (True, "file") or (self.use_texel_gbuffer == "auto" and os.path.exists(self.texel_gbuffer_path))
+        if use_file:
+            self._load_texel_gbuffer()
+        else:
+            self.generate_positions()
+            self.calcute_position_normal_texture()
+        print("Finish precomputing model!")
+        H, W, _ = self.position_texture.shape
+        pos = self.position_texture.reshape(-1, 3).contiguous()
+        nrm = self.normal_texture.reshape(-1, 3).contiguous()
+        nt = pos.shape[0]
+        # shifts: the reference draws torch.rand(512,1,2) per 512-texel batch from the CPU generator (sample_util.py:102);
+        # one [nt,1,2] draw consumes the same stream in the same order
+        shift = torch.rand(nt, 1, 2).reshape(nt, 2).to(self.device)
+        seam = torch.from_numpy((self.index_texture.astype(np.int64).sum(-1) == 0).reshape(-1)).to(self.device)
+        ids = torch.nonzero(~seam)[:, 0].to(torch.int32)
+        rank, world, _ = dist_util.world_info()
+        ids = dist_util.shard_block_cyclic(ids, rank, world)
+        irr = torch.zeros((nt, 3), device=self.device)
+        self.scene.irt_generate(pos, nrm, shift, int(self.sample_l[0]), self.sample_type[0], texel_ids=ids, out=irr)
+        dist_util.assemble_sum(irr)
+        self.ir_texture = irr.reshape(H, W, 3)
+        return self.ir_texture
+
+    def query_irf(self, points, directions, num_sample):
+        """tracer_o3d_irt.py:240-269: points [b,n,3], directions [b,n,1,3] -> radiance [b,n,3]"""
+        b, n, _ = points.shape
+        return self.scene.trace_shade(points.reshape(-1, 3), directions.reshape(-1, 3)).reshape(b, n, 3)
+
+
+class MaterialModel(nn.Module):
+    """Material model: forward(mvp, id, cam_position, stage) -> dict(rgb, albedo, normal, position, empty_mask,
+    roughness_womipmap, roughness)  (mat_nvdiffrast.py:107-190)."""
+
+    def __init__(self, conf, ids, extrinsics, optim_cam=False, gt_irf=True, gt_irrt=True):
+        super().__init__()
+        self.resolution = conf.get_list("train.env_res", default=[8, 16])
+        self.path_traced_mesh = conf.get_string("train.path_mesh_open3d")
+        self.pano_res = conf.get_list("train.pano_img_res", default=[1000, 2000])
+        self.cube_res = int(self.pano_res[1] / 4)
+        self.sample_l = conf.get_list("train.sample_light", default=[64, 64])
+        self.sample_type = conf.get_list("models.render.sample_type", default=["uniform", "importance"])
+        self.optim_cam, self.ids, self.extrinsics, self.conf = optim_cam, ids, extrinsics, conf
+        self.max_mip_level = get_mip_level(8192)
+        # texture sizes: reference hard-codes 2048^2 x 3 and 4096^2 x 1 (mat_nvdiffrast.py:68-69); optional keys make them configurable
+        ra = int(conf.get("train.albedo_res", 2048))
+        rr = int(conf.get("train.roughness_res", 4096))
+        self.materials_a = nn.Parameter(torch.ones((ra, ra, 3)) * 0.5, requires_grad=True)
+        self.materials_r = nn.Parameter(torch.ones((rr, rr, 1)) * 0.1, requires_grad=True)
+        self.gt_irrt = gt_irrt
+        if gt_irrt:
+            irt = IO.read_hdr(_sibling(self.path_traced_mesh, "irt.hdr"))        # NOT flipped (mat_nvdiffrast.py:73-76)
+            self.irrt = nn.Parameter(torch.from_numpy(np.ascontiguousarray(irt)), requires_grad=False)
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.scene, self.obj, tex = _load_scene(conf, self.device.index)
+        self.texture = tex.permute(2, 0, 1).unsqueeze(0).float()                   # [1,3,H,W] like the reference attribute
+        self._gb_cache = {}
+
+    def _gbuffer(self, mvp, view_id):
+        key = str(view_id)
+        gb = self._gb_cache.get(key)
+        if gb is None:
+            gb = GB.cast_gbuffer(self.scene, mvp, self.cube_res, flip_v=True)     # pyredner-style uvs for the nvdiffrast-side textures
+            self._gb_cache[key] = gb
+        return gb
+
+    def _fetch_materials(self, gb):
+        """the four dr.texture fetches of mat_nvdiffrast.py:131-139"""
+        texc, texd = gb["uv"], gb["uv_da"]
+        albedo = tex_fetch(self.materials_a, texc, texd, "linear-mipmap-linear", self.max_mip_level)
+        roughness_womipmap = tex_fetch(self.materials_r, texc, texd, "linear")
+        roughness = tex_fetch(self.materials_r, texc, texd, "linear-mipmap-linear", self.max_mip_level)
+        irr = tex_fetch(self.irrt, texc, texd, "linear-mipmap-linear", self.max_mip_level)
+        return albedo, roughness_womipmap, roughness, irr
+
+    def forward(self, mvp, id, cam_position, stage=1):
+        gb = self._gbuffer(mvp, id)
+        pos, nrm, mask = gb["position"], gb["normal"], gb["mask"]
+        albedo, roughness_womipmap, roughness, irr = self._fetch_materials(gb)
+        cam_position = cam_position.to(self.device)
+        if stage == -1:
+            # light-source-only radiance texture (mat_nvdiffrast.py:141-150)
+            src = self.texture[0].permute(1, 2, 0).to(self.device)
+            inten = rgb_to_intensity(src * (2 ** -self.conf.get_float("train.hdr_exposure")))
+            self.scene.set_texture(torch.where(inten >= 0.5, src, torch.zeros_like(src)).contiguous())
+            try:
+                res = self.render(nrm, torch.zeros_like(albedo), torch.ones_like(roughness) * 0.01, pos + 1e-2 * nrm, cam_position, irr)
+            finally:
+                self.scene.set_texture(src.contiguous())
+        elif stage == 0:
+            res = {"rgb": irr * albedo / np.pi, "albedo": albedo, "normal": nrm, "position": pos + 1e-1 * nrm}
+        elif stage == 1:
+            res = self.render(nrm, albedo.detach(), roughness_womipmap, pos + 1e-2 * nrm, cam_position, irr)
+        elif stage == 2:
+            res = self.render(nrm, albedo, roughness, pos + 1e-2 * nrm, cam_position, irr)
+        else:
+            raise ValueError("MaterialModel.forward: unknown stage %r" % (stage,))
+        res.update({"empty_mask": mask, "roughness_womipmap": roughness_womipmap, "roughness": roughness})
+        return res
+
+    def render(self, normal, albedo, roughness, points, cam_position, irr):
+        """mat_nvdiffrast.py:201-249: fused GGX-importance sampling + trace + BRDF (texir_spec_forward/backward)"""
+        face, h, w, _ = normal.shape
+        P = face * h * w
+        S = int(self.sample_l[1])
+        if self.sample_type[1] != "importance":
+            raise NotImplementedError("specular sample_type %r: the reference path uses 'importance'" % (self.sample_type[1],))
+        shift = torch.rand(P, 1, 2).reshape(P, 2).to(self.device)               # sample_util.py:102 (CPU generator)
+        rgb = spec_render(self.scene, normal.reshape(P, 3), albedo.reshape(P, 3), roughness.reshape(P), points.reshape(P, 3),
+                          irr.reshape(P, 3), cam_position, shift, S)
+        return {"rgb": rgb.reshape(face, h, w, 3), "albedo": albedo.reshape(face, h, w, 3), "normal": normal.reshape(face, h, w, 3).detach(),
+                "position": (points + 2e-2 * normal).reshape(face, h, w, 3).detach()}
+
+    # -- API-complete helpers (dead on the default path, mat_nvdiffrast.py:252-258) ---------------------------------
+    def diffuse_reflectance(self, lighting, l, n, albedo, sample_type="uniform"):
+        ndl = torch.clamp(torch.sum(n.unsqueeze(1) * l, dim=-1, keepdim=True), 0.0, 1.0)
+        brdf = albedo.unsqueeze(1) / np.pi
+        if sample_type == "cosine":
+            return torch.sum(lighting * brdf * np.pi, dim=1)
+        return torch.sum(lighting * brdf * ndl * 2 * np.pi, dim=1)
+
+    def query_irf(self, points, directions, num_sample):
+        b, n, _ = points.shape
+        return self.scene.trace_shade(points.reshape(-1, 3), directions.reshape(-1, 3)).reshape(b, n, 3)

@@ -146,7 +146,7 @@ def make_scene(T, seed=666, tex_res=1024, n_boxes=40, amp=3e-3):
     P = _room_and_boxes(rng, 0 if T < 12 + 40 * 10 else n_boxes)
     _allocate_grids(P, T)
     _pack(P)
-    verts, tris, tuvs = [], [], []
+    verts, tris, tuvs, tcls = [], [], [], []
     vbase = 0
     tcount = 0
     for p in P:
@@ -173,12 +173,14 @@ def make_scene(T, seed=666, tex_res=1024, n_boxes=40, amp=3e-3):
         vb = y + h * b
         uvgrid = np.stack(np.meshgrid(ua, vb, indexing="ij"), -1).reshape(-1, 2)
         tuvs.append(uvgrid[(t.reshape(-1, 3) - vbase).reshape(-1)].reshape(-1, 2))
+        tcls.append(np.full(2 * gu * gv, p.cls, np.int32))
         p.vbase, p.tbase, p.ntri = vbase, tcount, 2 * gu * gv
         vbase += (gu + 1) * (gv + 1)
         tcount += 2 * gu * gv
     verts = np.concatenate(verts).astype(np.float64)
     tris = np.concatenate(tris)
     tuvs = np.concatenate(tuvs).reshape(-1, 3, 2)
+    tcls = np.concatenate(tcls)
     # fix-up to exactly T: split triangles at the midpoint of their first edge (stays on the edge -> no crack)
     rem = T - tris.shape[0]
     assert rem >= 0
@@ -194,10 +196,11 @@ def make_scene(T, seed=666, tex_res=1024, n_boxes=40, amp=3e-3):
         tuvs[pick, 1] = muv
         tris = np.concatenate([tris, new_t])
         tuvs = np.concatenate([tuvs, new_uv])
+        tcls = np.concatenate([tcls, tcls[pick]])
     assert tris.shape[0] == T
     sc = {
         "verts": verts.astype(np.float32), "tris": tris.astype(np.int32),
-        "tri_uvs": tuvs.reshape(-1, 2).astype(np.float32), "patches": P, "seed": seed, "T": T,
+        "tri_uvs": tuvs.reshape(-1, 2).astype(np.float32), "patches": P, "seed": seed, "T": T, "tri_class": tcls,
     }
     sc["hdr"] = make_hdr_texture(sc, tex_res, seed)
     return sc
@@ -301,3 +304,26 @@ def make_shifts(nt, seed=666):
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
     return torch.rand(nt, 1, 2, generator=g).reshape(nt, 2).numpy()
+
+
+def make_gt_materials(sc, albedo_res, rough_res, seed=666):
+    """ground-truth material textures in FILE orientation (row 0 = top; sampled with (u, 1-v) by the nvdiffrast-side
+    convention): albedo = per-chart colour x checker, roughness per chart in [0.1, 0.7]  """
+    rng = np.random.default_rng(seed + 2)
+    alb = np.full((albedo_res, albedo_res, 3), 0.5, np.float32)
+    rgh = np.full((rough_res, rough_res, 1), 0.3, np.float32)
+    for p in sc["patches"]:
+        x, y, w, h = p.rect
+        col = rng.uniform(0.2, 0.9, 3).astype(np.float32)
+        r = np.float32(rng.uniform(0.1, 0.7))
+        for tex, res, val in ((alb, albedo_res, col), (rgh, rough_res, r)):
+            c0 = max(0, int(math.floor((x - GUTTER / 2) * res))); c1 = min(res, int(math.ceil((x + w + GUTTER / 2) * res)))
+            r0 = max(0, int(math.floor((y - GUTTER / 2) * res))); r1 = min(res, int(math.ceil((y + h + GUTTER / 2) * res)))
+            if tex is alb:
+                yy, xx = np.meshgrid(np.arange(r0, r1), np.arange(c0, c1), indexing="ij")
+                chk = (((xx * 16 // res) + (yy * 16 // res)) % 2).astype(np.float32)[..., None]
+                tex[r0:r1, c0:c1] = val[None, None, :] * (0.75 + 0.25 * chk)
+            else:
+                tex[r0:r1, c0:c1] = val
+    # arrays above are in the tracer ("flipped") layout; files / nvdiffrast-side parameters are un-flipped
+    return np.ascontiguousarray(alb[::-1]), np.ascontiguousarray(rgh[::-1])

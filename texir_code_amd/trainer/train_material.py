@@ -1,0 +1,198 @@
+"""MatTrainRunner -- the three-stage material optimisation loop of trainer/train_material.py:408-605 (and its `_syn`
+twin): stage order, requires_grad toggling, optimiser + scheduler re-creation, per-step clamps and the mask
+construction of plot_to_disk_cube's first-validation branch (:251-296).  Plots / tensorboard / metrics are debug
+output and are not reproduced."""
+import os
+import sys
+import time
+from datetime import datetime
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .. import dist_util
+from ..conf import ConfigFactory
+from ..datasets import parse_roomseg
+from ..models import rgb_to_intensity
+from ..optim import FusedAdam
+from ..plugin import get_class
+
+N_SEG_CLASSES = 49          # trainer/train_material.py:188
+
+
+def build_masks(segs, stage_m1_rgb, room_img=None, positions=None, room_meta=None):
+    """trainer/train_material.py:251-296 on one view.
+    segs [6,h,w,1] (class ids), stage_m1_rgb [6,h,w,3] (stage -1 render: light-source-only specular)
+    -> seg_mask [49,6,h,w,1] (one-hot, un-eroded copy), floor_max_mask [49,6,h,w,1], room_seg_mask [R,6,h,w,1]"""
+    tag = torch.arange(N_SEG_CLASSES, dtype=torch.float32, device=segs.device)
+    seg_mask = ((tag.reshape(-1, 1, 1, 1, 1) - segs.unsqueeze(0)) == 0).float()
+    source_seg_mask = seg_mask.clone()
+    floor = seg_mask[-3]                                                            # class 46 = floor
+    floor = -F.max_pool2d(-floor.permute(0, 3, 1, 2), kernel_size=15, stride=1, padding=7).permute(0, 2, 3, 1)
+    seg_mask[-3] = floor
+    pred = stage_m1_rgb.unsqueeze(0) * seg_mask
+    floor_max_mask = (rgb_to_intensity(torch.abs(pred)) > 0.).float()
+    room_mask = None
+    if room_img is not None:
+        scale, w, h, xmin, zmin = room_meta
+        u = (positions[..., 0:1] - xmin) / scale / w
+        v = (positions[..., 2:3] - zmin) / scale / h
+        uv = torch.cat([u * 2 - 1, v * 2 - 1], dim=-1)
+        ri = F.grid_sample(room_img.to(uv.device).expand(6, -1, -1, -1), uv, mode="nearest", padding_mode="border", align_corners=False).permute(0, 2, 3, 1)
+        room_mask = ((ri.unsqueeze(0) - torch.unique(ri).reshape(-1, 1, 1, 1, 1)) == 0).float()
+    return source_seg_mask, floor_max_mask, room_mask
+
+
+class MatTrainRunner:
+    def __init__(self, **kwargs):
+        torch.set_default_dtype(torch.float32)
+        self.conf = ConfigFactory.parse_file(kwargs["conf"])
+        self.exps_folder_name = kwargs["exps_folder_name"]
+        self.train_batch_size = self.conf.get_int("train.batch_size")
+        self.nepochs = self.conf.get_int("train.mat_epoch")
+        self.max_niters = kwargs["max_niters"]
+        self.GPU_INDEX = kwargs["gpu_index"]
+        self.expname = "Mat-" + kwargs["expname"]
+        # --is_continue: the reference's resume path is dead code; the flags are accepted and ignored
+        self.expdir = os.path.join("../", self.exps_folder_name, self.expname)
+        self.timestamp = "{:%Y_%m_%d_%H_%M_%S}".format(datetime.now())
+        self.plots_dir = os.path.join(self.expdir, self.timestamp, "plots")
+        self.checkpoints_path = os.path.join(self.expdir, self.timestamp, "checkpoints")
+        if int(os.environ.get("RANK", "0")) == 0 and not kwargs.get("dry_dirs", False):
+            for d in (self.plots_dir, os.path.join(self.checkpoints_path, "ModelParameters")):
+                os.makedirs(d, exist_ok=True)
+            try:
+                import shutil
+                shutil.copy(kwargs["conf"], os.path.join(self.expdir, self.timestamp, "runconf.conf"))
+            except OSError:
+                pass
+        torch.manual_seed(666)
+        torch.cuda.manual_seed(666)
+        np.random.seed(666)
+        print("shell command : {0}".format(" ".join(sys.argv)))
+        print("Loading data ...")
+        self.train_dataset = get_class(self.conf.get_string("train.dataset_class"))(
+            self.conf.get_string("train.path_mesh_open3d"), self.conf.get_list("train.pano_img_res"), self.conf.get_float("train.hdr_exposure"))
+        print("Finish loading data ...")
+        self.train_dataloader = torch.utils.data.DataLoader(self.train_dataset, batch_size=1, shuffle=True)
+        self.model = get_class(self.conf.get_string("train.model_class"))(
+            conf=self.conf, ids=self.train_dataset.ids, extrinsics=self.train_dataset.extrinsics_list, optim_cam=self.conf.get_bool("train.optim_cam"))
+        self.model.cuda()
+        self.mat_loss = get_class(self.conf.get_string("train.irf_loss_class"))(**self.conf.get_config("render_loss"))
+        self._new_optimizer()
+        self.start_epoch = 0
+        self.n_batches = len(self.train_dataloader)
+        self.plot_freq = self.conf.get_int("train.plot_freq")
+        self.pano_res = self.conf.get_list("train.pano_img_res")
+        self.cube_lenth = int(self.pano_res[1] / 4)
+        self.first_val = True
+        self.floor_max_mask, self.seg_mask, self.room_seg_mask = {}, {}, {}
+        rs = os.path.join(os.path.dirname(os.path.dirname(self.conf.get_string("train.path_mesh_open3d"))), "roomseg")
+        rs = rs if os.path.isdir(rs) else os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(self.conf.get_string("train.path_mesh_open3d")))), "roomseg")
+        (self.room_meta_scale, self.room_meta_w, self.room_meta_h, self.room_meta_xmin, self.room_meta_zmin, self.room_img) = parse_roomseg(rs)
+        self.cur_iter = 0
+        self.log = []
+
+    def _new_optimizer(self):
+        """fresh Adam + StepLR over ALL model parameters (train_material.py:122-128, 472-476, 539-543); the post-step
+        clamps of :458/:592-593 are fused into the optimiser kernel"""
+        self.mat_optimizer = FusedAdam(self.model.parameters(), lr=self.conf.get_float("train.mat_learning_rate"))
+        self.mat_optimizer.set_clamp(self.model.materials_r, 1e-2, 0.8)
+        self.mat_scheduler = torch.optim.lr_scheduler.StepLR(self.mat_optimizer, self.conf.get_int("train.mat_sched_step", default=100),
+                                                            gamma=self.conf.get_float("train.mat_sched_factor", default=0.0))
+
+    def save_checkpoints(self, epoch):
+        torch.save({"epoch": epoch, "model_state_dict": self.model.state_dict()},
+                   os.path.join(self.checkpoints_path, "ModelParameters", "latest.pth"))
+
+    # first-validation branch of plot_to_disk_cube (train_material.py:251-296): per-view masks from a stage -1 render
+    def build_view_masks(self):
+        self.model.eval()
+        with torch.no_grad():
+            for i, vid in enumerate(self.train_dataset.ids):
+                segs = self.train_dataset.images_items[i]["segs"].float().cuda()
+                res = self.model(self.train_dataset.extrinsics_list[i], vid, self.train_dataset.cam_position_list[i].cuda(), -1)
+                seg, fm, room = build_masks(segs, res["rgb"], self.room_img, res["position"],
+                                            (self.room_meta_scale, self.room_meta_w, self.room_meta_h, self.room_meta_xmin, self.room_meta_zmin))
+                self.seg_mask[str(vid)], self.floor_max_mask[str(vid)], self.room_seg_mask[str(vid)] = seg, fm, room
+        self.model.train()
+        self.first_val = False
+
+    def train_step(self, gt_item, stage):
+        """one optimiser step (train_material.py:424-458 / 486-525 / 552-593)"""
+        gt_color = gt_item["color"].float().cuda()
+        h, w, c = gt_color.shape[-3:]
+        gt_color = gt_color.reshape(-1, h, w, c)
+        gt_mask = gt_item["mask"].float().cuda().reshape(-1, h, w, 1)
+        mvp = gt_item["cam_to_world"].float()
+        vid = gt_item["id"]
+        vid0 = vid[0] if isinstance(vid, (list, tuple)) else vid
+        cam = gt_item["cam_position"].float().cuda()
+        fm, seg = self.floor_max_mask[str(vid0)], self.seg_mask[str(vid0)]
+        preds = self.model(mvp[0] if mvp.dim() == 4 else mvp, vid0, cam[0] if cam.dim() == 2 else cam, stage)
+        out = self.mat_loss(gt_color, preds, gt_mask, fm, seg, stage=stage, room_seg_mask=self.room_seg_mask[str(vid0)] if stage == 2 else None)
+        loss = out[0]
+        self.mat_optimizer.zero_grad()
+        loss.backward()
+        if dist_util.world_info()[1] > 1:
+            for p in (self.model.materials_a, self.model.materials_r):
+                if p.grad is not None:
+                    dist_util.assemble_sum(p.grad)
+        self.mat_optimizer.step()
+        return loss, out[1]
+
+    def validation_forward(self, stage):
+        """non-first branch of plot_to_disk_cube (train_material.py:319-345): one eval forward per view.  The images it
+        plots are debug output (not reproduced), but the forward draws GGX shifts from the global CPU generator, so it is
+        kept to consume the random stream exactly like the reference does."""
+        self.model.eval()
+        with torch.no_grad():
+            for i, vid in enumerate(self.train_dataset.ids):
+                self.model(self.train_dataset.extrinsics_list[i], vid, self.train_dataset.cam_position_list[i].cuda(), stage)
+        self.model.train()
+
+    def _stage(self, stage, max_steps=None):
+        for epoch in range(self.start_epoch, self.nepochs + 1):
+            if stage > 0 and epoch % self.plot_freq == 0 and not self.cur_iter == 0:      # train_material.py:484-485, 550-551
+                self.validation_forward(stage)
+            for data_index, gt_item in enumerate(self.train_dataloader):
+                t0 = time.time()
+                self.model.train()
+                loss, seg_item = self.train_step(gt_item, stage)
+                self.log.append((stage, epoch, data_index, float(loss.item()), float(seg_item)))
+                print("{0} [{1}] ({2}/{3}): img_loss_stage{7} ({5}) = {4}, seg_loss = {6}, batch cost time : {8:.4f}s".format(
+                    self.expname, epoch, data_index, self.n_batches, loss.item(), self.conf.get_string("render_loss.loss_type"), seg_item, stage,
+                    time.time() - t0))
+                self.cur_iter += 1
+                if max_steps is not None and self.cur_iter >= max_steps:
+                    return
+            self.mat_scheduler.step()
+
+    def run(self):
+        print("training...")
+        self.cur_iter = self.start_epoch * len(self.train_dataloader)
+        self.build_view_masks()                                  # "generate vhl mask" (train_material.py:413)
+        # stage 0: albedo only (:416-469)
+        self.model.materials_r.requires_grad = False
+        self.model.materials_a.requires_grad = True
+        self._stage(0)
+        # stage 1: roughness on highlights (:472-536)
+        self._new_optimizer()
+        self.model.materials_a.data = torch.clamp(self.model.materials_a.data, 0.)
+        self.model.materials_a.requires_grad = False
+        self.model.materials_r.requires_grad = True
+        self._stage(1)
+        # stage 2: joint (:539-605); materials_a >= 0 after every step (:592)
+        self._new_optimizer()
+        self.mat_optimizer.set_clamp(self.model.materials_a, 0.0, float("inf"))
+        self.model.materials_a.requires_grad = True
+        self.model.materials_r.requires_grad = True
+        self._stage(2)
+        if int(os.environ.get("RANK", "0")) == 0 and os.path.isdir(os.path.join(self.checkpoints_path, "ModelParameters")):
+            self.save_checkpoints(self.nepochs)
+
+
+class MatTrainSynRunner(MatTrainRunner):
+    """trainer/train_material_syn.py: same step loop; the GT-material metrics / novel-view renders that follow it are
+    evaluation output, outside the hot path."""
