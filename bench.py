@@ -72,6 +72,70 @@ def cpu_leg(sc0, pos, nrm, valid, shift, spp, budget_s=15.0):
             "sample": "%d random valid texels x %d spp (%.1f s) of the same workload, canonical BVH2 oracle, OpenMP" % (n, spp, dt)}, c
 
 
+def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5):
+    """material-estimation step latency (BASELINE.json: "material-step ms at 4k tex"): stage-2 (joint) optimiser step =
+    4 texture fetches (4k albedo x3 / 4k roughness x1 / irradiance, mip stacks rebuilt) + GGX-importance specular trace
+    (P = 6*128^2 pixels x 16 spp) + fused RenderLoss/SegLoss + backward + (gradient all-reduce) + fused Adam over 67.1 M texels."""
+    from texir_code_amd import cameras, conf as C, synth
+    from texir_code_amd.loss import RenderLoss
+    from texir_code_amd.models import MaterialModel
+    from texir_code_amd.optim import FusedAdam
+    from texir_code_amd.trainer.train_material import build_masks
+    cube, S, tres = 128, 16, 4096
+    conf = C.parse_string("train{ pano_img_res = [%d,%d]\n sample_light = [2048,%d]\n hdr_exposure = 0 }\nmodels{ render{ sample_type = [uniform, importance] } }"
+                          % (2 * cube, 4 * cube, S))
+    irrt = torch.flip(irr_tex.reshape(res, res, 3), dims=[0]).contiguous()          # file orientation
+    model = MaterialModel.from_arrays(sc, sc0["hdr"], irrt, conf, albedo_res=tres, roughness_res=tres)
+    views = [cameras.cube_mvps(E) for E in cameras.grid_cameras(4)]
+    alb_gt, rgh_gt = synth.make_gt_materials(sc0, tres, tres)
+    tri_class = torch.from_numpy(sc0["tri_class"]).to(dev)
+    data = []
+    with torch.no_grad():
+        a0, r0 = model.materials_a.detach().clone(), model.materials_r.detach().clone()
+        model.materials_a.copy_(torch.from_numpy(alb_gt))
+        model.materials_r.copy_(torch.from_numpy(rgh_gt))
+        for i, (mvp, cam) in enumerate(views):
+            gt = model(mvp, i, cam, 2)
+            tri = model._gbuffer(mvp, i)["tri_id"].long()
+            segs = torch.where(tri > 0, tri_class[(tri - 1).clamp(min=0)].long(), torch.zeros_like(tri)).float().unsqueeze(-1)
+            m1 = model(mvp, i, cam, -1)
+            seg, fm, _ = build_masks(segs, m1["rgb"])
+            room = torch.ones((1,) + tuple(seg.shape[1:]), device=dev)
+            data.append((mvp, cam, gt["rgb"].clone(), gt["empty_mask"].clone(), seg, fm, room))
+        model.materials_a.copy_(a0)
+        model.materials_r.copy_(r0)
+    loss_fn = RenderLoss("L1", 1)
+    opt = FusedAdam([model.materials_a, model.materials_r], lr=3e-2)
+    opt.set_clamp(model.materials_r, 1e-2, 0.8)
+    opt.set_clamp(model.materials_a, 0.0, float("inf"))
+    times = []
+    for it in range(warmup + steps):
+        v = (it * world + rank) % len(views)
+        mvp, cam, gt, gmask, seg, fm, room = data[v]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        preds = model(mvp, v, cam, 2)
+        loss = loss_fn(gt, preds, gmask, fm, seg, stage=2, room_seg_mask=room)[0]
+        opt.zero_grad()
+        loss.backward()
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(model.materials_a.grad)
+            dist.all_reduce(model.materials_r.grad)
+        opt.step()
+        torch.cuda.synchronize()
+        if it >= warmup:
+            times.append((time.perf_counter() - t0) * 1e3)
+    med = float(np.median(times))
+    if world > 1:
+        tt = torch.tensor([med], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        med = float(tt.item())
+    return {"ms": round(med, 3), "stage": 2, "steps": steps, "warmup": warmup,
+            "config": "stage-2 step: albedo %d^2x3 + roughness %d^2x1 (%.1f M params), %d px x %d spp, %d-tri mesh, %d views%s"
+                      % (tres, tres, (tres * tres * 4) / 1e6, 6 * cube * cube, S, sc0["T"], len(views), ", view-sharded + grad all_reduce" if world > 1 else "")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +144,7 @@ def main():
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-mat", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,6 +205,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    mat = None
+    if not args.no_mat and args.workload == "c4":
+        mat = mat_leg(sc, sc0, irr, res, dev, rank, world)
+
     if rank == 0:
         rays_per_step = n_valid * spp
         value = rays_per_step * args.steps / dt / 1e6
@@ -152,6 +221,8 @@ def main():
                        "parallelism": "texel-sharded x%d (block-cyclic %d) + RCCL all_reduce" % (world, BLOCK) if world > 1 else "single GPU",
                        "bvh_build_s": round(build_s, 2), "scene": sc.info()},
         }
+        if mat is not None:
+            out["material_step"] = mat
         rays_this_rank = int(ids.numel()) * spp
         if not args.no_cpu:
             cpu, counters = cpu_leg(sc0, pos, nrm, valid, shift, spp)

@@ -185,6 +185,26 @@ class MaterialModel(nn.Module):
         self.texture = tex.permute(2, 0, 1).unsqueeze(0).float()                   # [1,3,H,W] like the reference attribute
         self._gb_cache = {}
 
+    @classmethod
+    def from_arrays(cls, scene, hdr_texture, irrt, conf, albedo_res=2048, roughness_res=4096):
+        """build the model around an existing Scene and in-memory textures (synthetic benches / tests; no files).
+        hdr_texture [Ht,Wt,3] in the tracer layout (flipped + exposed), irrt [H,W,3] in file orientation."""
+        self = cls.__new__(cls)
+        nn.Module.__init__(self)
+        self.pano_res = conf.get_list("train.pano_img_res", default=[1000, 2000])
+        self.cube_res = int(self.pano_res[1] / 4)
+        self.sample_l = conf.get_list("train.sample_light", default=[64, 64])
+        self.sample_type = conf.get_list("models.render.sample_type", default=["uniform", "importance"])
+        self.conf, self.max_mip_level, self.gt_irrt = conf, get_mip_level(8192), True
+        self.device = scene.device
+        self.materials_a = nn.Parameter(torch.ones((albedo_res, albedo_res, 3), device=self.device) * 0.5, requires_grad=True)
+        self.materials_r = nn.Parameter(torch.ones((roughness_res, roughness_res, 1), device=self.device) * 0.1, requires_grad=True)
+        self.irrt = nn.Parameter(torch.as_tensor(irrt, dtype=torch.float32).to(self.device).contiguous(), requires_grad=False)
+        self.scene = scene
+        self.texture = torch.as_tensor(hdr_texture, dtype=torch.float32).permute(2, 0, 1).unsqueeze(0)
+        self._gb_cache = {}
+        return self
+
     def _gbuffer(self, mvp, view_id):
         key = str(view_id)
         gb = self._gb_cache.get(key)
