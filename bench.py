@@ -150,11 +150,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = local % max(1, torch.cuda.device_count())            # lets a 2-rank smoke test share one GPU (with TEXIR_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("TEXIR_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from texir_code_amd import scene as S, synth, dist_util
     T, res, tex_res, spp = WORKLOADS[args.workload]
@@ -170,6 +175,8 @@ def main():
     d_nrm = torch.from_numpy(nrm).to(dev).reshape(-1, 3)
     d_shift = torch.from_numpy(shift).to(dev)
     ids_all = torch.nonzero(torch.from_numpy(valid.reshape(-1)) > 0)[:, 0].to(torch.int32)
+    if os.environ.get("TEXIR_TEXEL_ORDER", "morton") == "morton":
+        ids_all = dist_util.morton_order(ids_all, res)
     ids = dist_util.shard_block_cyclic(ids_all, rank, world, BLOCK).to(dev)
     n_valid = int(ids_all.numel())
     irr = torch.zeros((res * res, 3), device=dev)
@@ -227,16 +234,20 @@ def main():
         if not args.no_cpu:
             cpu, counters = cpu_leg(sc0, pos, nrm, valid, shift, spp)
             bpr, nbar, tbar, phit = algorithmic_bytes_per_ray(counters, spp)
+            from texir_code_amd import _lib
+            launches = int(_lib.lib().texir_irt_launch_count(spp))
             achieved = bpr * rays_this_rank / (kern_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.workload)
             if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_step", 0) / launches if "hbm_bytes_per_step" in tj else tj.get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                               "kernel": "irt_kernel", "kernel_ms": round(kern_ms, 3), "bytes_per_ray": round(bpr, 1),
+                               "kernel": "irt_kernel", "launches_per_step": launches, "kernel_ms": round(kern_ms / launches, 4),
+                               "kernel_ms_per_step": round(kern_ms, 3), "bytes_per_ray": round(bpr, 1),
                                "nodes_per_ray": round(nbar, 2), "tris_per_ray": round(tbar, 2), "p_hit": round(phit, 4),
-                               "rays_per_launch": rays_this_rank}
+                               "rays_per_launch": rays_this_rank // launches}
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:

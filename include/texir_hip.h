@@ -92,6 +92,10 @@ TEXIR_API int texir_irt_generate(const texir_scene* scene, const float* pos /*de
                        int64_t Nt, int32_t N, int32_t mode, float* irr /*dev*/, uint64_t* stats /*dev, nullable*/,
                        void* stream);
 
+/* number of kernel launches one texir_irt_generate call issues for N samples per texel (the cell-major schedule launches
+ * once per 64-sample direction cell when N is a power of two >= 128); used by bench.py to report per-launch figures. */
+TEXIR_API int32_t texir_irt_launch_count(int32_t N);
+
 /* Replaces MaterialModel.render + specular_reflectance (models/mat_nvdiffrast.py:201-249, 260-279), forward:
  *   rgb = irr*albedo/pi + (1/S) sum_i Ls_i * w_i(roughness)        
  * normal,albedo,points,irr [P,3] dev; rough [P] dev; cam [3] dev; shift [P,2] dev (GGX sample shift, as above)

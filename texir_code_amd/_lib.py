@@ -63,6 +63,8 @@ def lib():
         sig["texir_tex_fetch_forward"] = [vp, i32, i32, i32, i32, vp, vp, i32, i64, vp, vp]
         sig["texir_tex_fetch_backward"] = [vp, i32, i32, i32, i32, vp, vp, i32, i64, vp, vp]
         sig["texir_adam_step"] = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, f32, vp]
+        L.texir_irt_launch_count.argtypes = [i32]
+        L.texir_irt_launch_count.restype = i32
         L.texir_mip_levels.argtypes = [i32, i32, i32]
         L.texir_mip_levels.restype = i32
         L.texir_mip_elems.argtypes = [i32, i32, i32, i32]

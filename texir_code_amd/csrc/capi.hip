@@ -138,6 +138,8 @@ int texir_irt_generate(const texir_scene* s, const float* pos, const float* nrm,
     return TEXIR_OK;
 }
 
+int32_t texir_irt_launch_count(int32_t N) { return irt_launch_count(N); }
+
 int texir_spec_forward(const texir_scene* s, const float* normal, const float* albedo, const float* rough, const float* points, const float* irr,
                        const float* cam, const float* shift, int64_t P, int32_t S, float* rgb, float* Ls_ws, void* stream)
 {

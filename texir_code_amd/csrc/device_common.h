@@ -18,8 +18,7 @@ struct SceneDev {
 };
 
 constexpr int kBlock = 256;          // 4 waves
-constexpr int kLdsStack = 24;        // entries per lane kept in LDS (24 KiB per block)
-constexpr int kOvfStack = kMaxDepth + 4 - kLdsStack;
+constexpr int kLdsStack = 24;        // default: entries per lane kept in LDS (24 KiB per block)
 constexpr int kSentinel = 0x7FFFFFFF;
 
 // ------------------------------------------------------------------------------------------------
@@ -127,22 +126,36 @@ __device__ __forceinline__ void shade_hit(const SceneDev& sc, int tri_slot, floa
 // ------------------------------------------------------------------------------------------------
 struct Hit { float t, u, v; int slot; };
 
-template <bool STATS>
+template <bool STATS, int LSTK = kLdsStack>
 __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float oy, float oz, float dx, float dy, float dz,
-                                             int* lds_stack /* this thread's column: lds_stack[e * kBlock] */,
                                              uint32_t& n_nodes, uint32_t& n_tris)
 {
+    // the traversal stack: LSTK entries per lane in LDS ([entry][thread], one instance per kernel), deeper ones private
+    __shared__ int lds_all[LSTK * kBlock];
+    int* lds_stack = lds_all + threadIdx.x;
     const float ooeps = 8.271806e-25f;  // 2^-80
     float idx = __builtin_amdgcn_rcpf(fabsf(dx) > ooeps ? dx : copysignf(ooeps, dx));
     float idy = __builtin_amdgcn_rcpf(fabsf(dy) > ooeps ? dy : copysignf(ooeps, dy));
     float idz = __builtin_amdgcn_rcpf(fabsf(dz) > ooeps ? dz : copysignf(ooeps, dz));
     float oodx = ox * idx, oody = oy * idy, oodz = oz * idz;
     Hit h; h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f; h.slot = -1;
-    int ovf[kOvfStack];
+    int ovf[kMaxDepth + 4 - LSTK];
     int sp = 0;
     int node = 0;
-    auto push = [&](int x) { if (sp < kLdsStack) lds_stack[sp * kBlock] = x; else ovf[sp - kLdsStack] = x; sp++; };
-    auto pop = [&]() -> int { if (sp == 0) return kSentinel; sp--; return sp < kLdsStack ? lds_stack[sp * kBlock] : ovf[sp - kLdsStack]; };
+    // LDS part and private overflow are kept in separate, wave-uniformly guarded code paths: the overflow is almost never
+    // touched (depth > LSTK), and hipcc must not merge the two address spaces into one flat access
+    auto push = [&](int x) {
+        if (sp < LSTK) lds_stack[sp * kBlock] = x;
+        if (__any(sp >= LSTK)) { if (sp >= LSTK) ovf[sp - LSTK] = x; }
+        sp++;
+    };
+    auto pop = [&]() -> int {
+        if (sp == 0) return kSentinel;
+        sp--;
+        int v = lds_stack[(sp < LSTK ? sp : LSTK - 1) * kBlock];
+        if (__any(sp >= LSTK)) { int b = ovf[sp >= LSTK ? sp - LSTK : 0]; v = sp >= LSTK ? b : v; }
+        return v;
+    };
     while (node != kSentinel) {
         while (node >= 0 && node != kSentinel) {
             const float4* np = sc.nodes + 4 * (size_t)node;

@@ -5,6 +5,8 @@
 //   spec_fwd/bwd_kernel render + specular_reflectance and its analytic grad  (models/mat_nvdiffrast.py:201-279)
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "device_common.h"
 #include "kernels.h"
 
@@ -24,16 +26,36 @@ __device__ __forceinline__ uint32_t sample_index(uint32_t pass, uint32_t lane, u
     return (th << (log2N - bth)) | (lane << bphi) | low;
 }
 
-template <bool STATS>
-__global__ __launch_bounds__(kBlock) void irt_kernel(SceneDev sc, const float* __restrict__ pos, const float* __restrict__ nrm,
+// Cell-major schedule.  With N = 2^m >= 128 the samples of a texel fall into 2^(m-6) lattice cells of 64 samples; the
+// kernel is launched once per ABSOLUTE direction cell J and every texel contributes the lattice pass whose cell lies
+// nearest to J after its own Cranley-Patterson shift (a bijection J -> pass for a fixed shift, so every sample is traced
+// exactly once over the launches).  All rays in flight on the chip then leave neighbouring texels towards the same
+// ~1/32 of the hemisphere: the BVH/triangle/texel working set of a launch shrinks by the number of cells and fits the
+// per-XCD L2 instead of streaming from the Infinity Cache.
+__device__ __forceinline__ uint32_t cell_to_pass(uint32_t J, float sh0, float sh1, int log2N)
+{
+    int cells = log2N - 6;
+    int bphi = (cells + 1) >> 1, bth = cells - bphi;
+    uint32_t nphi = 1u << bphi, nth = 1u << bth;
+    uint32_t Jphi = J & (nphi - 1u), Jth = J >> bphi;
+    uint32_t dphi = (uint32_t)(sh1 * (float)nphi + 0.5f), dth = (uint32_t)(sh0 * (float)nth + 0.5f);
+    uint32_t phibin = (Jphi + nphi - (dphi & (nphi - 1u))) & (nphi - 1u);
+    uint32_t th = (Jth + nth - (dth & (nth - 1u))) & (nth - 1u);
+    uint32_t low = __brev(phibin) >> (32 - bphi);          // phi's high bits are i's low bits reversed
+    if (bphi == 0) low = 0;
+    return (th << bphi) | low;
+}
+
+// MODE 0: all passes of a texel in one launch (any N).  MODE 1: one direction cell per launch (cell-major schedule);
+// irr accumulates the raw sum over launches and the last launch applies the 2*pi/N scale.
+template <bool STATS, int MODE, int LSTK, int MINW>
+__global__ __launch_bounds__(kBlock, MINW) void irt_kernel(SceneDev sc, const float* __restrict__ pos, const float* __restrict__ nrm,
                                                      const float* __restrict__ shift, const int32_t* __restrict__ ids, int64_t n_ids,
-                                                     int N, int log2N, int mode, float* __restrict__ irr,
+                                                     int N, int log2N, int mode, int cell, int last_cell, float* __restrict__ irr,
                                                      unsigned long long* __restrict__ stats)
 {
-    __shared__ int lds_stack[kLdsStack * kBlock];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + wave, nw = (int64_t)gridDim.x * (kBlock / 64);
-    int* my_stack = lds_stack + threadIdx.x;
     uint32_t c_nodes = 0, c_tris = 0, c_rays = 0, c_hits = 0;
     const int passes = (N + 63) >> 6;
     for (int64_t k = gw; k < n_ids; k += nw) {
@@ -43,14 +65,16 @@ __global__ __launch_bounds__(kBlock) void irt_kernel(SceneDev sc, const float* _
         const float sh0 = shift[2 * t], sh1 = shift[2 * t + 1];
         const Frame f = make_frame(nx, ny, nz);
         float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
-        for (int p = 0; p < passes; p++) {
+        const int p_begin = MODE ? (int)cell_to_pass((uint32_t)cell, sh0, sh1, log2N) : 0;
+        const int p_end = MODE ? p_begin + 1 : passes;
+        for (int p = p_begin; p < p_end; p++) {
             uint32_t i = sample_index((uint32_t)p, (uint32_t)lane, (uint32_t)N, log2N);
             if (i < (uint32_t)N) {
                 float s0 = shift_wrap_clamp(ham0(i, (uint32_t)N), sh0);
                 float s1 = shift_wrap_clamp(ham1(i), sh1);
                 float d[3];
                 sample_dir(mode, s0, s1, 0.f, f, d);
-                Hit h = trace_closest<STATS>(sc, px, py, pz, d[0], d[1], d[2], my_stack, c_nodes, c_tris);
+                Hit h = trace_closest<STATS, LSTK>(sc, px, py, pz, d[0], d[1], d[2], c_nodes, c_tris);
                 if (STATS) c_rays++;
                 if (h.slot >= 0 && h.t > 1e-4f) {          // tracer_o3d_irt.py:248
                     float L[3];
@@ -64,11 +88,15 @@ __global__ __launch_bounds__(kBlock) void irt_kernel(SceneDev sc, const float* _
         }
         acc0 = wave_sum(acc0); acc1 = wave_sum(acc1); acc2 = wave_sum(acc2);
         if (lane == 0) {
-            // :171  sum * 2 * np.pi / N
-            const float pi = 3.141592653589793f;
-            irr[3 * t] = ((acc0 * 2.f) * pi) / (float)N;
-            irr[3 * t + 1] = ((acc1 * 2.f) * pi) / (float)N;
-            irr[3 * t + 2] = ((acc2 * 2.f) * pi) / (float)N;
+            if (MODE) {
+                if (cell != 0) { acc0 += irr[3 * t]; acc1 += irr[3 * t + 1]; acc2 += irr[3 * t + 2]; }
+            }
+            if (!MODE || last_cell) {
+                // :171  sum * 2 * np.pi / N
+                const float pi = 3.141592653589793f;
+                acc0 = ((acc0 * 2.f) * pi) / (float)N; acc1 = ((acc1 * 2.f) * pi) / (float)N; acc2 = ((acc2 * 2.f) * pi) / (float)N;
+            }
+            irr[3 * t] = acc0; irr[3 * t + 1] = acc1; irr[3 * t + 2] = acc2;
         }
     }
     if (STATS) {
@@ -86,13 +114,11 @@ __global__ __launch_bounds__(kBlock) void trace_shade_kernel(SceneDev sc, const 
                                                              int64_t R, float t_min, float* __restrict__ rad, float* __restrict__ t_hit,
                                                              uint32_t* __restrict__ prim, float* __restrict__ puv)
 {
-    __shared__ int lds_stack[kLdsStack * kBlock];
-    int* my_stack = lds_stack + threadIdx.x;
     uint32_t cn = 0, ct = 0;
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < R; r += (int64_t)gridDim.x * kBlock) {
         float ox = org[3 * r], oy = org[3 * r + 1], oz = org[3 * r + 2];
         float dx = dir[3 * r], dy = dir[3 * r + 1], dz = dir[3 * r + 2];
-        Hit h = trace_closest<false>(sc, ox, oy, oz, dx, dy, dz, my_stack, cn, ct);
+        Hit h = trace_closest<false>(sc, ox, oy, oz, dx, dy, dz, cn, ct);
         float L[3] = {0.f, 0.f, 0.f};
         bool hit = h.slot >= 0 && h.t > t_min;
         if (hit) shade_hit(sc, h.slot, h.u, h.v, L);
@@ -190,8 +216,6 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(SceneDev sc, const float* 
                                                       float* __restrict__ rgb, float* __restrict__ Ls_ws,
                                                       const float* __restrict__ d_rgb, float* __restrict__ d_albedo, float* __restrict__ d_rough)
 {
-    __shared__ int lds_stack[BWD ? 1 : kLdsStack * kBlock];
-    int* my_stack = lds_stack + (BWD ? 0 : threadIdx.x);
     const int lane = threadIdx.x & 63;
     const int ppw = 64 / lpp;                              // pixels per wave
     const int sub = lane / lpp, sl = lane % lpp;
@@ -230,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(SceneDev sc, const float* 
                     L[0] = lp[0]; L[1] = lp[1]; L[2] = lp[2];
                     dacc += (L[0] * g0 + L[1] * g1 + L[2] * g2) * ss.w.d;
                 } else {
-                    Hit h = trace_closest<false>(sc, ox, oy, oz, ss.l[0], ss.l[1], ss.l[2], my_stack, cn, ct);
+                    Hit h = trace_closest<false>(sc, ox, oy, oz, ss.l[0], ss.l[1], ss.l[2], cn, ct);
                     if (h.slot >= 0 && h.t > 1e-4f) shade_hit(sc, h.slot, h.u, h.v, L);
                     if (Ls_ws) { float* lp = Ls_ws + 3 * ((size_t)p * S + i); lp[0] = L[0]; lp[1] = L[1]; lp[2] = L[2]; }
                     acc[0] += L[0] * ss.w.v; acc[1] += L[1] * ss.w.v; acc[2] += L[2] * ss.w.v;
@@ -269,14 +293,51 @@ static int grid_for(int64_t work_items_per_block_unit, int64_t n)
 
 static int ilog2_exact(int N) { if (N <= 0 || (N & (N - 1))) return 0; int l = 0; while ((1 << l) < N) l++; return l; }
 
+// workgroups that are co-resident on the whole chip for a kernel (so a grid-stride loop has no second, partial round)
+template <typename K>
+static int resident_grid(K kernel, int block)
+{
+    int dev = 0, cus = 256, per_cu = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    return cus * per_cu;
+}
+
+static int irt_variant()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TEXIR_IRT_VARIANT"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
+int irt_launch_count(int N) { return (irt_variant() == 2 && ilog2_exact(N) >= 7) ? (N >> 6) : 1; }
+
+template <bool STATS, int MODE, int LSTK, int MINW>
+static void irt_launch_one(bool resident, const SceneDev& sc, const float* pos, const float* nrm, const float* shift, const int32_t* ids, int64_t n_ids,
+                           int N, int l2, int mode, int cell, int last, float* irr, unsigned long long* stats, hipStream_t st)
+{
+    int64_t want = (n_ids + (kBlock / 64) - 1) / (kBlock / 64);
+    int grid = resident ? resident_grid(irt_kernel<STATS, MODE, LSTK, MINW>, kBlock) : 2048;
+    if (want < grid) grid = (int)want;
+    hipLaunchKernelGGL((irt_kernel<STATS, MODE, LSTK, MINW>), dim3(grid), dim3(kBlock), 0, st, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, cell, last, irr, stats);
+}
+
 hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, const float* shift, const int32_t* ids, int64_t n_ids,
                       int N, int mode, float* irr, unsigned long long* stats, hipStream_t st)
 {
     if (n_ids <= 0) return hipSuccess;
-    int grid = grid_for(kBlock / 64, n_ids);
+    // variants (TEXIR_IRT_VARIANT, default 1): 0 capped grid; 1 resident grid; 2 resident + cell-major launches;
+    // 3 resident, 16-entry LDS stack, <=64 VGPR (8 waves/SIMD); 4 resident, 20-entry LDS stack, <=80 VGPR (6 waves/SIMD)
+    const int variant = irt_variant();
     int l2 = ilog2_exact(N);
-    if (stats) hipLaunchKernelGGL(irt_kernel<true>, dim3(grid), dim3(kBlock), 0, st, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, irr, stats);
-    else hipLaunchKernelGGL(irt_kernel<false>, dim3(grid), dim3(kBlock), 0, st, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, irr, stats);
+    if (stats) { irt_launch_one<true, 0, 24, 1>(variant >= 1, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, 0, 1, irr, stats, st); return hipGetLastError(); }
+    if (variant == 2 && l2 >= 7) {
+        const int cells = N >> 6;
+        for (int j = 0; j < cells; j++) irt_launch_one<false, 1, 24, 1>(true, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, j, j == cells - 1, irr, stats, st);
+    } else if (variant == 3) irt_launch_one<false, 0, 16, 8>(true, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, 0, 1, irr, stats, st);
+    else if (variant == 4) irt_launch_one<false, 0, 20, 6>(true, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, 0, 1, irr, stats, st);
+    else irt_launch_one<false, 0, 24, 1>(variant >= 1, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, 0, 1, irr, stats, st);
     return hipGetLastError();
 }
 

@@ -33,8 +33,6 @@ struct GbufArgs {
 
 __global__ __launch_bounds__(kBlock) void gbuffer_kernel(SceneDev sc, GbufArgs g)
 {
-    __shared__ int lds_stack[kLdsStack * kBlock];
-    int* my_stack = lds_stack + threadIdx.x;
     const int64_t P = (int64_t)6 * g.c * g.c;
     uint32_t cn = 0, ct = 0;
     for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < P; p += (int64_t)gridDim.x * kBlock) {
@@ -49,7 +47,7 @@ __global__ __launch_bounds__(kBlock) void gbuffer_kernel(SceneDev sc, GbufArgs g
         const float s2 = 2.f / (float)g.c;
         float dXx = s2 * fb.dx[0], dXy = s2 * fb.dx[1], dXz = s2 * fb.dx[2];
         float dYx = s2 * fb.dy[0], dYy = s2 * fb.dy[1], dYz = s2 * fb.dy[2];
-        Hit h = trace_closest<false>(sc, ex, ey, ez, dx, dy, dz, my_stack, cn, ct);
+        Hit h = trace_closest<false>(sc, ex, ey, ez, dx, dy, dz, cn, ct);
         float o_pos[3] = {1.f, 0.f, 0.f}, o_n[3] = {1.f, 0.f, 0.f}, o_uv[2] = {0.f, 0.f}, o_da[4] = {0.f, 0.f, 0.f, 0.f};   // bg (mat_nvdiffrast.py:125)
         float m = 0.f; int32_t tri = 0;
         if (h.slot >= 0) {

@@ -24,3 +24,16 @@ def assemble_sum(t):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t)
     return t
+
+
+def morton_order(ids, width):
+    """reorder a texel-id list (row-major ids of a [H,width] texture) along the Z-order curve, so that texels processed
+    concurrently by neighbouring wavefronts are neighbours on the surface (their rays then share BVH leaves and texture
+    lines in L2).  The estimator is per-texel, so the order is free."""
+    ids64 = ids.to(torch.int64)
+    r, c = ids64 // width, ids64 % width
+    code = torch.zeros_like(ids64)
+    for b in range(16):
+        code |= ((c >> b) & 1) << (2 * b)
+        code |= ((r >> b) & 1) << (2 * b + 1)
+    return ids[torch.argsort(code)]

@@ -142,7 +142,7 @@ class TracerO3d(nn.Module):
         # one [nt,1,2] draw consumes the same stream in the same order
         shift = torch.rand(nt, 1, 2).reshape(nt, 2).to(self.device)
         seam = torch.from_numpy((self.index_texture.astype(np.int64).sum(-1) == 0).reshape(-1)).to(self.device)
-        ids = torch.nonzero(~seam)[:, 0].to(torch.int32)
+        ids = dist_util.morton_order(torch.nonzero(~seam)[:, 0].to(torch.int32), W)
         rank, world, _ = dist_util.world_info()
         ids = dist_util.shard_block_cyclic(ids, rank, world)
         irr = torch.zeros((nt, 3), device=self.device)
