@@ -59,8 +59,8 @@ TEXIR_API int texir_scene_destroy(texir_scene* scene);
  * (models/mat_nvdiffrast.py:141-150).  tex [Ht,Wt,3] f32; is_device selects pointer kind. */
 TEXIR_API int texir_scene_set_texture(texir_scene* scene, const float* tex, int32_t Ht, int32_t Wt, int32_t is_device, void* stream);
 
-/* out[0]=inner nodes, [1]=triangles, [2]=max depth, [3]=node bytes, [4]=triangle bytes, [5]=uv bytes,
- * [6]=texture bytes, [7]=device */
+/* out[0]=inner nodes of the traversal tree (4-wide quantised by default), [1]=triangles, [2]=max depth, [3]=node bytes,
+ * [4]=triangle bytes, [5]=uv bytes, [6]=texture bytes, [7]=device */
 TEXIR_API int texir_scene_info(const texir_scene* scene, int64_t out[8]);
 
 /* Replaces query_irf (models/tracer_o3d_irt.py:240-269, models/mat_nvdiffrast.py:292-320):

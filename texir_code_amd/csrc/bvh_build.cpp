@@ -133,6 +133,93 @@ int32_t emit(const Tmp* t, std::vector<GpuNode>& out)
     return idx;
 }
 
+// ---- 4-wide collapse: repeatedly open the inner child with the largest surface area until four children ----
+struct Quant { uint8_t lo[3], hi[3]; };
+
+void emit4_fill(GpuNode4& g, const Box& nb, const Tmp* const* kids, int nk, const int32_t* codes)
+{
+    uint32_t e[3]; float scale[3];
+    for (int a = 0; a < 3; a++) {
+        double ext = (double)nb.mx[a] - (double)nb.mn[a];
+        int ex = 1;
+        if (ext > 0.0) { ex = 127 + (int)std::ceil(std::log2(ext / 255.0)); if (ex < 1) ex = 1; if (ex > 254) ex = 254; }
+        // make sure 255 cells really cover the extent in float arithmetic
+        for (;;) { uint32_t bits = (uint32_t)ex << 23; float sc; std::memcpy(&sc, &bits, 4); if ((double)nb.mn[a] + 255.0 * (double)sc >= (double)nb.mx[a] || ex >= 254) { scale[a] = sc; break; } ex++; }
+        e[a] = (uint32_t)ex;
+        g.origin[a] = nb.mn[a];
+    }
+    g.exps = e[0] | (e[1] << 8) | (e[2] << 16);
+    uint32_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    for (int k = 0; k < 4; k++) {
+        uint32_t ql[3] = {255, 255, 255}, qh[3] = {0, 0, 0};          // unused slot: inverted box
+        if (k < nk) {
+            for (int a = 0; a < 3; a++) {
+                double l = std::floor(((double)kids[k]->box.mn[a] - (double)nb.mn[a]) / (double)scale[a]);
+                double h = std::ceil(((double)kids[k]->box.mx[a] - (double)nb.mn[a]) / (double)scale[a]);
+                int li = (int)std::max(0.0, std::min(255.0, l)), hi_ = (int)std::max(0.0, std::min(255.0, h));
+                // conservative in FLOAT decode: origin + q*scale must bracket the child box
+                while (li > 0 && nb.mn[a] + (float)li * scale[a] > kids[k]->box.mn[a]) li--;
+                while (hi_ < 255 && nb.mn[a] + (float)hi_ * scale[a] < kids[k]->box.mx[a]) hi_++;
+                ql[a] = (uint32_t)li; qh[a] = (uint32_t)hi_;
+            }
+        }
+        for (int a = 0; a < 3; a++) { lo[a] |= ql[a] << (8 * k); hi[a] |= qh[a] << (8 * k); }
+        g.c[k] = k < nk ? codes[k] : kEmptyChild;
+    }
+    g.lox = lo[0]; g.loy = lo[1]; g.loz = lo[2]; g.hix = hi[0]; g.hiy = hi[1]; g.hiz = hi[2]; g.pad0 = g.pad1 = 0;
+}
+
+int32_t emit4(const Tmp* t, std::vector<GpuNode4>& out, int depth, int& max_depth)
+{
+    int32_t idx = (int32_t)out.size();
+    out.emplace_back();
+    if (depth > max_depth) max_depth = depth;
+    const Tmp* kids[4]; int nk = 0;
+    if (t->count) { kids[nk++] = t; }                      // degenerate root leaf
+    else { kids[nk++] = t->l.get(); kids[nk++] = t->r.get(); }
+    while (nk < 4) {
+        int best = -1; float ba = -1.f;
+        for (int k = 0; k < nk; k++) if (!kids[k]->count) { float a = kids[k]->box.half_area(); if (a > ba) { ba = a; best = k; } }
+        if (best < 0) break;
+        const Tmp* o = kids[best];
+        kids[best] = o->l.get(); kids[nk++] = o->r.get();
+    }
+    int32_t codes[4];
+    for (int k = 0; k < nk; k++) codes[k] = kids[k]->count ? leaf_code(kids[k]) : emit4(kids[k], out, depth + 1, max_depth);
+    emit4_fill(out[idx], t->box, kids, nk, codes);
+    return idx;
+}
+
+// renumber the wide tree so that the nodes of the first `levels` levels come first, in breadth-first order (they are
+// staged into LDS by the traversal kernels); all other nodes keep their depth-first relative order
+int reorder_top_levels(std::vector<GpuNode4>& nodes, int levels)
+{
+    const int n = (int)nodes.size();
+    std::vector<int32_t> order; order.reserve(n);
+    std::vector<char> taken((size_t)n, 0);
+    std::vector<int32_t> frontier{0};
+    for (int lv = 0; lv < levels && !frontier.empty(); lv++) {
+        std::vector<int32_t> next;
+        for (int32_t i : frontier) {
+            order.push_back(i); taken[i] = 1;
+            for (int k = 0; k < 4; k++) if (nodes[i].c[k] >= 0) next.push_back(nodes[i].c[k]);
+        }
+        frontier.swap(next);
+    }
+    const int top = (int)order.size();
+    for (int i = 0; i < n; i++) if (!taken[i]) order.push_back(i);
+    std::vector<int32_t> new_of((size_t)n);
+    for (int i = 0; i < n; i++) new_of[order[i]] = i;
+    std::vector<GpuNode4> out((size_t)n);
+    for (int i = 0; i < n; i++) {
+        GpuNode4 g = nodes[order[i]];
+        for (int k = 0; k < 4; k++) if (g.c[k] >= 0) g.c[k] = new_of[g.c[k]];
+        out[i] = g;
+    }
+    nodes.swap(out);
+    return top;
+}
+
 }  // namespace
 
 void build_bvh(const float* verts, int V, const int32_t* tris, int T, const float* tri_uvs, BvhHost& out)
@@ -169,6 +256,12 @@ void build_bvh(const float* verts, int V, const int32_t* tris, int T, const floa
         emit(root.get(), out.nodes);
         out.max_depth = root->depth_below;
     }
+    out.nodes4.clear();
+    out.nodes4.reserve((size_t)T / 2 + 16);
+    int d4 = 0;
+    emit4(root.get(), out.nodes4, 1, d4);
+    out.max_depth4 = d4;
+    out.top4 = reorder_top_levels(out.nodes4, kTopLevels);
     out.tris.resize((size_t)T);
     out.uvs.resize((size_t)T);
     for (int i = 0; i < T; i++) {

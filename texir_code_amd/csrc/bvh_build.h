@@ -30,15 +30,33 @@ struct alignas(16) GpuTriUV {
     float uv[8];
 };
 
+// 64-byte 4-wide node with 8-bit child boxes quantised relative to the node's own box (one cache line per traversal step,
+// half the steps of the binary tree):
+//   q0 = (origin.x, origin.y, origin.z, bits: ex | ey<<8 | ez<<16)      biased float exponents: cell size = 2^(e-127)
+//   q1 = (lo.x[4], lo.y[4], lo.z[4], hi.x[4])                           one byte per child, child k in byte k
+//   q2 = (hi.y[4], hi.z[4], 0, 0)
+//   q3 = (child0..3)  child >= 0: inner node index; < 0: leaf code as above; kEmptyChild: unused slot (inverted box)
+struct alignas(16) GpuNode4 {
+    float origin[3]; uint32_t exps;
+    uint32_t lox, loy, loz, hix;
+    uint32_t hiy, hiz, pad0, pad1;
+    int32_t c[4];
+};
+static_assert(sizeof(GpuNode4) == 64, "wide node must be 64 bytes");
+
 constexpr int32_t kEmptyChild = INT32_MIN;   // child slot with an inverted box, never entered
 constexpr int kMaxLeaf = 4;
+constexpr int kTopLevels = 4;             // 1 + 4 + 16 + 64 = at most 85 wide nodes (5440 B) cached in LDS per workgroup
+constexpr int kTopMax = 85;
 constexpr int kMaxDepth = 60;                // traversal stack bound (LDS part + private overflow)
 
 struct BvhHost {
     std::vector<GpuNode> nodes;
+    std::vector<GpuNode4> nodes4;
     std::vector<GpuTri> tris;
     std::vector<GpuTriUV> uvs;
-    int max_depth = 0;
+    int max_depth = 0, max_depth4 = 0;
+    int top4 = 0;            // nodes4[0 .. top4) = the first kTopLevels levels in breadth-first order
 };
 
 // verts [V,3], tris [T,3], tri_uvs [3T,2]

@@ -3,6 +3,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -17,8 +18,10 @@ using namespace texir;
 struct texir_scene {
     int device = 0;
     SceneDev dev{};
+    void* d_nodes4 = nullptr;
     void* d_nodes = nullptr; void* d_tris = nullptr; void* d_uvs = nullptr; float* d_tex = nullptr;
-    int64_t n_nodes = 0, n_tris = 0, max_depth = 0;
+    int64_t n_nodes = 0, n_nodes4 = 0, n_tris = 0, max_depth = 0;
+    int width = 2;
     size_t tex_bytes = 0;
     std::vector<uint32_t> slot_prim;     // leaf slot -> primitive id (host copy, for per-corner attribute uploads)
     void* d_cnrm = nullptr;              // leaf-ordered corner normals, 3 x float4 per triangle
@@ -64,6 +67,16 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
     s->tex_bytes = sizeof(float) * 3 * (size_t)Ht * Wt;
     auto bail = [&](hipError_t e, const char* what) { texir_scene_destroy(s); return fail(TEXIR_ERR_HIP, "%s: %s", what, hipGetErrorString(e)); };
     hipError_t e;
+    // traversal tree: 4-wide quantised by default (TEXIR_BVH_WIDTH=2 keeps the binary tree); falls back to binary when the wide
+    // tree's worst-case stack (3 pushes per level) would not fit the traversal stack
+    const char* wenv = getenv("TEXIR_BVH_WIDTH");
+    int want_w = wenv ? atoi(wenv) : 4;
+    s->width = (want_w == 4 && 3 * h.max_depth4 + 2 <= kStackCap) ? 4 : 2;
+    if (s->width == 4) {
+        s->n_nodes4 = (int64_t)h.nodes4.size(); s->max_depth = h.max_depth4;
+        if ((e = hipMalloc(&s->d_nodes4, h.nodes4.size() * sizeof(GpuNode4))) != hipSuccess) return bail(e, "hipMalloc nodes4");
+        if ((e = hipMemcpy(s->d_nodes4, h.nodes4.data(), h.nodes4.size() * sizeof(GpuNode4), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload nodes4");
+    }
     if ((e = hipMalloc(&s->d_nodes, h.nodes.size() * sizeof(GpuNode))) != hipSuccess) return bail(e, "hipMalloc nodes");
     if ((e = hipMalloc(&s->d_tris, h.tris.size() * sizeof(GpuTri))) != hipSuccess) return bail(e, "hipMalloc tris");
     if ((e = hipMalloc(&s->d_uvs, h.uvs.size() * sizeof(GpuTriUV))) != hipSuccess) return bail(e, "hipMalloc uvs");
@@ -72,6 +85,7 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
     if ((e = hipMemcpy(s->d_tris, h.tris.data(), h.tris.size() * sizeof(GpuTri), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload tris");
     if ((e = hipMemcpy(s->d_uvs, h.uvs.data(), h.uvs.size() * sizeof(GpuTriUV), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload uvs");
     if ((e = hipMemcpy(s->d_tex, hdr_tex, s->tex_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload texture");
+    s->dev.nodes4 = (const float4*)s->d_nodes4; s->dev.top4 = s->width == 4 ? h.top4 : 0;
     s->dev.nodes = (const float4*)s->d_nodes; s->dev.tris = (const float4*)s->d_tris; s->dev.uvs = (const float4*)s->d_uvs;
     s->dev.tex = s->d_tex; s->dev.Ht = Ht; s->dev.Wt = Wt;
     *out = s;
@@ -82,6 +96,7 @@ int texir_scene_destroy(texir_scene* s)
 {
     if (!s) return TEXIR_OK;
     (void)hipSetDevice(s->device);
+    if (s->d_nodes4) (void)hipFree(s->d_nodes4);
     if (s->d_nodes) (void)hipFree(s->d_nodes);
     if (s->d_tris) (void)hipFree(s->d_tris);
     if (s->d_uvs) (void)hipFree(s->d_uvs);
@@ -102,7 +117,8 @@ int texir_scene_set_texture(texir_scene* s, const float* tex, int32_t Ht, int32_
 int texir_scene_info(const texir_scene* s, int64_t out[8])
 {
     if (!s || !out) return fail(TEXIR_ERR_INVALID, "texir_scene_info: null argument");
-    out[0] = s->n_nodes; out[1] = s->n_tris; out[2] = s->max_depth; out[3] = s->n_nodes * (int64_t)sizeof(GpuNode);
+    out[0] = s->width == 4 ? s->n_nodes4 : s->n_nodes; out[1] = s->n_tris; out[2] = s->max_depth;
+    out[3] = s->width == 4 ? s->n_nodes4 * (int64_t)sizeof(GpuNode4) : s->n_nodes * (int64_t)sizeof(GpuNode);
     out[4] = s->n_tris * (int64_t)sizeof(GpuTri); out[5] = s->n_tris * (int64_t)sizeof(GpuTriUV); out[6] = (int64_t)s->tex_bytes; out[7] = s->device;
     return TEXIR_OK;
 }

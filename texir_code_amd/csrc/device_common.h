@@ -10,16 +10,19 @@
 namespace texir {
 
 struct SceneDev {
+    const float4* nodes4;  // GpuNode4 as 4 x 16 B (4-wide quantised tree; null when the scene was built binary-only)
     const float4* nodes;   // GpuNode as 4 x float4
     const float4* tris;    // GpuTri as 3 x float4
     const float4* uvs;     // GpuTriUV as 2 x float4
     const float* tex;      // [Ht,Wt,3]
     int Ht, Wt;
+    int top4;              // first top4 wide nodes = upper tree levels (breadth-first), staged into LDS by kernels that opt in
 };
 
 constexpr int kBlock = 256;          // 4 waves
 constexpr int kLdsStack = 24;        // default: entries per lane kept in LDS (24 KiB per block)
 constexpr int kSentinel = 0x7FFFFFFF;
+constexpr int kStackCap = 96;        // LDS part + private overflow; the host checks the tree's worst case against it
 
 // ------------------------------------------------------------------------------------------------
 // sampling -- kept free of fused multiply-adds so that it tracks the reference's separately rounded
@@ -126,9 +129,17 @@ __device__ __forceinline__ void shade_hit(const SceneDev& sc, int tri_slot, floa
 // ------------------------------------------------------------------------------------------------
 struct Hit { float t, u, v; int slot; };
 
-template <bool STATS, int LSTK = kLdsStack>
+// workgroup-wide copy of the upper levels of the wide tree into LDS (call once per block, all threads)
+__device__ __forceinline__ void stage_top_levels(const SceneDev& sc, float4* lds_top)
+{
+    const int n16 = 4 * sc.top4;
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) lds_top[i] = sc.nodes4[i];
+    __syncthreads();
+}
+
+template <bool STATS, int LSTK = kLdsStack, int WIDTH = 2, bool TOPLDS = false>
 __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float oy, float oz, float dx, float dy, float dz,
-                                             uint32_t& n_nodes, uint32_t& n_tris)
+                                             uint32_t& n_nodes, uint32_t& n_tris, const float4* lds_top = nullptr)
 {
     // the traversal stack: LSTK entries per lane in LDS ([entry][thread], one instance per kernel), deeper ones private
     __shared__ int lds_all[LSTK * kBlock];
@@ -139,7 +150,7 @@ __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float
     float idz = __builtin_amdgcn_rcpf(fabsf(dz) > ooeps ? dz : copysignf(ooeps, dz));
     float oodx = ox * idx, oody = oy * idy, oodz = oz * idz;
     Hit h; h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f; h.slot = -1;
-    int ovf[kMaxDepth + 4 - LSTK];
+    int ovf[kStackCap - LSTK];
     int sp = 0;
     int node = 0;
     // LDS part and private overflow are kept in separate, wave-uniformly guarded code paths: the overflow is almost never
@@ -157,29 +168,76 @@ __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float
         return v;
     };
     while (node != kSentinel) {
+        if (WIDTH == 4) {
+            while (node >= 0 && node != kSentinel) {
+                float4 q0; uint4 q1; uint2 q2; int4 ch;
+                if (TOPLDS && node < sc.top4) {
+                    // upper levels: every ray passes through them -- served from LDS instead of the vector L1
+                    const float4* lp = lds_top + 4 * node;
+                    q0 = lp[0];
+                    q1 = *reinterpret_cast<const uint4*>(lp + 1);
+                    q2 = *reinterpret_cast<const uint2*>(lp + 2);
+                    ch = *reinterpret_cast<const int4*>(lp + 3);
+                } else {
+                    const float4* np = sc.nodes4 + 4 * (size_t)node;
+                    q0 = np[0];
+                    q1 = *reinterpret_cast<const uint4*>(np + 1);
+                    q2 = *reinterpret_cast<const uint2*>(np + 2);
+                    ch = *reinterpret_cast<const int4*>(np + 3);
+                }
+                if (STATS) n_nodes++;
+                const uint32_t ex = __float_as_uint(q0.w);
+                // cell size 2^(e-127) folded into the reciprocal direction; origin folded into the offset
+                const float sx = __uint_as_float((ex & 255u) << 23) * idx, sy = __uint_as_float(((ex >> 8) & 255u) << 23) * idy,
+                            sz = __uint_as_float(((ex >> 16) & 255u) << 23) * idz;
+                const float bx = q0.x * idx - oodx, by = q0.y * idy - oody, bz = q0.z * idz - oodz;
+                float key[4]; int code[4] = {ch.x, ch.y, ch.z, ch.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int sh = 8 * k;
+                    float lx = (float)((q1.x >> sh) & 255u) * sx + bx, hx = (float)((q1.w >> sh) & 255u) * sx + bx;
+                    float ly = (float)((q1.y >> sh) & 255u) * sy + by, hy = (float)((q2.x >> sh) & 255u) * sy + by;
+                    float lz = (float)((q1.z >> sh) & 255u) * sz + bz, hz = (float)((q2.y >> sh) & 255u) * sz + bz;
+                    float tn = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fmaxf(fminf(lz, hz), 0.f));
+                    float tf = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fminf(fmaxf(lz, hz), h.t));
+                    // unused slots carry an inverted box (lo = 255, hi = 0): but a negative direction swaps lo/hi, so test the code too
+                    key[k] = (tn <= tf && code[k] != kEmptyChild) ? tn : __builtin_inff();
+                }
+                // sort the four (key, code) pairs ascending: 5-comparator network
+#define TEXIR_CSWAP(a, b) { bool s_ = key[b] < key[a]; float ka = s_ ? key[b] : key[a], kb = s_ ? key[a] : key[b]; int ca = s_ ? code[b] : code[a], cb = s_ ? code[a] : code[b]; key[a] = ka; key[b] = kb; code[a] = ca; code[b] = cb; }
+                TEXIR_CSWAP(0, 1) TEXIR_CSWAP(2, 3) TEXIR_CSWAP(0, 2) TEXIR_CSWAP(1, 3) TEXIR_CSWAP(1, 2)
+#undef TEXIR_CSWAP
+                const float inf = __builtin_inff();
+                if (key[3] < inf) push(code[3]);
+                if (key[2] < inf) push(code[2]);
+                if (key[1] < inf) push(code[1]);
+                node = key[0] < inf ? code[0] : pop();
+            }
+        } else {
         while (node >= 0 && node != kSentinel) {
-            const float4* np = sc.nodes + 4 * (size_t)node;
-            float4 n0 = np[0], n1 = np[1], n2 = np[2];
-            int2 ch = *reinterpret_cast<const int2*>(np + 3);
-            if (STATS) n_nodes++;
-            float c0lox = n0.x * idx - oodx, c0hix = n0.y * idx - oodx, c0loy = n0.z * idy - oody, c0hiy = n0.w * idy - oody;
-            float c0loz = n2.x * idz - oodz, c0hiz = n2.y * idz - oodz;
-            float c1lox = n1.x * idx - oodx, c1hix = n1.y * idx - oodx, c1loy = n1.z * idy - oody, c1hiy = n1.w * idy - oody;
-            float c1loz = n2.z * idz - oodz, c1hiz = n2.w * idz - oodz;
-            float t0n = fmaxf(fmaxf(fminf(c0lox, c0hix), fminf(c0loy, c0hiy)), fmaxf(fminf(c0loz, c0hiz), 0.f));
-            float t0f = fminf(fminf(fmaxf(c0lox, c0hix), fmaxf(c0loy, c0hiy)), fminf(fmaxf(c0loz, c0hiz), h.t));
-            float t1n = fmaxf(fmaxf(fminf(c1lox, c1hix), fminf(c1loy, c1hiy)), fmaxf(fminf(c1loz, c1hiz), 0.f));
-            float t1f = fminf(fminf(fmaxf(c1lox, c1hix), fmaxf(c1loy, c1hiy)), fminf(fmaxf(c1loz, c1hiz), h.t));
-            bool h0 = t0n <= t0f, h1 = t1n <= t1f;
-            if (h0 && h1) {
-                bool swp = t1n < t0n;
-                int nearc = swp ? ch.y : ch.x, farc = swp ? ch.x : ch.y;
-                push(farc);
-                node = nearc;
-            } else if (h0) node = ch.x;
-            else if (h1) node = ch.y;
-            else node = pop();
-        }
+                const float4* np = sc.nodes + 4 * (size_t)node;
+                float4 n0 = np[0], n1 = np[1], n2 = np[2];
+                int2 ch = *reinterpret_cast<const int2*>(np + 3);
+                if (STATS) n_nodes++;
+                float c0lox = n0.x * idx - oodx, c0hix = n0.y * idx - oodx, c0loy = n0.z * idy - oody, c0hiy = n0.w * idy - oody;
+                float c0loz = n2.x * idz - oodz, c0hiz = n2.y * idz - oodz;
+                float c1lox = n1.x * idx - oodx, c1hix = n1.y * idx - oodx, c1loy = n1.z * idy - oody, c1hiy = n1.w * idy - oody;
+                float c1loz = n2.z * idz - oodz, c1hiz = n2.w * idz - oodz;
+                float t0n = fmaxf(fmaxf(fminf(c0lox, c0hix), fminf(c0loy, c0hiy)), fmaxf(fminf(c0loz, c0hiz), 0.f));
+                float t0f = fminf(fminf(fmaxf(c0lox, c0hix), fmaxf(c0loy, c0hiy)), fminf(fmaxf(c0loz, c0hiz), h.t));
+                float t1n = fmaxf(fmaxf(fminf(c1lox, c1hix), fminf(c1loy, c1hiy)), fmaxf(fminf(c1loz, c1hiz), 0.f));
+                float t1f = fminf(fminf(fmaxf(c1lox, c1hix), fmaxf(c1loy, c1hiy)), fminf(fmaxf(c1loz, c1hiz), h.t));
+                bool h0 = t0n <= t0f, h1 = t1n <= t1f;
+                if (h0 && h1) {
+                    bool swp = t1n < t0n;
+                    int nearc = swp ? ch.y : ch.x, farc = swp ? ch.x : ch.y;
+                    push(farc);
+                    node = nearc;
+                } else if (h0) node = ch.x;
+                else if (h1) node = ch.y;
+                else node = pop();
+            }
+}
         while (node < 0) {
             uint32_t code = ~(uint32_t)node;
             int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
@@ -203,6 +261,131 @@ __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float
         }
     }
     return h;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Resumable variant for persistent waves with lane refill: the per-lane traversal state lives in a struct, and
+// trace_resume() runs whole while-while rounds until at least `refill_min` lanes of the wave have finished their ray
+// (wave ballot), so the caller can compact: shade the finished rays in one batch and hand their lanes new rays.
+// ------------------------------------------------------------------------------------------------
+struct RayState {
+    float dx, dy, dz, idx, idy, idz, oodx, oody, oodz;
+    Hit h;
+    int node, sp;
+};
+
+__device__ __forceinline__ void ray_begin(RayState& r, float ox, float oy, float oz, float dx, float dy, float dz)
+{
+    const float ooeps = 8.271806e-25f;  // 2^-80
+    r.dx = dx; r.dy = dy; r.dz = dz;
+    r.idx = __builtin_amdgcn_rcpf(fabsf(dx) > ooeps ? dx : copysignf(ooeps, dx));
+    r.idy = __builtin_amdgcn_rcpf(fabsf(dy) > ooeps ? dy : copysignf(ooeps, dy));
+    r.idz = __builtin_amdgcn_rcpf(fabsf(dz) > ooeps ? dz : copysignf(ooeps, dz));
+    r.oodx = ox * r.idx; r.oody = oy * r.idy; r.oodz = oz * r.idz;
+    r.h.t = __builtin_inff(); r.h.u = 0.f; r.h.v = 0.f; r.h.slot = -1;
+    r.node = 0; r.sp = 0;
+}
+
+template <int LSTK, int WIDTH>
+__device__ __forceinline__ void trace_resume(const SceneDev& sc, RayState& r, int (&ovf)[kStackCap - LSTK], float ox, float oy, float oz,
+                                             bool more_rays, int refill_min)
+{
+    __shared__ int lds_all[LSTK * kBlock];
+    int* lds_stack = lds_all + threadIdx.x;
+    int sp = r.sp, node = r.node;
+    Hit h = r.h;
+    const float dx = r.dx, dy = r.dy, dz = r.dz, idx = r.idx, idy = r.idy, idz = r.idz, oodx = r.oodx, oody = r.oody, oodz = r.oodz;
+    auto push = [&](int x) {
+        if (sp < LSTK) lds_stack[sp * kBlock] = x;
+        if (__any(sp >= LSTK)) { if (sp >= LSTK) ovf[sp - LSTK] = x; }
+        sp++;
+    };
+    auto pop = [&]() -> int {
+        if (sp == 0) return kSentinel;
+        sp--;
+        int v = lds_stack[(sp < LSTK ? sp : LSTK - 1) * kBlock];
+        if (__any(sp >= LSTK)) { int b = ovf[sp >= LSTK ? sp - LSTK : 0]; v = sp >= LSTK ? b : v; }
+        return v;
+    };
+    for (;;) {
+        const int n_act = __popcll(__ballot(node != kSentinel));
+        if (n_act == 0) break;
+        if (more_rays && 64 - n_act >= refill_min) break;
+        if (WIDTH == 4) {
+            while (node >= 0 && node != kSentinel) {
+                const float4* np = sc.nodes4 + 4 * (size_t)node;
+                float4 q0 = np[0];
+                uint4 q1 = *reinterpret_cast<const uint4*>(np + 1);
+                uint2 q2 = *reinterpret_cast<const uint2*>(np + 2);
+                int4 ch = *reinterpret_cast<const int4*>(np + 3);
+                const uint32_t ex = __float_as_uint(q0.w);
+                const float sx = __uint_as_float((ex & 255u) << 23) * idx, sy = __uint_as_float(((ex >> 8) & 255u) << 23) * idy,
+                            sz = __uint_as_float(((ex >> 16) & 255u) << 23) * idz;
+                const float bx = q0.x * idx - oodx, by = q0.y * idy - oody, bz = q0.z * idz - oodz;
+                float key[4]; int code[4] = {ch.x, ch.y, ch.z, ch.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int sh = 8 * k;
+                    float lx = (float)((q1.x >> sh) & 255u) * sx + bx, hx = (float)((q1.w >> sh) & 255u) * sx + bx;
+                    float ly = (float)((q1.y >> sh) & 255u) * sy + by, hy = (float)((q2.x >> sh) & 255u) * sy + by;
+                    float lz = (float)((q1.z >> sh) & 255u) * sz + bz, hz = (float)((q2.y >> sh) & 255u) * sz + bz;
+                    float tn = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fmaxf(fminf(lz, hz), 0.f));
+                    float tf = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fminf(fmaxf(lz, hz), h.t));
+                    key[k] = (tn <= tf && code[k] != kEmptyChild) ? tn : __builtin_inff();
+                }
+#define TEXIR_CSWAP(a, b) { bool s_ = key[b] < key[a]; float ka = s_ ? key[b] : key[a], kb = s_ ? key[a] : key[b]; int ca = s_ ? code[b] : code[a], cb = s_ ? code[a] : code[b]; key[a] = ka; key[b] = kb; code[a] = ca; code[b] = cb; }
+                TEXIR_CSWAP(0, 1) TEXIR_CSWAP(2, 3) TEXIR_CSWAP(0, 2) TEXIR_CSWAP(1, 3) TEXIR_CSWAP(1, 2)
+#undef TEXIR_CSWAP
+                const float inf = __builtin_inff();
+                if (key[3] < inf) push(code[3]);
+                if (key[2] < inf) push(code[2]);
+                if (key[1] < inf) push(code[1]);
+                node = key[0] < inf ? code[0] : pop();
+            }
+        } else {
+            while (node >= 0 && node != kSentinel) {
+                const float4* np = sc.nodes + 4 * (size_t)node;
+                float4 n0 = np[0], n1 = np[1], n2 = np[2];
+                int2 ch = *reinterpret_cast<const int2*>(np + 3);
+                float c0lox = n0.x * idx - oodx, c0hix = n0.y * idx - oodx, c0loy = n0.z * idy - oody, c0hiy = n0.w * idy - oody;
+                float c0loz = n2.x * idz - oodz, c0hiz = n2.y * idz - oodz;
+                float c1lox = n1.x * idx - oodx, c1hix = n1.y * idx - oodx, c1loy = n1.z * idy - oody, c1hiy = n1.w * idy - oody;
+                float c1loz = n2.z * idz - oodz, c1hiz = n2.w * idz - oodz;
+                float t0n = fmaxf(fmaxf(fminf(c0lox, c0hix), fminf(c0loy, c0hiy)), fmaxf(fminf(c0loz, c0hiz), 0.f));
+                float t0f = fminf(fminf(fmaxf(c0lox, c0hix), fmaxf(c0loy, c0hiy)), fminf(fmaxf(c0loz, c0hiz), h.t));
+                float t1n = fmaxf(fmaxf(fminf(c1lox, c1hix), fminf(c1loy, c1hiy)), fmaxf(fminf(c1loz, c1hiz), 0.f));
+                float t1f = fminf(fminf(fmaxf(c1lox, c1hix), fmaxf(c1loy, c1hiy)), fminf(fmaxf(c1loz, c1hiz), h.t));
+                bool h0 = t0n <= t0f, h1 = t1n <= t1f;
+                if (h0 && h1) {
+                    bool swp = t1n < t0n;
+                    push(swp ? ch.x : ch.y);
+                    node = swp ? ch.y : ch.x;
+                } else if (h0) node = ch.x;
+                else if (h1) node = ch.y;
+                else node = pop();
+            }
+        }
+        while (node < 0) {
+            uint32_t code = ~(uint32_t)node;
+            int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
+            for (int i = first; i < first + cnt; i++) {
+                const float4* tp = sc.tris + 3 * (size_t)i;
+                float4 v0 = tp[0], e1 = tp[1], e2 = tp[2];
+                float px = dy * e2.z - dz * e2.y, py = dz * e2.x - dx * e2.z, pz = dx * e2.y - dy * e2.x;
+                float det = e1.x * px + e1.y * py + e1.z * pz;
+                float inv = __builtin_amdgcn_rcpf(det);
+                float tx = ox - v0.x, ty = oy - v0.y, tz = oz - v0.z;
+                float u = (tx * px + ty * py + tz * pz) * inv;
+                float qx = ty * e1.z - tz * e1.y, qy = tz * e1.x - tx * e1.z, qz = tx * e1.y - ty * e1.x;
+                float v = (dx * qx + dy * qy + dz * qz) * inv;
+                float t = (e2.x * qx + e2.y * qy + e2.z * qz) * inv;
+                bool ok = (det != 0.f) & (u >= 0.f) & (u <= 1.f) & (v >= 0.f) & (u + v <= 1.f) & (t > 0.f) & (t < h.t);
+                if (ok) { h.t = t; h.u = u; h.v = v; h.slot = i; }
+            }
+            node = pop();
+        }
+    }
+    r.sp = sp; r.node = node; r.h = h;
 }
 
 __device__ __forceinline__ float wave_sum(float x)

@@ -48,12 +48,14 @@ __device__ __forceinline__ uint32_t cell_to_pass(uint32_t J, float sh0, float sh
 
 // MODE 0: all passes of a texel in one launch (any N).  MODE 1: one direction cell per launch (cell-major schedule);
 // irr accumulates the raw sum over launches and the last launch applies the 2*pi/N scale.
-template <bool STATS, int MODE, int LSTK, int MINW>
+template <bool STATS, int MODE, int LSTK, int MINW, int WIDTH, bool TOPLDS>
 __global__ __launch_bounds__(kBlock, MINW) void irt_kernel(SceneDev sc, const float* __restrict__ pos, const float* __restrict__ nrm,
                                                      const float* __restrict__ shift, const int32_t* __restrict__ ids, int64_t n_ids,
                                                      int N, int log2N, int mode, int cell, int last_cell, float* __restrict__ irr,
                                                      unsigned long long* __restrict__ stats)
 {
+    __shared__ float4 lds_top[TOPLDS ? 4 * kTopMax : 1];
+    if (TOPLDS) stage_top_levels(sc, lds_top);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + wave, nw = (int64_t)gridDim.x * (kBlock / 64);
     uint32_t c_nodes = 0, c_tris = 0, c_rays = 0, c_hits = 0;
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(kBlock, MINW) void irt_kernel(SceneDev sc, const fl
                 float s1 = shift_wrap_clamp(ham1(i), sh1);
                 float d[3];
                 sample_dir(mode, s0, s1, 0.f, f, d);
-                Hit h = trace_closest<STATS, LSTK>(sc, px, py, pz, d[0], d[1], d[2], c_nodes, c_tris);
+                Hit h = trace_closest<STATS, LSTK, WIDTH, TOPLDS>(sc, px, py, pz, d[0], d[1], d[2], c_nodes, c_tris, lds_top);
                 if (STATS) c_rays++;
                 if (h.slot >= 0 && h.t > 1e-4f) {          // tracer_o3d_irt.py:248
                     float L[3];
@@ -110,6 +112,72 @@ __global__ __launch_bounds__(kBlock, MINW) void irt_kernel(SceneDev sc, const fl
     }
 }
 
+// Persistent-wave variant with lane refill (wavefront ballot / prefix-sum ray compaction): a wave owns one texel at a time
+// and keeps its 64 lanes busy -- whenever >= refill_min lanes have finished their ray, the finished rays are shaded in one
+// batch and the idle lanes take the texel's next samples (rank among idle lanes = mbcnt of the ballot mask).
+template <int WIDTH>
+__global__ __launch_bounds__(kBlock) void irt_refill_kernel(SceneDev sc, const float* __restrict__ pos, const float* __restrict__ nrm,
+                                                            const float* __restrict__ shift, const int32_t* __restrict__ ids, int64_t n_ids,
+                                                            int N, int log2N, int mode, int refill_min, float* __restrict__ irr)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + wave, nw = (int64_t)gridDim.x * (kBlock / 64);
+    int ovf[kStackCap - kLdsStack];
+    for (int64_t k = gw; k < n_ids; k += nw) {
+        const int64_t t = ids ? (int64_t)ids[k] : k;
+        const float px = pos[3 * t], py = pos[3 * t + 1], pz = pos[3 * t + 2];
+        const float nx = nrm[3 * t], ny = nrm[3 * t + 1], nz = nrm[3 * t + 2];
+        const float sh0 = shift[2 * t], sh1 = shift[2 * t + 1];
+        const Frame f = make_frame(nx, ny, nz);
+        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+        RayState r;
+        r.node = kSentinel; r.sp = 0; r.h.slot = -1; r.h.t = 0.f; r.h.u = r.h.v = 0.f;
+        r.dx = r.dy = r.dz = 0.f; r.idx = r.idy = r.idz = 0.f; r.oodx = r.oody = r.oodz = 0.f;
+        bool have_ray = false;
+        int q_next = 0;                                        // wave-uniform: samples handed out so far
+        for (;;) {
+            const bool idle = r.node == kSentinel;
+            // finished rays: hit shader + accumulate (batched over all lanes that finished since the last refill)
+            if (idle && have_ray) {
+                if (r.h.slot >= 0 && r.h.t > 1e-4f) {              // tracer_o3d_irt.py:248
+                    float L[3];
+                    shade_hit(sc, r.h.slot, r.h.u, r.h.v, L);
+                    float ndl = fminf(fmaxf(nx * r.dx + ny * r.dy + nz * r.dz, 0.f), 1.f);     // :170, RAW normal
+                    acc0 += L[0] * ndl; acc1 += L[1] * ndl; acc2 += L[2] * ndl;
+                }
+                have_ray = false;
+            }
+            // compaction: idle lanes take the next samples, rank = number of idle lanes below this one
+            const unsigned long long idle_mask = __ballot(idle);
+            if (q_next < N) {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+                const int q = q_next + rank;
+                if (idle && q < N) {
+                    uint32_t i = sample_index((uint32_t)(q >> 6), (uint32_t)(q & 63), (uint32_t)N, log2N);
+                    if (i >= (uint32_t)N) i = (uint32_t)q;          // (N not a multiple of 64: natural order already)
+                    float s0 = shift_wrap_clamp(ham0(i, (uint32_t)N), sh0);
+                    float s1 = shift_wrap_clamp(ham1(i), sh1);
+                    float d[3];
+                    sample_dir(mode, s0, s1, 0.f, f, d);
+                    ray_begin(r, px, py, pz, d[0], d[1], d[2]);
+                    have_ray = true;
+                }
+                q_next += __popcll(idle_mask);
+            }
+            if (__ballot(r.node != kSentinel) == 0ull) break;
+            trace_resume<kLdsStack, WIDTH>(sc, r, ovf, px, py, pz, q_next < N, refill_min);
+        }
+        acc0 = wave_sum(acc0); acc1 = wave_sum(acc1); acc2 = wave_sum(acc2);
+        if (lane == 0) {
+            const float pi = 3.141592653589793f;
+            irr[3 * t] = ((acc0 * 2.f) * pi) / (float)N;
+            irr[3 * t + 1] = ((acc1 * 2.f) * pi) / (float)N;
+            irr[3 * t + 2] = ((acc2 * 2.f) * pi) / (float)N;
+        }
+    }
+}
+
+template <int WIDTH>
 __global__ __launch_bounds__(kBlock) void trace_shade_kernel(SceneDev sc, const float* __restrict__ org, const float* __restrict__ dir,
                                                              int64_t R, float t_min, float* __restrict__ rad, float* __restrict__ t_hit,
                                                              uint32_t* __restrict__ prim, float* __restrict__ puv)
@@ -118,7 +186,7 @@ __global__ __launch_bounds__(kBlock) void trace_shade_kernel(SceneDev sc, const 
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < R; r += (int64_t)gridDim.x * kBlock) {
         float ox = org[3 * r], oy = org[3 * r + 1], oz = org[3 * r + 2];
         float dx = dir[3 * r], dy = dir[3 * r + 1], dz = dir[3 * r + 2];
-        Hit h = trace_closest<false>(sc, ox, oy, oz, dx, dy, dz, cn, ct);
+        Hit h = trace_closest<false, kLdsStack, WIDTH>(sc, ox, oy, oz, dx, dy, dz, cn, ct);
         float L[3] = {0.f, 0.f, 0.f};
         bool hit = h.slot >= 0 && h.t > t_min;
         if (hit) shade_hit(sc, h.slot, h.u, h.v, L);
@@ -208,7 +276,7 @@ __device__ __forceinline__ SpecSample spec_sample(const Frame& f, float nx, floa
 #pragma clang fp contract(fast)
 
 // lanes-per-pixel = S when S is a power of two <= 64 (several pixels per wave), else 64 with ceil(S/64) passes
-template <bool BWD>
+template <bool BWD, int WIDTH>
 __global__ __launch_bounds__(kBlock) void spec_kernel(SceneDev sc, const float* __restrict__ normal, const float* __restrict__ albedo,
                                                       const float* __restrict__ rough, const float* __restrict__ points,
                                                       const float* __restrict__ irr, const float* __restrict__ cam,
@@ -254,7 +322,7 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(SceneDev sc, const float* 
                     L[0] = lp[0]; L[1] = lp[1]; L[2] = lp[2];
                     dacc += (L[0] * g0 + L[1] * g1 + L[2] * g2) * ss.w.d;
                 } else {
-                    Hit h = trace_closest<false>(sc, ox, oy, oz, ss.l[0], ss.l[1], ss.l[2], cn, ct);
+                    Hit h = trace_closest<false, kLdsStack, WIDTH>(sc, ox, oy, oz, ss.l[0], ss.l[1], ss.l[2], cn, ct);
                     if (h.slot >= 0 && h.t > 1e-4f) shade_hit(sc, h.slot, h.u, h.v, L);
                     if (Ls_ws) { float* lp = Ls_ws + 3 * ((size_t)p * S + i); lp[0] = L[0]; lp[1] = L[1]; lp[2] = L[2]; }
                     acc[0] += L[0] * ss.w.v; acc[1] += L[1] * ss.w.v; acc[2] += L[2] * ss.w.v;
@@ -313,31 +381,49 @@ static int irt_variant()
 
 int irt_launch_count(int N) { return (irt_variant() == 2 && ilog2_exact(N) >= 7) ? (N >> 6) : 1; }
 
+template <bool STATS, int MODE, int LSTK, int MINW, int WIDTH, bool TOPLDS>
+static void irt_launch_w(bool resident, const SceneDev& sc, const float* pos, const float* nrm, const float* shift, const int32_t* ids, int64_t n_ids,
+                         int N, int l2, int mode, int cell, int last, float* irr, unsigned long long* stats, hipStream_t st)
+{
+    int64_t want = (n_ids + (kBlock / 64) - 1) / (kBlock / 64);
+    int grid = resident ? resident_grid(irt_kernel<STATS, MODE, LSTK, MINW, WIDTH, TOPLDS>, kBlock) : 2048;
+    if (want < grid) grid = (int)want;
+    hipLaunchKernelGGL((irt_kernel<STATS, MODE, LSTK, MINW, WIDTH, TOPLDS>), dim3(grid), dim3(kBlock), 0, st, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, cell, last, irr, stats);
+}
+
 template <bool STATS, int MODE, int LSTK, int MINW>
 static void irt_launch_one(bool resident, const SceneDev& sc, const float* pos, const float* nrm, const float* shift, const int32_t* ids, int64_t n_ids,
                            int N, int l2, int mode, int cell, int last, float* irr, unsigned long long* stats, hipStream_t st)
 {
-    int64_t want = (n_ids + (kBlock / 64) - 1) / (kBlock / 64);
-    int grid = resident ? resident_grid(irt_kernel<STATS, MODE, LSTK, MINW>, kBlock) : 2048;
-    if (want < grid) grid = (int)want;
-    hipLaunchKernelGGL((irt_kernel<STATS, MODE, LSTK, MINW>), dim3(grid), dim3(kBlock), 0, st, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, cell, last, irr, stats);
+    static const bool top_lds = getenv("TEXIR_TOP_LDS") ? atoi(getenv("TEXIR_TOP_LDS")) != 0 : false;
+    if (sc.nodes4 && top_lds) irt_launch_w<STATS, MODE, LSTK, MINW, 4, true>(resident, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, cell, last, irr, stats, st);
+    else if (sc.nodes4) irt_launch_w<STATS, MODE, LSTK, MINW, 4, false>(resident, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, cell, last, irr, stats, st);
+    else irt_launch_w<STATS, MODE, LSTK, MINW, 2, false>(resident, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, cell, last, irr, stats, st);
 }
 
 hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, const float* shift, const int32_t* ids, int64_t n_ids,
                       int N, int mode, float* irr, unsigned long long* stats, hipStream_t st)
 {
     if (n_ids <= 0) return hipSuccess;
-    // variants (TEXIR_IRT_VARIANT, default 1): 0 capped grid; 1 resident grid; 2 resident + cell-major launches;
-    // 3 resident, 16-entry LDS stack, <=64 VGPR (8 waves/SIMD); 4 resident, 20-entry LDS stack, <=80 VGPR (6 waves/SIMD)
+    // variants (TEXIR_IRT_VARIANT, default 1): 0 capped grid; 1 resident grid; 2 resident + cell-major launches
     const int variant = irt_variant();
     int l2 = ilog2_exact(N);
     if (stats) { irt_launch_one<true, 0, 24, 1>(variant >= 1, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, 0, 1, irr, stats, st); return hipGetLastError(); }
     if (variant == 2 && l2 >= 7) {
         const int cells = N >> 6;
         for (int j = 0; j < cells; j++) irt_launch_one<false, 1, 24, 1>(true, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, j, j == cells - 1, irr, stats, st);
-    } else if (variant == 3) irt_launch_one<false, 0, 16, 8>(true, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, 0, 1, irr, stats, st);
-    else if (variant == 4) irt_launch_one<false, 0, 20, 6>(true, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, 0, 1, irr, stats, st);
-    else irt_launch_one<false, 0, 24, 1>(variant >= 1, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, 0, 1, irr, stats, st);
+    } else if (variant >= 5) {
+        // 5: persistent waves with lane refill; refill threshold from TEXIR_REFILL_MIN (default 16 idle lanes)
+        static const int refill_min = getenv("TEXIR_REFILL_MIN") ? atoi(getenv("TEXIR_REFILL_MIN")) : 16;
+        int64_t want = (n_ids + (kBlock / 64) - 1) / (kBlock / 64);
+        if (sc.nodes4) {
+            int grid = resident_grid(irt_refill_kernel<4>, kBlock); if (want < grid) grid = (int)want;
+            hipLaunchKernelGGL(irt_refill_kernel<4>, dim3(grid), dim3(kBlock), 0, st, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, refill_min, irr);
+        } else {
+            int grid = resident_grid(irt_refill_kernel<2>, kBlock); if (want < grid) grid = (int)want;
+            hipLaunchKernelGGL(irt_refill_kernel<2>, dim3(grid), dim3(kBlock), 0, st, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, refill_min, irr);
+        }
+    } else irt_launch_one<false, 0, 24, 1>(variant >= 1, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, 0, 1, irr, stats, st);
     return hipGetLastError();
 }
 
@@ -345,7 +431,8 @@ hipError_t launch_trace_shade(const SceneDev& sc, const float* org, const float*
                               uint32_t* prim, float* puv, hipStream_t st)
 {
     if (R <= 0) return hipSuccess;
-    hipLaunchKernelGGL(trace_shade_kernel, dim3(grid_for(kBlock, R)), dim3(kBlock), 0, st, sc, org, dir, R, t_min, rad, t_hit, prim, puv);
+    if (sc.nodes4) hipLaunchKernelGGL(trace_shade_kernel<4>, dim3(grid_for(kBlock, R)), dim3(kBlock), 0, st, sc, org, dir, R, t_min, rad, t_hit, prim, puv);
+    else hipLaunchKernelGGL(trace_shade_kernel<2>, dim3(grid_for(kBlock, R)), dim3(kBlock), 0, st, sc, org, dir, R, t_min, rad, t_hit, prim, puv);
     return hipGetLastError();
 }
 
@@ -364,8 +451,12 @@ hipError_t launch_spec_fwd(const SceneDev& sc, const float* normal, const float*
     if (P <= 0) return hipSuccess;
     int lpp = lanes_per_pixel(S);
     int64_t pix_per_block = (int64_t)(kBlock / 64) * (64 / lpp);
-    hipLaunchKernelGGL(spec_kernel<false>, dim3(grid_for(pix_per_block, P)), dim3(kBlock), 0, st, sc, normal, albedo, rough, points, irr, cam,
-                       shift, P, S, lpp, rgb, Ls_ws, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+    if (sc.nodes4)
+        hipLaunchKernelGGL((spec_kernel<false, 4>), dim3(grid_for(pix_per_block, P)), dim3(kBlock), 0, st, sc, normal, albedo, rough, points, irr, cam,
+                           shift, P, S, lpp, rgb, Ls_ws, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+    else
+        hipLaunchKernelGGL((spec_kernel<false, 2>), dim3(grid_for(pix_per_block, P)), dim3(kBlock), 0, st, sc, normal, albedo, rough, points, irr, cam,
+                           shift, P, S, lpp, rgb, Ls_ws, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
     return hipGetLastError();
 }
 
@@ -377,7 +468,7 @@ hipError_t launch_spec_bwd(const float* normal, const float* rough, const float*
     int lpp = lanes_per_pixel(S);
     int64_t pix_per_block = (int64_t)(kBlock / 64) * (64 / lpp);
     SceneDev none{};
-    hipLaunchKernelGGL(spec_kernel<true>, dim3(grid_for(pix_per_block, P)), dim3(kBlock), 0, st, none, normal, (const float*)nullptr, rough,
+    hipLaunchKernelGGL((spec_kernel<true, 2>), dim3(grid_for(pix_per_block, P)), dim3(kBlock), 0, st, none, normal, (const float*)nullptr, rough,
                        points, irr, cam, shift, P, S, lpp, (float*)nullptr, const_cast<float*>(Ls_ws), d_rgb, d_albedo, d_rough);
     return hipGetLastError();
 }

@@ -31,6 +31,7 @@ struct GbufArgs {
     float *pos, *nrm, *mask, *uv, *uvda; int32_t* tri;
 };
 
+template <int WIDTH>
 __global__ __launch_bounds__(kBlock) void gbuffer_kernel(SceneDev sc, GbufArgs g)
 {
     const int64_t P = (int64_t)6 * g.c * g.c;
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(kBlock) void gbuffer_kernel(SceneDev sc, GbufArgs g
         const float s2 = 2.f / (float)g.c;
         float dXx = s2 * fb.dx[0], dXy = s2 * fb.dx[1], dXz = s2 * fb.dx[2];
         float dYx = s2 * fb.dy[0], dYy = s2 * fb.dy[1], dYz = s2 * fb.dy[2];
-        Hit h = trace_closest<false>(sc, ex, ey, ez, dx, dy, dz, cn, ct);
+        Hit h = trace_closest<false, kLdsStack, WIDTH>(sc, ex, ey, ez, dx, dy, dz, cn, ct);
         float o_pos[3] = {1.f, 0.f, 0.f}, o_n[3] = {1.f, 0.f, 0.f}, o_uv[2] = {0.f, 0.f}, o_da[4] = {0.f, 0.f, 0.f, 0.f};   // bg (mat_nvdiffrast.py:125)
         float m = 0.f; int32_t tri = 0;
         if (h.slot >= 0) {
@@ -136,7 +137,8 @@ hipError_t launch_gbuffer(const SceneDev& sc, const float* mvp_host, const float
     g.cnrm = cnrm; g.c = c; g.flip_v = flip_v; g.pos = pos; g.nrm = nrm; g.mask = mask; g.uv = uv; g.uvda = uvda; g.tri = tri;
     int64_t P = (int64_t)6 * c * c;
     int64_t nb = (P + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(gbuffer_kernel, dim3((int)(nb > 2048 ? 2048 : nb)), dim3(kBlock), 0, st, sc, g);
+    if (sc.nodes4) hipLaunchKernelGGL(gbuffer_kernel<4>, dim3((int)(nb > 2048 ? 2048 : nb)), dim3(kBlock), 0, st, sc, g);
+    else hipLaunchKernelGGL(gbuffer_kernel<2>, dim3((int)(nb > 2048 ? 2048 : nb)), dim3(kBlock), 0, st, sc, g);
     return hipGetLastError();
 }
 
