@@ -101,37 +101,69 @@ def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5):
             m1 = model(mvp, i, cam, -1)
             seg, fm, _ = build_masks(segs, m1["rgb"])
             room = torch.ones((1,) + tuple(seg.shape[1:]), device=dev)
-            data.append((mvp, cam, gt["rgb"].clone(), gt["empty_mask"].clone(), seg, fm, room))
+            data.append((mvp, cam.to(dev), gt["rgb"].clone(), gt["empty_mask"].clone(), seg, fm, room))
         model.materials_a.copy_(a0)
         model.materials_r.copy_(r0)
-    loss_fn = RenderLoss("L1", 1)
+    loss_fn = RenderLoss("L1", 1, lazy_item=True)
     opt = FusedAdam([model.materials_a, model.materials_r], lr=3e-2)
     opt.set_clamp(model.materials_r, 1e-2, 0.8)
     opt.set_clamp(model.materials_a, 0.0, float("inf"))
-    times = []
-    for it in range(warmup + steps):
-        v = (it * world + rank) % len(views)
+    if world > 1:
+        import torch.distributed as dist
+
+    def fwd_bwd(v):
         mvp, cam, gt, gmask, seg, fm, room = data[v]
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
         preds = model(mvp, v, cam, 2)
         loss = loss_fn(gt, preds, gmask, fm, seg, stage=2, room_seg_mask=room)[0]
-        opt.zero_grad()
+        opt.zero_grad(set_to_none=False)
         loss.backward()
+        return loss
+
+    def eager_step(v):
+        fwd_bwd(v)
         if world > 1:
-            import torch.distributed as dist
             dist.all_reduce(model.materials_a.grad)
             dist.all_reduce(model.materials_r.grad)
         opt.step()
+
+    # hipGraph capture of the launch-bound part of the step (texir_code_amd/graph_step.py); TEXIR_MAT_GRAPH=0 runs eagerly
+    use_graph = os.environ.get("TEXIR_MAT_GRAPH", "1") == "1"
+    for p in (model.materials_a, model.materials_r):
+        p.grad = torch.zeros_like(p)
+    for v in range(len(views)):
+        eager_step(v)                       # warm caches
+    gs = None
+    if use_graph:
+        from texir_code_amd.graph_step import GraphedMatStep
+        try:
+            gs = GraphedMatStep(model, loss_fn, opt, [model.materials_a, model.materials_r])
+            for v in range(len(views)):
+                mvp, cam, gt, gmask, seg, fm, room = data[v]
+                gs.capture(v, mvp, cam, gt, gmask, seg, fm, room, 2)
+        except Exception as e:             # capture is an optimisation, not a requirement
+            print("material-step graph capture unavailable (%s); running eagerly" % (str(e).splitlines()[0][:120],), file=sys.stderr)
+            gs = None
+            model._static_shift = None
+    graphs = gs is not None
+    times = []
+    for it in range(warmup + steps):
+        v = (it * world + rank) % len(views)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if gs is not None:
+            gs.step(v, 2, all_reduce=dist.all_reduce if world > 1 else None)
+        else:
+            eager_step(v)
         torch.cuda.synchronize()
         if it >= warmup:
             times.append((time.perf_counter() - t0) * 1e3)
     med = float(np.median(times))
+    model._static_shift = None
     if world > 1:
         tt = torch.tensor([med], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         med = float(tt.item())
-    return {"ms": round(med, 3), "stage": 2, "steps": steps, "warmup": warmup,
+    return {"ms": round(med, 3), "stage": 2, "steps": steps, "warmup": warmup, "hipgraph": bool(graphs),
             "config": "stage-2 step: albedo %d^2x3 + roughness %d^2x1 (%.1f M params), %d px x %d spp, %d-tri mesh, %d views%s"
                       % (tres, tres, (tres * tres * 4) / 1e6, 6 * cube * cube, S, sc0["T"], len(views), ", view-sharded + grad all_reduce" if world > 1 else "")}
 

@@ -147,18 +147,22 @@ TEXIR_API int texir_scene_set_corner_normals(texir_scene* scene, const float* co
 TEXIR_API int texir_gbuffer_cast(const texir_scene* scene, const float* mvp /*host*/, int32_t cube_res, int32_t flip_v,
                        float* pos, float* nrm, float* mask, float* uv, float* uv_da, int32_t* tri_id, void* stream);
 
-/* ---- nvdiffrast `texture` restated (models/mat_nvdiffrast.py:131-139).  A texture [H,W,C] (C <= 4) lives at the
- * head of a mip buffer of texir_mip_elems() floats; texir_mip_build fills levels 1.. by 2x2 box filtering.
- * filter_mode 0 = 'linear' (bilinear, level 0), 1 = 'linear-mipmap-linear' (trilinear, LOD from uv_da); wrap boundary. */
+/* ---- nvdiffrast `texture` restated (models/mat_nvdiffrast.py:131-139).  Level 0 of the mip stack IS the caller's texture
+ * [H,W,C] (C <= 4, no copy); levels 1.. live in a caller-provided "rest" buffer of texir_mip_elems() floats that
+ * texir_mip_build fills by 2x2 box filtering.
+ * filter_mode 0 = 'linear' (bilinear, level 0; mips_rest may be NULL), 1 = 'linear-mipmap-linear' (trilinear, LOD from
+ * uv_da); boundary_mode 'wrap'. */
 TEXIR_API int32_t texir_mip_levels(int32_t H, int32_t W, int32_t max_mip_level);
 TEXIR_API int64_t texir_mip_elems(int32_t H, int32_t W, int32_t C, int32_t levels);
-TEXIR_API int texir_mip_build(float* mips /*dev*/, int32_t H, int32_t W, int32_t C, int32_t levels, void* stream);
-TEXIR_API int texir_tex_fetch_forward(const float* mips /*dev*/, int32_t H, int32_t W, int32_t C, int32_t levels,
-                       const float* uv /*dev [P,2]*/, const float* uv_da /*dev [P,4], nullable for mode 0*/,
+TEXIR_API int texir_mip_build(const float* tex /*dev*/, float* mips_rest /*dev*/, int32_t H, int32_t W, int32_t C, int32_t levels,
+                       void* stream);
+TEXIR_API int texir_tex_fetch_forward(const float* tex /*dev*/, const float* mips_rest /*dev, nullable*/, int32_t H, int32_t W,
+                       int32_t C, int32_t levels, const float* uv /*dev [P,2]*/, const float* uv_da /*dev [P,4], nullable for mode 0*/,
                        int32_t filter_mode, int64_t P, float* out /*dev [P,C]*/, void* stream);
-/* grad_mips [texir_mip_elems] dev must be zero on entry; on return its first H*W*C floats hold d loss / d texture. */
-TEXIR_API int texir_tex_fetch_backward(float* grad_mips /*dev*/, int32_t H, int32_t W, int32_t C, int32_t levels,
-                       const float* uv, const float* uv_da, int32_t filter_mode, int64_t P,
+/* d_tex [H,W,C] and grad_rest [texir_mip_elems] (dev) must be zero on entry; on return d_tex holds d loss / d texture
+ * (the gradient scattered into the mip levels is folded down to level 0). */
+TEXIR_API int texir_tex_fetch_backward(float* d_tex /*dev*/, float* grad_rest /*dev, nullable for mode 0*/, int32_t H, int32_t W,
+                       int32_t C, int32_t levels, const float* uv, const float* uv_da, int32_t filter_mode, int64_t P,
                        const float* d_out /*dev [P,C]*/, void* stream);
 
 /* ---- optimiser step of the material textures: torch.optim.Adam(lr, betas, eps) (trainer/train_material.py:122-123,448-450)

@@ -199,3 +199,50 @@ def test_index_texture_path_generate_positions_and_gather(tmp_path):
     close = np.abs(got - ref).max(-1) < 1e-3
     assert close.mean() > 0.98, close.mean()
     assert rel_l2(got[close], ref[close]) < 1e-5
+
+
+def test_graphed_material_step_equals_eager(golden):
+    """hipGraph replay of forward+loss+backward must reproduce the eager step bit-for-bit (same shifts, same Adam)"""
+    from texir_code_amd import cameras, conf as C
+    from texir_code_amd.graph_step import GraphedMatStep
+    from texir_code_amd.loss import RenderLoss
+    from texir_code_amd.models import MaterialModel
+    from texir_code_amd.optim import FusedAdam
+    from texir_code_amd.scene import Scene
+    g = golden("irt_room.npz")
+    cf = C.parse_string("train{ pano_img_res = [32,64]\n sample_light = [64,16]\n hdr_exposure = 0 }\nmodels{ render{ sample_type = [uniform, importance] } }")
+    mvp, cam = cameras.cube_mvps(cameras.grid_cameras(1)[0])
+    cam = cam.cuda()
+    res = []
+    for mode in ("eager", "graph"):
+        torch.manual_seed(5)
+        sc = Scene(g["verts"], g["tris"], g["tri_uvs"], g["hdr"], device=0)
+        m = MaterialModel.from_arrays(sc, g["hdr"], torch.rand(64, 64, 3) * 2, cf, albedo_res=64, roughness_res=128)
+        c = m.cube_res
+        gt = torch.rand(6, c, c, 3, device="cuda")
+        gmask = torch.ones(6, c, c, 1, device="cuda")
+        segs = torch.randint(40, 49, (6, c, c, 1)).float().cuda()
+        from texir_code_amd.trainer.train_material import build_masks
+        seg, fm, _ = build_masks(segs, torch.rand(6, c, c, 3, device="cuda") - 0.5)
+        room = torch.ones((1, 6, c, c, 1), device="cuda")
+        loss_fn = RenderLoss("L1", 1, lazy_item=True)
+        opt = FusedAdam([m.materials_a, m.materials_r], lr=3e-2)
+        opt.set_clamp(m.materials_r, 1e-2, 0.8)
+        torch.manual_seed(9)
+        if mode == "eager":
+            for _ in range(3):
+                preds = m(mvp, "v", cam, 2)
+                loss = loss_fn(gt, preds, gmask, fm, seg, stage=2, room_seg_mask=room)[0]
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+        else:
+            gs = GraphedMatStep(m, loss_fn, opt, [m.materials_a, m.materials_r])
+            gs.capture("v", mvp, cam, gt, gmask, seg, fm, room, 2)       # warm-up + capture draw shifts too: reseed after
+            torch.manual_seed(9)
+            for _ in range(3):
+                loss = gs.step("v", 2)
+        res.append((m.materials_a.detach().cpu().numpy().copy(), m.materials_r.detach().cpu().numpy().copy(), float(loss)))
+    # float atomics in the texture backward make the sums order-dependent: compare to float tolerance
+    assert rel_l2(res[1][0], res[0][0]) < 1e-5 and rel_l2(res[1][1], res[0][1]) < 1e-5
+    assert abs(res[1][2] - res[0][2]) < 1e-5 * max(1.0, abs(res[0][2]))

@@ -59,9 +59,9 @@ def lib():
         sig["texir_loss_forward"] = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp]
         sig["texir_scene_set_corner_normals"] = [vp, vp]
         sig["texir_gbuffer_cast"] = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
-        sig["texir_mip_build"] = [vp, i32, i32, i32, i32, vp]
-        sig["texir_tex_fetch_forward"] = [vp, i32, i32, i32, i32, vp, vp, i32, i64, vp, vp]
-        sig["texir_tex_fetch_backward"] = [vp, i32, i32, i32, i32, vp, vp, i32, i64, vp, vp]
+        sig["texir_mip_build"] = [vp, vp, i32, i32, i32, i32, vp]
+        sig["texir_tex_fetch_forward"] = [vp, vp, i32, i32, i32, i32, vp, vp, i32, i64, vp, vp]
+        sig["texir_tex_fetch_backward"] = [vp, vp, i32, i32, i32, i32, vp, vp, i32, i64, vp, vp]
         sig["texir_adam_step"] = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, f32, vp]
         L.texir_irt_launch_count.argtypes = [i32]
         L.texir_irt_launch_count.restype = i32

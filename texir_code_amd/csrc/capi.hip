@@ -207,31 +207,31 @@ static int check_tex(const char* fn, int H, int W, int C, int levels)
     return 0;
 }
 
-int texir_mip_build(float* mips, int32_t H, int32_t W, int32_t C, int32_t levels, void* stream)
+int texir_mip_build(const float* tex, float* mips_rest, int32_t H, int32_t W, int32_t C, int32_t levels, void* stream)
 {
-    if (!mips) return fail(TEXIR_ERR_INVALID, "texir_mip_build: null argument");
+    if (!tex || !mips_rest) return fail(TEXIR_ERR_INVALID, "texir_mip_build: null argument");
     if (int rc = check_tex("texir_mip_build", H, W, C, levels)) return rc;
-    HIP_TRY(launch_mip_build(mips, H, W, C, levels, (hipStream_t)stream));
+    HIP_TRY(launch_mip_build(tex, mips_rest, H, W, C, levels, (hipStream_t)stream));
     return TEXIR_OK;
 }
 
-int texir_tex_fetch_forward(const float* mips, int32_t H, int32_t W, int32_t C, int32_t levels, const float* uv, const float* uv_da,
-                            int32_t filter_mode, int64_t P, float* out, void* stream)
+int texir_tex_fetch_forward(const float* tex, const float* mips_rest, int32_t H, int32_t W, int32_t C, int32_t levels, const float* uv,
+                            const float* uv_da, int32_t filter_mode, int64_t P, float* out, void* stream)
 {
-    if (!mips || !uv || !out || (filter_mode == 1 && !uv_da)) return fail(TEXIR_ERR_INVALID, "texir_tex_fetch_forward: null argument");
+    if (!tex || !uv || !out || (filter_mode == 1 && (!uv_da || (levels > 1 && !mips_rest)))) return fail(TEXIR_ERR_INVALID, "texir_tex_fetch_forward: null argument");
     if (filter_mode < 0 || filter_mode > 1 || P < 0) return fail(TEXIR_ERR_INVALID, "texir_tex_fetch_forward: bad filter_mode/P");
     if (int rc = check_tex("texir_tex_fetch_forward", H, W, C, levels)) return rc;
-    HIP_TRY(launch_tex_fetch(mips, H, W, C, levels, uv, uv_da, filter_mode, P, out, (hipStream_t)stream));
+    HIP_TRY(launch_tex_fetch(tex, mips_rest, H, W, C, levels, uv, uv_da, filter_mode, P, out, (hipStream_t)stream));
     return TEXIR_OK;
 }
 
-int texir_tex_fetch_backward(float* grad_mips, int32_t H, int32_t W, int32_t C, int32_t levels, const float* uv, const float* uv_da,
+int texir_tex_fetch_backward(float* d_tex, float* grad_rest, int32_t H, int32_t W, int32_t C, int32_t levels, const float* uv, const float* uv_da,
                              int32_t filter_mode, int64_t P, const float* d_out, void* stream)
 {
-    if (!grad_mips || !uv || !d_out || (filter_mode == 1 && !uv_da)) return fail(TEXIR_ERR_INVALID, "texir_tex_fetch_backward: null argument");
+    if (!d_tex || !uv || !d_out || (filter_mode == 1 && (!uv_da || (levels > 1 && !grad_rest)))) return fail(TEXIR_ERR_INVALID, "texir_tex_fetch_backward: null argument");
     if (filter_mode < 0 || filter_mode > 1 || P < 0) return fail(TEXIR_ERR_INVALID, "texir_tex_fetch_backward: bad filter_mode/P");
     if (int rc = check_tex("texir_tex_fetch_backward", H, W, C, levels)) return rc;
-    HIP_TRY(launch_tex_fetch_bwd(grad_mips, H, W, C, levels, uv, uv_da, filter_mode, P, d_out, (hipStream_t)stream));
+    HIP_TRY(launch_tex_fetch_bwd(d_tex, grad_rest, H, W, C, levels, uv, uv_da, filter_mode, P, d_out, (hipStream_t)stream));
     return TEXIR_OK;
 }
 

@@ -25,11 +25,11 @@ hipError_t launch_gbuffer(const SceneDev& sc, const float* mvp_host, const float
                           float* uv, float* uvda, int32_t* tri, hipStream_t st);
 int mip_levels(int H, int W, int max_mip_level);
 int64_t mip_total_elems(int H, int W, int C, int levels);
-hipError_t launch_mip_build(float* mips, int H, int W, int C, int levels, hipStream_t st);
-hipError_t launch_tex_fetch(const float* mips, int H, int W, int C, int levels, const float* uv, const float* uvda, int trilinear, int64_t P,
-                            float* out, hipStream_t st);
-hipError_t launch_tex_fetch_bwd(float* grad_mips, int H, int W, int C, int levels, const float* uv, const float* uvda, int trilinear, int64_t P,
-                                const float* d_out, hipStream_t st);
+hipError_t launch_mip_build(const float* tex, float* rest, int H, int W, int C, int levels, hipStream_t st);
+hipError_t launch_tex_fetch(const float* tex, const float* rest, int H, int W, int C, int levels, const float* uv, const float* uvda, int trilinear,
+                            int64_t P, float* out, hipStream_t st);
+hipError_t launch_tex_fetch_bwd(float* d_tex, float* grad_rest, int H, int W, int C, int levels, const float* uv, const float* uvda, int trilinear,
+                                int64_t P, const float* d_out, hipStream_t st);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step,
                        float lo, float hi, hipStream_t st);
 }  // namespace texir

@@ -145,13 +145,15 @@ hipError_t launch_gbuffer(const SceneDev& sc, const float* mvp_host, const float
 // ------------------------------------------------------------------------------------------------------------------
 // mip stack + texture fetch
 // ------------------------------------------------------------------------------------------------------------------
-struct MipDesc { int H, W, C, levels; int64_t off[16]; };     // level l: [H>>l, W>>l, C] at base + off[l]
+// Level 0 IS the caller's texture (no copy); levels 1.. live in a separate "rest" buffer: level l at rest + off[l].
+struct MipDesc { int H, W, C, levels; int64_t off[16]; };
 
 static MipDesc make_desc(int H, int W, int C, int levels)
 {
     MipDesc d; d.H = H; d.W = W; d.C = C; d.levels = levels;
     int64_t o = 0;
-    for (int l = 0; l < 16; l++) { d.off[l] = o; if (l < levels) o += (int64_t)(H >> l) * (W >> l) * C; }
+    d.off[0] = 0;
+    for (int l = 1; l < 16; l++) { d.off[l] = o; if (l < levels) o += (int64_t)(H >> l) * (W >> l) * C; }
     return d;
 }
 
@@ -162,11 +164,12 @@ int mip_levels(int H, int W, int max_mip_level)
     return l;
 }
 
+// elements of levels 1 .. levels-1 (the "rest" buffer); at least 1 so that callers can always allocate
 int64_t mip_total_elems(int H, int W, int C, int levels)
 {
     int64_t o = 0;
-    for (int l = 0; l < levels; l++) o += (int64_t)(H >> l) * (W >> l) * C;
-    return o;
+    for (int l = 1; l < levels; l++) o += (int64_t)(H >> l) * (W >> l) * C;
+    return o > 0 ? o : 1;
 }
 
 __global__ __launch_bounds__(256) void mip_down_kernel(const float* __restrict__ src, float* __restrict__ dst, int Hd, int Wd, int C)
@@ -180,6 +183,24 @@ __global__ __launch_bounds__(256) void mip_down_kernel(const float* __restrict__
     }
 }
 
+// all remaining (small) levels in one single-block launch: level l from level l-1, block barrier in between
+__global__ __launch_bounds__(1024) void mip_down_tail_kernel(float* __restrict__ rest, MipDesc d, int l_begin)
+{
+    for (int l = l_begin; l < d.levels; l++) {
+        const int Hd = d.H >> l, Wd = d.W >> l, C = d.C, Ws = Wd * 2;
+        const float* src = rest + d.off[l - 1];
+        float* dst = rest + d.off[l];
+        const int n = Hd * Wd * C;
+        for (int g = threadIdx.x; g < n; g += 1024) {
+            int ch = g % C, t = g / C, x = t % Wd, y = t / Wd;
+            const float* s = src + ((2 * y) * Ws + 2 * x) * C + ch;
+            dst[g] = 0.25f * (s[0] + s[C] + s[Ws * C] + s[Ws * C + C]);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 // fold: grad[l-1][2y+a][2x+b] += 0.25 * grad[l][y][x]
 __global__ __launch_bounds__(256) void mip_fold_kernel(float* __restrict__ fine, const float* __restrict__ coarse, int Hf, int Wf, int C)
 {
@@ -187,6 +208,22 @@ __global__ __launch_bounds__(256) void mip_fold_kernel(float* __restrict__ fine,
     for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < n; g += (int64_t)gridDim.x * 256) {
         int ch = (int)(g % C); int64_t t = g / C; int x = (int)(t % Wf), y = (int)(t / Wf);
         fine[g] += 0.25f * coarse[((int64_t)(y >> 1) * (Wf >> 1) + (x >> 1)) * C + ch];
+    }
+}
+
+__global__ __launch_bounds__(1024) void mip_fold_tail_kernel(float* __restrict__ rest, MipDesc d, int l_end /* fold levels-1 .. l_end+1 into l_end */)
+{
+    for (int l = d.levels - 1; l > l_end; l--) {
+        const int Hf = d.H >> (l - 1), Wf = d.W >> (l - 1), C = d.C;
+        float* fine = rest + d.off[l - 1];
+        const float* coarse = rest + d.off[l];
+        const int n = Hf * Wf * C;
+        for (int g = threadIdx.x; g < n; g += 1024) {
+            int ch = g % C, t = g / C, x = t % Wf, y = t / Wf;
+            fine[g] += 0.25f * coarse[((y >> 1) * (Wf >> 1) + (x >> 1)) * C + ch];
+        }
+        __threadfence_block();
+        __syncthreads();
     }
 }
 
@@ -220,7 +257,7 @@ __device__ __forceinline__ Tap bilinear_wrap(float u, float v, int W, int H)
 }
 
 template <bool BWD>
-__global__ __launch_bounds__(256) void tex_fetch_kernel(float* __restrict__ mips, MipDesc d, const float* __restrict__ uv,
+__global__ __launch_bounds__(256) void tex_fetch_kernel(float* __restrict__ lvl0, float* __restrict__ rest, MipDesc d, const float* __restrict__ uv,
                                                         const float* __restrict__ uvda, int trilinear, int64_t P, float* __restrict__ io)
 {
     const int C = d.C;
@@ -238,7 +275,7 @@ __global__ __launch_bounds__(256) void tex_fetch_kernel(float* __restrict__ mips
             const float wl = pass ? f : 1.f - f;
             if (wl == 0.f) continue;
             Tap t = bilinear_wrap(u, v, d.W >> l, d.H >> l);
-            float* base = mips + d.off[l];
+            float* base = l == 0 ? lvl0 : rest + d.off[l];
             for (int ch = 0; ch < C; ch++) {
                 if (BWD) {
                     float g = io[(int64_t)C * p + ch] * wl;
@@ -257,38 +294,59 @@ __global__ __launch_bounds__(256) void tex_fetch_kernel(float* __restrict__ mips
 
 static int grid1d(int64_t n, int bs) { int64_t nb = (n + bs - 1) / bs; return (int)(nb > 4096 ? 4096 : (nb < 1 ? 1 : nb)); }
 
-// mips[0 : H*W*C] already holds level 0 (the caller copies / aliases the parameter there); builds levels 1..levels-1
-hipError_t launch_mip_build(float* mips, int H, int W, int C, int levels, hipStream_t st)
+constexpr int kTailElems = 64 * 64 * 4;     // levels with at most this many elements are handled by the single-block tail kernels
+
+static int tail_begin(const MipDesc& d)
 {
+    int l = 1;
+    while (l < d.levels && (int64_t)(d.H >> l) * (d.W >> l) * d.C > kTailElems) l++;
+    return l;        // first level produced by the tail kernel (>= 1)
+}
+
+// builds levels 1..levels-1 into `rest` from the caller's level-0 texture
+hipError_t launch_mip_build(const float* tex, float* rest, int H, int W, int C, int levels, hipStream_t st)
+{
+    if (levels <= 1) return hipSuccess;
     MipDesc d = make_desc(H, W, C, levels);
-    for (int l = 1; l < levels; l++) {
+    int lt = tail_begin(d);
+    if (lt < 2) lt = 2;                       // level 1 always comes from the separate level-0 pointer
+    for (int l = 1; l < lt && l < levels; l++) {
         int Hd = H >> l, Wd = W >> l;
-        hipLaunchKernelGGL(mip_down_kernel, dim3(grid1d((int64_t)Hd * Wd * C, 256)), dim3(256), 0, st, mips + d.off[l - 1], mips + d.off[l], Hd, Wd, C);
+        const float* src = l == 1 ? tex : rest + d.off[l - 1];
+        hipLaunchKernelGGL(mip_down_kernel, dim3(grid1d((int64_t)Hd * Wd * C, 256)), dim3(256), 0, st, src, rest + d.off[l], Hd, Wd, C);
     }
+    if (lt < levels) hipLaunchKernelGGL(mip_down_tail_kernel, dim3(1), dim3(1024), 0, st, rest, d, lt);
     return hipGetLastError();
 }
 
-hipError_t launch_tex_fetch(const float* mips, int H, int W, int C, int levels, const float* uv, const float* uvda, int trilinear, int64_t P,
-                            float* out, hipStream_t st)
+hipError_t launch_tex_fetch(const float* tex, const float* rest, int H, int W, int C, int levels, const float* uv, const float* uvda, int trilinear,
+                            int64_t P, float* out, hipStream_t st)
 {
     if (P <= 0) return hipSuccess;
     MipDesc d = make_desc(H, W, C, levels);
-    hipLaunchKernelGGL(tex_fetch_kernel<false>, dim3(grid1d(P, 256)), dim3(256), 0, st, const_cast<float*>(mips), d, uv, uvda, trilinear, P, out);
+    hipLaunchKernelGGL(tex_fetch_kernel<false>, dim3(grid1d(P, 256)), dim3(256), 0, st, const_cast<float*>(tex), const_cast<float*>(rest), d, uv, uvda,
+                       trilinear, P, out);
     return hipGetLastError();
 }
 
-// grad_mips must be zero-initialised [mip_total_elems]; after the scatter the stack is folded into level 0 (= d tex)
-hipError_t launch_tex_fetch_bwd(float* grad_mips, int H, int W, int C, int levels, const float* uv, const float* uvda, int trilinear, int64_t P,
-                                const float* d_out, hipStream_t st)
+// d_tex [H,W,C] and grad_rest [mip_total_elems] must be zero on entry; on return d_tex holds d loss / d texture
+hipError_t launch_tex_fetch_bwd(float* d_tex, float* grad_rest, int H, int W, int C, int levels, const float* uv, const float* uvda, int trilinear,
+                                int64_t P, const float* d_out, hipStream_t st)
 {
     MipDesc d = make_desc(H, W, C, levels);
     if (P > 0)
-        hipLaunchKernelGGL(tex_fetch_kernel<true>, dim3(grid1d(P, 256)), dim3(256), 0, st, grad_mips, d, uv, uvda, trilinear, P, const_cast<float*>(d_out));
-    if (trilinear)
-        for (int l = levels - 1; l >= 1; l--) {
+        hipLaunchKernelGGL(tex_fetch_kernel<true>, dim3(grid1d(P, 256)), dim3(256), 0, st, d_tex, grad_rest, d, uv, uvda, trilinear, P, const_cast<float*>(d_out));
+    if (trilinear && levels > 1) {
+        int lt = tail_begin(d);
+        if (lt < 2) lt = 2;
+        // small levels: levels-1 .. lt folded down to level lt-1 inside one block
+        if (lt < levels) hipLaunchKernelGGL(mip_fold_tail_kernel, dim3(1), dim3(1024), 0, st, grad_rest, d, lt - 1);
+        for (int l = (lt < levels ? lt : levels) - 1; l >= 1; l--) {
             int Hf = H >> (l - 1), Wf = W >> (l - 1);
-            hipLaunchKernelGGL(mip_fold_kernel, dim3(grid1d((int64_t)Hf * Wf * C, 256)), dim3(256), 0, st, grad_mips + d.off[l - 1], grad_mips + d.off[l], Hf, Wf, C);
+            float* fine = l == 1 ? d_tex : grad_rest + d.off[l - 1];
+            hipLaunchKernelGGL(mip_fold_kernel, dim3(grid1d((int64_t)Hf * Wf * C, 256)), dim3(256), 0, st, fine, grad_rest + d.off[l], Hf, Wf, C);
         }
+    }
     return hipGetLastError();
 }
 

@@ -76,8 +76,11 @@ class RenderLoss(nn.Module):
     """models.loss.RenderLoss(loss_type='L1', w_gradient=0).forward(gt_img, preds, gt_mask, floor_max_mask, seg_mask,
     stage, room_seg_mask) -> (loss, seg_loss_item[, 0])  (loss.py:56,81-115)."""
 
-    def __init__(self, loss_type="L1", w_gradient=0):
+    def __init__(self, loss_type="L1", w_gradient=0, lazy_item=False):
+        """lazy_item=True returns the seg term as a 0-dim device tensor instead of calling .item() (the reference's
+        `seg_loss.item()` forces a host sync every step, which also forbids hipGraph capture of the step)"""
         super().__init__()
+        self.lazy_item = lazy_item
         if loss_type not in _LOSS_TYPES:
             # psnr / ssim / msssim variants (loss.py:67-75) are evaluation-side options, outside the hot path
             raise NotImplementedError("RenderLoss loss_type %r is out of scope; use 'L1' or 'L2'" % (loss_type,))
@@ -108,7 +111,7 @@ class RenderLoss(nn.Module):
         out = _LossFn.apply(rgb, preds["albedo"] if stage == 0 else None, preds["roughness"] if stage != 0 else None,
                             preds["roughness_womipmap"] if stage == 1 else None, gt_img, preds["empty_mask"], gt_mask if stage == 0 else None,
                             seg_id, hl, room_id if stage == 2 else None, stage, _LOSS_TYPES[self.loss_type], C, R if stage == 2 else 0, hw)
-        loss, seg_item = out[0], out[1].item()
+        loss, seg_item = out[0], (out[1].detach() if self.lazy_item else out[1].item())
         if stage == 0:
             return loss, seg_item
         return loss, seg_item, (0. if stage == 1 else 0)

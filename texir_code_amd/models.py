@@ -254,7 +254,11 @@ class MaterialModel(nn.Module):
         S = int(self.sample_l[1])
         if self.sample_type[1] != "importance":
             raise NotImplementedError("specular sample_type %r: the reference path uses 'importance'" % (self.sample_type[1],))
-        shift = torch.rand(P, 1, 2).reshape(P, 2).to(self.device)               # sample_util.py:102 (CPU generator)
+        static = getattr(self, "_static_shift", None)
+        if static is not None:
+            shift = static                      # hipGraph replay: the caller refreshes this buffer from the CPU generator each step
+        else:
+            shift = torch.rand(P, 1, 2).reshape(P, 2).to(self.device)           # sample_util.py:102 (CPU generator)
         rgb = spec_render(self.scene, normal.reshape(P, 3), albedo.reshape(P, 3), roughness.reshape(P), points.reshape(P, 3),
                           irr.reshape(P, 3), cam_position, shift, S)
         return {"rgb": rgb.reshape(face, h, w, 3), "albedo": albedo.reshape(face, h, w, 3), "normal": normal.reshape(face, h, w, 3).detach(),
