@@ -45,7 +45,7 @@ struct alignas(16) GpuNode4 {
 static_assert(sizeof(GpuNode4) == 64, "wide node must be 64 bytes");
 
 constexpr int32_t kEmptyChild = INT32_MIN;   // child slot with an inverted box, never entered
-constexpr int kMaxLeaf = 4;
+constexpr int kMaxLeaf = 2;
 constexpr int kTopLevels = 4;             // 1 + 4 + 16 + 64 = at most 85 wide nodes (5440 B) cached in LDS per workgroup
 constexpr int kTopMax = 85;
 constexpr int kMaxDepth = 60;                // traversal stack bound (LDS part + private overflow)

@@ -192,14 +192,19 @@ __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float
                             sz = __uint_as_float(((ex >> 16) & 255u) << 23) * idz;
                 const float bx = q0.x * idx - oodx, by = q0.y * idy - oody, bz = q0.z * idz - oodz;
                 float key[4]; int code[4] = {ch.x, ch.y, ch.z, ch.w};
+                // the ray's direction signs decide once per node (for all four children at a time: the bytes stay packed) which of
+                // the lo/hi planes is the entry and which the exit plane -- no per-child min/max of the two slab distances
+                const uint32_t nx_ = idx < 0.f ? q1.w : q1.x, fx_ = idx < 0.f ? q1.x : q1.w;
+                const uint32_t ny_ = idy < 0.f ? q2.x : q1.y, fy_ = idy < 0.f ? q1.y : q2.x;
+                const uint32_t nz_ = idz < 0.f ? q2.y : q1.z, fz_ = idz < 0.f ? q1.z : q2.y;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int sh = 8 * k;
-                    float lx = (float)((q1.x >> sh) & 255u) * sx + bx, hx = (float)((q1.w >> sh) & 255u) * sx + bx;
-                    float ly = (float)((q1.y >> sh) & 255u) * sy + by, hy = (float)((q2.x >> sh) & 255u) * sy + by;
-                    float lz = (float)((q1.z >> sh) & 255u) * sz + bz, hz = (float)((q2.y >> sh) & 255u) * sz + bz;
-                    float tn = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fmaxf(fminf(lz, hz), 0.f));
-                    float tf = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fminf(fmaxf(lz, hz), h.t));
+                    float nxt = (float)((nx_ >> sh) & 255u) * sx + bx, fxt = (float)((fx_ >> sh) & 255u) * sx + bx;
+                    float nyt = (float)((ny_ >> sh) & 255u) * sy + by, fyt = (float)((fy_ >> sh) & 255u) * sy + by;
+                    float nzt = (float)((nz_ >> sh) & 255u) * sz + bz, fzt = (float)((fz_ >> sh) & 255u) * sz + bz;
+                    float tn = fmaxf(fmaxf(nxt, nyt), fmaxf(nzt, 0.f));
+                    float tf = fminf(fminf(fxt, fyt), fminf(fzt, h.t));
                     // unused slots carry an inverted box (lo = 255, hi = 0): but a negative direction swaps lo/hi, so test the code too
                     key[k] = (tn <= tf && code[k] != kEmptyChild) ? tn : __builtin_inff();
                 }
@@ -208,10 +213,20 @@ __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float
                 TEXIR_CSWAP(0, 1) TEXIR_CSWAP(2, 3) TEXIR_CSWAP(0, 2) TEXIR_CSWAP(1, 3) TEXIR_CSWAP(1, 2)
 #undef TEXIR_CSWAP
                 const float inf = __builtin_inff();
-                if (key[3] < inf) push(code[3]);
-                if (key[2] < inf) push(code[2]);
-                if (key[1] < inf) push(code[1]);
-                node = key[0] < inf ? code[0] : pop();
+                if (!__any(sp + 3 > LSTK)) {
+                    // common case (one wave-uniform test per node): the whole update stays inside the LDS part of the stack
+                    if (key[3] < inf) { lds_stack[sp * kBlock] = code[3]; sp++; }
+                    if (key[2] < inf) { lds_stack[sp * kBlock] = code[2]; sp++; }
+                    if (key[1] < inf) { lds_stack[sp * kBlock] = code[1]; sp++; }
+                    if (key[0] < inf) node = code[0];
+                    else if (sp > 0) { sp--; node = lds_stack[sp * kBlock]; }
+                    else node = kSentinel;
+                } else {
+                    if (key[3] < inf) push(code[3]);
+                    if (key[2] < inf) push(code[2]);
+                    if (key[1] < inf) push(code[1]);
+                    node = key[0] < inf ? code[0] : pop();
+                }
             }
         } else {
         while (node >= 0 && node != kSentinel) {
@@ -323,24 +338,39 @@ __device__ __forceinline__ void trace_resume(const SceneDev& sc, RayState& r, in
                             sz = __uint_as_float(((ex >> 16) & 255u) << 23) * idz;
                 const float bx = q0.x * idx - oodx, by = q0.y * idy - oody, bz = q0.z * idz - oodz;
                 float key[4]; int code[4] = {ch.x, ch.y, ch.z, ch.w};
+                // the ray's direction signs decide once per node (for all four children at a time: the bytes stay packed) which of
+                // the lo/hi planes is the entry and which the exit plane -- no per-child min/max of the two slab distances
+                const uint32_t nx_ = idx < 0.f ? q1.w : q1.x, fx_ = idx < 0.f ? q1.x : q1.w;
+                const uint32_t ny_ = idy < 0.f ? q2.x : q1.y, fy_ = idy < 0.f ? q1.y : q2.x;
+                const uint32_t nz_ = idz < 0.f ? q2.y : q1.z, fz_ = idz < 0.f ? q1.z : q2.y;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int sh = 8 * k;
-                    float lx = (float)((q1.x >> sh) & 255u) * sx + bx, hx = (float)((q1.w >> sh) & 255u) * sx + bx;
-                    float ly = (float)((q1.y >> sh) & 255u) * sy + by, hy = (float)((q2.x >> sh) & 255u) * sy + by;
-                    float lz = (float)((q1.z >> sh) & 255u) * sz + bz, hz = (float)((q2.y >> sh) & 255u) * sz + bz;
-                    float tn = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fmaxf(fminf(lz, hz), 0.f));
-                    float tf = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fminf(fmaxf(lz, hz), h.t));
+                    float nxt = (float)((nx_ >> sh) & 255u) * sx + bx, fxt = (float)((fx_ >> sh) & 255u) * sx + bx;
+                    float nyt = (float)((ny_ >> sh) & 255u) * sy + by, fyt = (float)((fy_ >> sh) & 255u) * sy + by;
+                    float nzt = (float)((nz_ >> sh) & 255u) * sz + bz, fzt = (float)((fz_ >> sh) & 255u) * sz + bz;
+                    float tn = fmaxf(fmaxf(nxt, nyt), fmaxf(nzt, 0.f));
+                    float tf = fminf(fminf(fxt, fyt), fminf(fzt, h.t));
                     key[k] = (tn <= tf && code[k] != kEmptyChild) ? tn : __builtin_inff();
                 }
 #define TEXIR_CSWAP(a, b) { bool s_ = key[b] < key[a]; float ka = s_ ? key[b] : key[a], kb = s_ ? key[a] : key[b]; int ca = s_ ? code[b] : code[a], cb = s_ ? code[a] : code[b]; key[a] = ka; key[b] = kb; code[a] = ca; code[b] = cb; }
                 TEXIR_CSWAP(0, 1) TEXIR_CSWAP(2, 3) TEXIR_CSWAP(0, 2) TEXIR_CSWAP(1, 3) TEXIR_CSWAP(1, 2)
 #undef TEXIR_CSWAP
                 const float inf = __builtin_inff();
-                if (key[3] < inf) push(code[3]);
-                if (key[2] < inf) push(code[2]);
-                if (key[1] < inf) push(code[1]);
-                node = key[0] < inf ? code[0] : pop();
+                if (!__any(sp + 3 > LSTK)) {
+                    // common case (one wave-uniform test per node): the whole update stays inside the LDS part of the stack
+                    if (key[3] < inf) { lds_stack[sp * kBlock] = code[3]; sp++; }
+                    if (key[2] < inf) { lds_stack[sp * kBlock] = code[2]; sp++; }
+                    if (key[1] < inf) { lds_stack[sp * kBlock] = code[1]; sp++; }
+                    if (key[0] < inf) node = code[0];
+                    else if (sp > 0) { sp--; node = lds_stack[sp * kBlock]; }
+                    else node = kSentinel;
+                } else {
+                    if (key[3] < inf) push(code[3]);
+                    if (key[2] < inf) push(code[2]);
+                    if (key[1] < inf) push(code[1]);
+                    node = key[0] < inf ? code[0] : pop();
+                }
             }
         } else {
             while (node >= 0 && node != kSentinel) {
