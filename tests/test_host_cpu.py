@@ -160,3 +160,17 @@ def test_build_masks_matches_reference_golden(golden):
     assert np.array_equal(seg.numpy(), g["seg_mask"])
     assert np.array_equal(fm.numpy(), g["floor_max_mask"])
     assert np.array_equal(room.numpy(), g["room_seg_mask"])
+
+
+def test_padding_texture_fills_zero_texels_from_nearest():
+    from texir_code_amd.tools import padding_texture
+    img = np.zeros((16, 16, 3), np.float32)
+    img[4:8, 4:8] = [1.0, 2.0, 3.0]
+    img[10:12, 12:14] = [5.0, 5.0, 5.0]
+    out = padding_texture(img)
+    assert np.array_equal(out[4:8, 4:8], img[4:8, 4:8]) and np.array_equal(out[10:12, 12:14], img[10:12, 12:14])
+    assert (out.sum(-1) > 0).all()
+    assert np.allclose(out[0, 0], [1.0, 2.0, 3.0]) and np.allclose(out[15, 15], [5.0, 5.0, 5.0])
+    # only the two source colours ever appear
+    cols = {tuple(c) for c in out.reshape(-1, 3).round(3).tolist()}
+    assert cols == {(1.0, 2.0, 3.0), (5.0, 5.0, 5.0)}
