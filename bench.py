@@ -146,12 +146,14 @@ def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5):
             model._static_shift = None
     graphs = gs is not None
     times = []
+    nxt = gs.draw_shift() if gs is not None else None
     for it in range(warmup + steps):
         v = (it * world + rank) % len(views)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if gs is not None:
-            gs.step(v, 2, all_reduce=dist.all_reduce if world > 1 else None)
+            gs.step(v, 2, all_reduce=dist.all_reduce if world > 1 else None, shift=nxt)
+            nxt = gs.draw_shift()           # next step's CPU-generator draw overlaps this step's GPU work (same stream order)
         else:
             eager_step(v)
         torch.cuda.synchronize()

@@ -246,3 +246,34 @@ def test_graphed_material_step_equals_eager(golden):
     # float atomics in the texture backward make the sums order-dependent: compare to float tolerance
     assert rel_l2(res[1][0], res[0][0]) < 1e-5 and rel_l2(res[1][1], res[0][1]) < 1e-5
     assert abs(res[1][2] - res[0][2]) < 1e-5 * max(1.0, abs(res[0][2]))
+
+
+def test_runner_with_hipgraph_matches_eager_runner(tmp_path):
+    """train.hipgraph = true must give the same optimisation trajectory as the default eager runner"""
+    from texir_code_amd import conf as C, datasets as D
+    from texir_code_amd.trainer import exp_runner as ER
+    from texir_code_amd.trainer.train_material import MatTrainRunner
+    root = str(tmp_path / "ds")
+    sc = D.write_synthetic_dataset(root, T=2000, texel_res=64, tex_res=64, n_side=1)
+    mesh_dir = os.path.join(root, "vrproc", "hdr_texture")
+    conf_irt = str(tmp_path / "irt.conf")
+    D.write_conf(conf_irt, root, cube_res=16, spp=(64, 16), model="irt")
+    ER.main(["--conf", conf_irt, "--trainstage", "IrrT", "--gpu", "0"])
+    shutil.copy(os.path.join(mesh_dir, "0_irr_texture.hdr"), os.path.join(mesh_dir, "irt.hdr"))
+    conf_mat = str(tmp_path / "mat.conf")
+    D.write_conf(conf_mat, root, cube_res=16, spp=(64, 16), albedo_res=64, rough_res=64, epochs=1, model="mat")
+    D.render_gt_views(root, C.parse_file(conf_mat), sc, 64, 64)
+    logs, finals = [], []
+    for graph in (False, True):
+        txt = open(conf_mat).read().replace("batch_size = 1", "batch_size = 1\n    hipgraph = %s" % ("true" if graph else "false"))
+        p = str(tmp_path / ("mat_%d.conf" % graph))
+        open(p, "w").write(txt)
+        r = MatTrainRunner(conf=p, exps_folder_name=str(tmp_path / "exps"), expname="g", frame_skip=1, max_niters=10, is_continue=False,
+                           timestamp="latest", checkpoint="latest", gpu_index=0, dry_dirs=True)
+        assert r.use_graph == graph
+        r.run()
+        logs.append(np.array(r.log))
+        finals.append((r.model.materials_a.detach().cpu().numpy(), r.model.materials_r.detach().cpu().numpy()))
+    assert logs[0].shape == logs[1].shape == (6, 5)
+    assert np.allclose(logs[0][:, 3], logs[1][:, 3], rtol=1e-4, atol=1e-6)
+    assert rel_l2(finals[1][0], finals[0][0]) < 1e-4 and rel_l2(finals[1][1], finals[0][1]) < 1e-4

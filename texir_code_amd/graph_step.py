@@ -8,18 +8,26 @@ import torch
 class GraphedMatStep:
     def __init__(self, model, loss_fn, optimizer, params):
         self.model, self.loss_fn, self.opt, self.params = model, loss_fn, optimizer, list(params)
-        self.graphs, self.losses, self.pool = {}, {}, None
+        self.graphs, self.losses, self.outs, self.pool = {}, {}, {}, None
         self.side = torch.cuda.Stream()
+        import os
+        self.grads_to_none = os.environ.get("TEXIR_GRAPH_GRADS_TO_NONE", "1") == "1"
+        if not self.grads_to_none:
+            for p in self.params:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
         self.static_shift = None
-        for p in self.params:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
 
     def _fwd_bwd(self, inp, stage):
         mvp, cam, gt, gmask, seg, fm, room, key = inp
         preds = self.model(mvp, key, cam, stage)
-        loss = self.loss_fn(gt, preds, gmask, fm, seg, stage=stage, room_seg_mask=room)[0]
-        self.opt.zero_grad(set_to_none=False)
+        out = self.loss_fn(gt, preds, gmask, fm, seg, stage=stage, room_seg_mask=room)
+        loss = out[0]
+        # only detached views are kept: an autograd graph rooted in capture-time tensors must not outlive the capture
+        self._last_out = (out[0].detach(),) + tuple(o.detach() if torch.is_tensor(o) else o for o in out[1:])
+        # grads are re-created by the backward itself (autograd assigns instead of accumulating): inside the captured graph their
+        # addresses are static, and the zero-fill + accumulate passes over the full textures disappear
+        self.opt.zero_grad(set_to_none=self.grads_to_none)
         loss.backward()
         return loss
 
@@ -30,25 +38,47 @@ class GraphedMatStep:
             self.static_shift = torch.zeros((P, 2), device=gt.device)
         inp = (mvp, cam, gt, gmask, seg, fm, room, key)
         self.model._static_shift = None
+        rng_state = torch.get_rng_state()               # warm-up must not consume the CPU-generator stream of the training run
         self._fwd_bwd(inp, stage)                       # eager warm-up: G-buffer cache, mask compaction, mip-stack buffers
+        torch.set_rng_state(rng_state)
         self.model._static_shift = self.static_shift
+        import gc
+        from .scene import defer_destroy
+        gc.collect()                                    # finalisers (hipFree of dead scenes/tensors) must not run inside the capture
+        gc_was = gc.isenabled()
+        gc.disable()
         try:
-            self.side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.side):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.pool, stream=self.side):
-                    loss = self._fwd_bwd(inp, stage)
-            torch.cuda.current_stream().wait_stream(self.side)
+            with defer_destroy():
+                self.side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.side):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=self.pool, stream=self.side):
+                        loss = self._fwd_bwd(inp, stage)
+                torch.cuda.current_stream().wait_stream(self.side)
         finally:
             self.model._static_shift = None
+            if gc_was:
+                gc.enable()
         self.pool = g.pool()
         self.graphs[(key, stage)] = g
-        self.losses[(key, stage)] = loss
+        self.losses[(key, stage)] = loss.detach()      # keep no autograd graph of the captured region alive
+        self.outs[(key, stage)] = self._last_out
 
-    def step(self, key, stage, all_reduce=None):
-        """one optimiser step on a captured view; returns the (static) loss tensor of that graph"""
+    def draw_shift(self):
+        """the step's GGX shifts from the CPU generator, exactly the reference's draw (sample_util.py:102).  Callers may draw the
+        NEXT step's shifts right after launching a step so that the host RNG overlaps the GPU work (same stream order)."""
         P = self.static_shift.shape[0]
-        self.static_shift.copy_(torch.rand(P, 1, 2).reshape(P, 2), non_blocking=True)
+        return torch.rand(P, 1, 2).reshape(P, 2)
+
+    def step(self, key, stage, all_reduce=None, shift=None):
+        """one optimiser step on a captured view; returns the (static) loss tensor of that graph"""
+        if stage != 0:                                  # stage 0 is Lambertian only: the reference draws no shifts there
+            if shift is None:
+                shift = self.draw_shift()
+            if getattr(self, "_pinned", None) is None:
+                self._pinned = torch.empty(tuple(self.static_shift.shape), dtype=torch.float32).pin_memory()
+            self._pinned.copy_(shift)
+            self.static_shift.copy_(self._pinned, non_blocking=True)
         self.graphs[(key, stage)].replay()
         if all_reduce is not None:
             for p in self.params:

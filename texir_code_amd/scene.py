@@ -9,6 +9,24 @@ from . import _lib
 
 MODES = {"uniform": 0, "cosine": 1, "importance": 2}
 
+# hipFree is not allowed while a stream capture (hipGraph) is in progress, and a Scene may be garbage-collected at any time:
+# destruction is deferred while this counter is non-zero (see defer_destroy()).
+_DEFER = [0]
+_PENDING = []
+
+
+class defer_destroy:
+    """context manager: scene handles released inside are destroyed on exit (used around hipGraph capture)"""
+
+    def __enter__(self):
+        _DEFER[0] += 1
+
+    def __exit__(self, *a):
+        _DEFER[0] -= 1
+        if _DEFER[0] == 0 and _lib._LIB is not None:
+            while _PENDING:
+                _lib._LIB.texir_scene_destroy(_PENDING.pop())
+
 
 def _dev_f32(t, device):
     if not torch.is_tensor(t):
@@ -43,7 +61,10 @@ class Scene:
         h = getattr(self, "h", None)
         if h and _lib._LIB is not None:
             try:
-                _lib._LIB.texir_scene_destroy(h)
+                if _DEFER[0] > 0:
+                    _PENDING.append(h)
+                else:
+                    _lib._LIB.texir_scene_destroy(h)
             except Exception:
                 pass
             self.h = None

@@ -2,45 +2,50 @@
 ('linear-mipmap-linear') fetch with wrap boundary, differentiable wrt the texture.  Semantics restated from
 nvdiffrast's public documentation (parity unpinned: nvdiffrast is not installable here).
 
-Level 0 of the mip stack is the texture tensor itself; levels 1.. are built into a side buffer.  The side buffer is cached
-per (storage, version): a frozen texture (the irradiance texture) builds its stack once, and several fetches of the same
+Level 0 of the mip stack is the texture tensor itself; levels 1.. are built into a side buffer cached on the texture tensor
+(keyed by its version): a frozen texture (the irradiance texture) builds its stack once, and several fetches of the same
 parameter inside one step share one build."""
 import torch
 
 from . import _lib
 
 FILTER = {"linear": 0, "linear-mipmap-linear": 1}
-_MIP_CACHE = {}
 
 
-def _mips_for(tex, levels):
-    """levels 1.. of `tex` (a contiguous [H,W,C] float32 CUDA tensor), cached on (data_ptr, version, shape)"""
-    H, W, C = tex.shape
-    key = (tex.data_ptr(), tex._version, H, W, C, levels, tex.device.index)
-    hit = _MIP_CACHE.get(tex.data_ptr())
-    if hit is not None and hit[0] == key:
-        return hit[1]
+def _mips_for(owner, t0, levels):
+    """levels 1.. of the contiguous [H,W,C] float32 tensor `t0`.  The side buffer is cached ON the owning tensor object (a
+    Parameter lives as long as its model), keyed by the tensor's version: no global state, nothing outlives its owner, and a
+    texture updated by the optimiser rebuilds its stack into the SAME buffer (static address => safe under hipGraph replay)."""
+    H, W, C = t0.shape
     L = _lib.lib()
     n = int(L.texir_mip_elems(H, W, C, levels))
-    rest = hit[1] if (hit is not None and hit[1].numel() == n and hit[1].device == tex.device) else torch.empty(n, device=tex.device, dtype=torch.float32)
-    _lib.check(L.texir_mip_build(_lib.ptr(tex), _lib.ptr(rest), H, W, C, levels, _lib.stream_ptr()))
-    if len(_MIP_CACHE) > 64:
-        _MIP_CACHE.clear()
-    _MIP_CACHE[tex.data_ptr()] = (key, rest)
+    key = (t0.data_ptr(), t0._version, H, W, C, levels)
+    hit = getattr(owner, "_texir_mips", None)
+    # a frozen texture keeps its stack; a trainable one is rebuilt on every use (it changes every optimiser step, and under
+    # hipGraph capture the build kernels must be part of the captured sequence)
+    if hit is not None and hit[0] == key and not owner.requires_grad:
+        return hit[1]
+    if hit is not None and hit[1].numel() == n and hit[1].device == t0.device:
+        rest = hit[1]
+    else:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.TexirError("mip stack must be allocated before hipGraph capture (run one eager step first)")
+        rest = torch.empty(n, device=t0.device, dtype=torch.float32)
+    _lib.check(L.texir_mip_build(_lib.ptr(t0), _lib.ptr(rest), H, W, C, levels, _lib.stream_ptr()))
+    try:
+        owner._texir_mips = (key, rest)
+    except AttributeError:
+        pass
     return rest
 
 
 class _TexFetch(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, tex, uv, uv_da, mode, max_mip_level):
+    def forward(ctx, tex, rest, uv, uv_da, mode, levels):
         L = _lib.lib()
         H, W, C = tex.shape
         P = uv.shape[0]
         t0 = tex.detach()
-        if not t0.is_contiguous():
-            t0 = t0.contiguous()
-        levels = int(L.texir_mip_levels(H, W, max_mip_level)) if mode == 1 else 1
-        rest = _mips_for(t0, levels) if levels > 1 else None
         out = torch.empty((P, C), device=tex.device, dtype=torch.float32)
         _lib.check(L.texir_tex_fetch_forward(_lib.ptr(t0), _lib.ptr(rest), H, W, C, levels, _lib.ptr(uv), _lib.ptr(uv_da), mode, P, _lib.ptr(out),
                                              _lib.stream_ptr()))
@@ -53,14 +58,14 @@ class _TexFetch(torch.autograd.Function):
         uv, uv_da = ctx.saved_tensors
         H, W, C, levels, mode = ctx.meta
         if not ctx.needs_input_grad[0]:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         L = _lib.lib()
         d_tex = torch.zeros((H, W, C), device=d_out.device, dtype=torch.float32)
         g_rest = torch.zeros(int(L.texir_mip_elems(H, W, C, levels)), device=d_out.device, dtype=torch.float32) if levels > 1 else None
         d_out = d_out.contiguous()
         _lib.check(L.texir_tex_fetch_backward(_lib.ptr(d_tex), _lib.ptr(g_rest), H, W, C, levels, _lib.ptr(uv), _lib.ptr(uv_da), mode, uv.shape[0],
                                               _lib.ptr(d_out), _lib.stream_ptr()))
-        return d_tex, None, None, None, None
+        return d_tex, None, None, None, None, None
 
 
 def texture(tex, uv, uv_da=None, filter_mode="linear", max_mip_level=13):
@@ -73,5 +78,11 @@ def texture(tex, uv, uv_da=None, filter_mode="linear", max_mip_level=13):
     mode = FILTER[filter_mode]
     if mode == 1 and daf is None:
         raise ValueError("linear-mipmap-linear needs uv_da")
-    out = _TexFetch.apply(tex if tex.dtype == torch.float32 else tex.to(torch.float32), uvf, daf, mode, int(max_mip_level))
-    return out.reshape(*lead, tex.shape[-1])
+    owner = tex
+    if tex.dtype != torch.float32 or not tex.is_contiguous():
+        tex = tex.to(torch.float32).contiguous()
+    H, W, C = tex.shape
+    levels = int(_lib.lib().texir_mip_levels(H, W, int(max_mip_level))) if mode == 1 else 1
+    rest = _mips_for(owner, tex.detach(), levels) if levels > 1 else None
+    out = _TexFetch.apply(tex, rest, uvf, daf, mode, levels)
+    return out.reshape(*lead, C)

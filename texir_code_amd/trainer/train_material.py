@@ -84,6 +84,7 @@ class MatTrainRunner:
         self.start_epoch = 0
         self.n_batches = len(self.train_dataloader)
         self.plot_freq = self.conf.get_int("train.plot_freq")
+        self.use_graph = self.conf.get_bool("train.hipgraph", default=False)      # new optional key; default = eager, reference call order
         self.pano_res = self.conf.get_list("train.pano_img_res")
         self.cube_lenth = int(self.pano_res[1] / 4)
         self.first_val = True
@@ -93,6 +94,31 @@ class MatTrainRunner:
         (self.room_meta_scale, self.room_meta_w, self.room_meta_h, self.room_meta_xmin, self.room_meta_zmin, self.room_img) = parse_roomseg(rs)
         self.cur_iter = 0
         self.log = []
+
+    def _graph_step(self, gt_item, stage):
+        """train.hipgraph = true: forward + loss + backward of a (view, stage) pair replayed as one hipGraph (graph_step.py)"""
+        from ..graph_step import GraphedMatStep
+        vid = gt_item["id"]
+        vid0 = vid[0] if isinstance(vid, (list, tuple)) else vid
+        if getattr(self, "_gs", None) is None or self._gs.opt is not self.mat_optimizer:
+            self.mat_loss.lazy_item = True
+            self._gs = GraphedMatStep(self.model, self.mat_loss, self.mat_optimizer, [self.model.materials_a, self.model.materials_r])
+            self._gs_inputs = getattr(self, "_gs_inputs", {})
+        if (vid0, stage) not in self._gs.graphs:
+            if vid0 not in self._gs_inputs:
+                gt = gt_item["color"].float().cuda()
+                h, w, c = gt.shape[-3:]
+                mvp = gt_item["cam_to_world"].float()
+                cam = gt_item["cam_position"].float().cuda()
+                self._gs_inputs[vid0] = (mvp[0] if mvp.dim() == 4 else mvp, (cam[0] if cam.dim() == 2 else cam).contiguous(),
+                                         gt.reshape(-1, h, w, c).contiguous(), gt_item["mask"].float().cuda().reshape(-1, h, w, 1).contiguous())
+            mvp, cam, gt, gmask = self._gs_inputs[vid0]
+            self._gs.capture(vid0, mvp, cam, gt, gmask, self.seg_mask[str(vid0)], self.floor_max_mask[str(vid0)],
+                             self.room_seg_mask[str(vid0)] if stage == 2 else None, stage)
+        world = dist_util.world_info()[1]
+        self._gs.step(vid0, stage, all_reduce=dist_util.assemble_sum if world > 1 else None)
+        out = self._gs.outs[(vid0, stage)]
+        return out[0], out[1]
 
     def _new_optimizer(self):
         """fresh Adam + StepLR over ALL model parameters (train_material.py:122-128, 472-476, 539-543); the post-step
@@ -121,6 +147,8 @@ class MatTrainRunner:
 
     def train_step(self, gt_item, stage):
         """one optimiser step (train_material.py:424-458 / 486-525 / 552-593)"""
+        if getattr(self, "use_graph", False):
+            return self._graph_step(gt_item, stage)
         gt_color = gt_item["color"].float().cuda()
         h, w, c = gt_color.shape[-3:]
         gt_color = gt_color.reshape(-1, h, w, c)
@@ -160,7 +188,7 @@ class MatTrainRunner:
                 t0 = time.time()
                 self.model.train()
                 loss, seg_item = self.train_step(gt_item, stage)
-                self.log.append((stage, epoch, data_index, float(loss.item()), float(seg_item)))
+                self.log.append((stage, epoch, data_index, float(loss.item()), float(seg_item)))     # the reference prints .item() every step too
                 print("{0} [{1}] ({2}/{3}): img_loss_stage{7} ({5}) = {4}, seg_loss = {6}, batch cost time : {8:.4f}s".format(
                     self.expname, epoch, data_index, self.n_batches, loss.item(), self.conf.get_string("render_loss.loss_type"), seg_item, stage,
                     time.time() - t0))
