@@ -136,7 +136,7 @@ int32_t emit(const Tmp* t, std::vector<GpuNode>& out)
 // ---- 4-wide collapse: repeatedly open the inner child with the largest surface area until four children ----
 struct Quant { uint8_t lo[3], hi[3]; };
 
-void emit4_fill(GpuNode4& g, const Box& nb, const Tmp* const* kids, int nk, const int32_t* codes)
+void emit4_fill(GpuNode4& g, const Box& nb, const Tmp* const* kids, int nk, const int32_t* codes, int32_t dummy_leaf)
 {
     uint32_t e[3]; float scale[3];
     for (int a = 0; a < 3; a++) {
@@ -148,7 +148,8 @@ void emit4_fill(GpuNode4& g, const Box& nb, const Tmp* const* kids, int nk, cons
         e[a] = (uint32_t)ex;
         g.origin[a] = nb.mn[a];
     }
-    g.exps = e[0] | (e[1] << 8) | (e[2] << 16);
+    g.cell_x = scale[0]; g.cell_y = scale[1]; g.cell_z = scale[2];
+    (void)e;
     uint32_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     for (int k = 0; k < 4; k++) {
         uint32_t ql[3] = {255, 255, 255}, qh[3] = {0, 0, 0};          // unused slot: inverted box
@@ -164,12 +165,12 @@ void emit4_fill(GpuNode4& g, const Box& nb, const Tmp* const* kids, int nk, cons
             }
         }
         for (int a = 0; a < 3; a++) { lo[a] |= ql[a] << (8 * k); hi[a] |= qh[a] << (8 * k); }
-        g.c[k] = k < nk ? codes[k] : kEmptyChild;
+        g.c[k] = k < nk ? codes[k] : dummy_leaf;
     }
-    g.lox = lo[0]; g.loy = lo[1]; g.loz = lo[2]; g.hix = hi[0]; g.hiy = hi[1]; g.hiz = hi[2]; g.pad0 = g.pad1 = 0;
+    g.lox = lo[0]; g.loy = lo[1]; g.loz = lo[2]; g.hix = hi[0]; g.hiy = hi[1]; g.hiz = hi[2];
 }
 
-int32_t emit4(const Tmp* t, std::vector<GpuNode4>& out, int depth, int& max_depth)
+int32_t emit4(const Tmp* t, std::vector<GpuNode4>& out, int depth, int& max_depth, int32_t dummy_leaf)
 {
     int32_t idx = (int32_t)out.size();
     out.emplace_back();
@@ -185,8 +186,8 @@ int32_t emit4(const Tmp* t, std::vector<GpuNode4>& out, int depth, int& max_dept
         kids[best] = o->l.get(); kids[nk++] = o->r.get();
     }
     int32_t codes[4];
-    for (int k = 0; k < nk; k++) codes[k] = kids[k]->count ? leaf_code(kids[k]) : emit4(kids[k], out, depth + 1, max_depth);
-    emit4_fill(out[idx], t->box, kids, nk, codes);
+    for (int k = 0; k < nk; k++) codes[k] = kids[k]->count ? leaf_code(kids[k]) : emit4(kids[k], out, depth + 1, max_depth, dummy_leaf);
+    emit4_fill(out[idx], t->box, kids, nk, codes, dummy_leaf);
     return idx;
 }
 
@@ -259,11 +260,16 @@ void build_bvh(const float* verts, int V, const int32_t* tris, int T, const floa
     out.nodes4.clear();
     out.nodes4.reserve((size_t)T / 2 + 16);
     int d4 = 0;
-    emit4(root.get(), out.nodes4, 1, d4);
+    // slot T holds a degenerate (all-zero) triangle: the target of unused child slots
+    const int32_t dummy_leaf = ~(int32_t)(((uint32_t)T << 3) | 0u);
+    emit4(root.get(), out.nodes4, 1, d4, dummy_leaf);
     out.max_depth4 = d4;
     out.top4 = reorder_top_levels(out.nodes4, kTopLevels);
-    out.tris.resize((size_t)T);
-    out.uvs.resize((size_t)T);
+    out.tris.resize((size_t)T + 1);
+    out.uvs.resize((size_t)T + 1);
+    std::memset(&out.tris[T], 0, sizeof(GpuTri));
+    std::memset(&out.uvs[T], 0, sizeof(GpuTriUV));
+    out.tris[T].prim = 0xFFFFFFFFu;
     for (int i = 0; i < T; i++) {
         int p = order[i];
         const float* a = verts + 3 * (size_t)tris[3 * (size_t)p];

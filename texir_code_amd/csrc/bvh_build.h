@@ -32,14 +32,15 @@ struct alignas(16) GpuTriUV {
 
 // 64-byte 4-wide node with 8-bit child boxes quantised relative to the node's own box (one cache line per traversal step,
 // half the steps of the binary tree):
-//   q0 = (origin.x, origin.y, origin.z, bits: ex | ey<<8 | ez<<16)      biased float exponents: cell size = 2^(e-127)
+//   q0 = (origin.x, origin.y, origin.z, cell.x)                         cell size per axis = a power of two (float)
 //   q1 = (lo.x[4], lo.y[4], lo.z[4], hi.x[4])                           one byte per child, child k in byte k
-//   q2 = (hi.y[4], hi.z[4], 0, 0)
-//   q3 = (child0..3)  child >= 0: inner node index; < 0: leaf code as above; kEmptyChild: unused slot (inverted box)
+//   q2 = (hi.y[4], hi.z[4], cell.y, cell.z)
+//   q3 = (child0..3)  child >= 0: inner node index; < 0: leaf code as above.  Unused slots carry an inverted box and the
+//        leaf code of a degenerate dummy triangle appended after the mesh, so they need no test in the traversal loop.
 struct alignas(16) GpuNode4 {
-    float origin[3]; uint32_t exps;
+    float origin[3]; float cell_x;
     uint32_t lox, loy, loz, hix;
-    uint32_t hiy, hiz, pad0, pad1;
+    uint32_t hiy, hiz; float cell_y, cell_z;
     int32_t c[4];
 };
 static_assert(sizeof(GpuNode4) == 64, "wide node must be 64 bytes");

@@ -170,26 +170,24 @@ __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float
     while (node != kSentinel) {
         if (WIDTH == 4) {
             while (node >= 0 && node != kSentinel) {
-                float4 q0; uint4 q1; uint2 q2; int4 ch;
+                float4 q0; uint4 q1; uint4 q2; int4 ch;
                 if (TOPLDS && node < sc.top4) {
                     // upper levels: every ray passes through them -- served from LDS instead of the vector L1
                     const float4* lp = lds_top + 4 * node;
                     q0 = lp[0];
                     q1 = *reinterpret_cast<const uint4*>(lp + 1);
-                    q2 = *reinterpret_cast<const uint2*>(lp + 2);
+                    q2 = *reinterpret_cast<const uint4*>(lp + 2);
                     ch = *reinterpret_cast<const int4*>(lp + 3);
                 } else {
                     const float4* np = sc.nodes4 + 4 * (size_t)node;
                     q0 = np[0];
                     q1 = *reinterpret_cast<const uint4*>(np + 1);
-                    q2 = *reinterpret_cast<const uint2*>(np + 2);
+                    q2 = *reinterpret_cast<const uint4*>(np + 2);
                     ch = *reinterpret_cast<const int4*>(np + 3);
                 }
                 if (STATS) n_nodes++;
-                const uint32_t ex = __float_as_uint(q0.w);
-                // cell size 2^(e-127) folded into the reciprocal direction; origin folded into the offset
-                const float sx = __uint_as_float((ex & 255u) << 23) * idx, sy = __uint_as_float(((ex >> 8) & 255u) << 23) * idy,
-                            sz = __uint_as_float(((ex >> 16) & 255u) << 23) * idz;
+                // cell size folded into the reciprocal direction; origin folded into the offset
+                const float sx = q0.w * idx, sy = __uint_as_float(q2.z) * idy, sz = __uint_as_float(q2.w) * idz;
                 const float bx = q0.x * idx - oodx, by = q0.y * idy - oody, bz = q0.z * idz - oodz;
                 float key[4]; int code[4] = {ch.x, ch.y, ch.z, ch.w};
                 // the ray's direction signs decide once per node (for all four children at a time: the bytes stay packed) which of
@@ -205,8 +203,8 @@ __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float
                     float nzt = (float)((nz_ >> sh) & 255u) * sz + bz, fzt = (float)((fz_ >> sh) & 255u) * sz + bz;
                     float tn = fmaxf(fmaxf(nxt, nyt), fmaxf(nzt, 0.f));
                     float tf = fminf(fminf(fxt, fyt), fminf(fzt, h.t));
-                    // unused slots carry an inverted box (lo = 255, hi = 0): but a negative direction swaps lo/hi, so test the code too
-                    key[k] = (tn <= tf && code[k] != kEmptyChild) ? tn : __builtin_inff();
+                    // (unused slots: inverted box, and if ever entered they lead to a degenerate dummy triangle -- no test needed here)
+                    key[k] = tn <= tf ? tn : __builtin_inff();
                 }
                 // sort the four (key, code) pairs ascending: 5-comparator network
 #define TEXIR_CSWAP(a, b) { bool s_ = key[b] < key[a]; float ka = s_ ? key[b] : key[a], kb = s_ ? key[a] : key[b]; int ca = s_ ? code[b] : code[a], cb = s_ ? code[a] : code[b]; key[a] = ka; key[b] = kb; code[a] = ca; code[b] = cb; }
@@ -331,11 +329,10 @@ __device__ __forceinline__ void trace_resume(const SceneDev& sc, RayState& r, in
                 const float4* np = sc.nodes4 + 4 * (size_t)node;
                 float4 q0 = np[0];
                 uint4 q1 = *reinterpret_cast<const uint4*>(np + 1);
-                uint2 q2 = *reinterpret_cast<const uint2*>(np + 2);
+                uint4 q2 = *reinterpret_cast<const uint4*>(np + 2);
                 int4 ch = *reinterpret_cast<const int4*>(np + 3);
-                const uint32_t ex = __float_as_uint(q0.w);
-                const float sx = __uint_as_float((ex & 255u) << 23) * idx, sy = __uint_as_float(((ex >> 8) & 255u) << 23) * idy,
-                            sz = __uint_as_float(((ex >> 16) & 255u) << 23) * idz;
+                // cell size folded into the reciprocal direction; origin folded into the offset
+                const float sx = q0.w * idx, sy = __uint_as_float(q2.z) * idy, sz = __uint_as_float(q2.w) * idz;
                 const float bx = q0.x * idx - oodx, by = q0.y * idy - oody, bz = q0.z * idz - oodz;
                 float key[4]; int code[4] = {ch.x, ch.y, ch.z, ch.w};
                 // the ray's direction signs decide once per node (for all four children at a time: the bytes stay packed) which of
@@ -351,7 +348,7 @@ __device__ __forceinline__ void trace_resume(const SceneDev& sc, RayState& r, in
                     float nzt = (float)((nz_ >> sh) & 255u) * sz + bz, fzt = (float)((fz_ >> sh) & 255u) * sz + bz;
                     float tn = fmaxf(fmaxf(nxt, nyt), fmaxf(nzt, 0.f));
                     float tf = fminf(fminf(fxt, fyt), fminf(fzt, h.t));
-                    key[k] = (tn <= tf && code[k] != kEmptyChild) ? tn : __builtin_inff();
+                    key[k] = tn <= tf ? tn : __builtin_inff();
                 }
 #define TEXIR_CSWAP(a, b) { bool s_ = key[b] < key[a]; float ka = s_ ? key[b] : key[a], kb = s_ ? key[a] : key[b]; int ca = s_ ? code[b] : code[a], cb = s_ ? code[a] : code[b]; key[a] = ka; key[b] = kb; code[a] = ca; code[b] = cb; }
                 TEXIR_CSWAP(0, 1) TEXIR_CSWAP(2, 3) TEXIR_CSWAP(0, 2) TEXIR_CSWAP(1, 3) TEXIR_CSWAP(1, 2)
