@@ -85,6 +85,8 @@ class MatTrainRunner:
         self.n_batches = len(self.train_dataloader)
         self.plot_freq = self.conf.get_int("train.plot_freq")
         self.use_graph = self.conf.get_bool("train.hipgraph", default=False)      # new optional key; default = eager, reference call order
+        # multi-GPU: "pixel" = one view split across ranks (same trajectory as one GPU), "view" = one view per rank per step
+        self.mat_shard = self.conf.get_string("train.mat_shard", default="pixel")
         self.pano_res = self.conf.get_list("train.pano_img_res")
         self.cube_lenth = int(self.pano_res[1] / 4)
         self.first_val = True
@@ -147,7 +149,7 @@ class MatTrainRunner:
 
     def train_step(self, gt_item, stage):
         """one optimiser step (train_material.py:424-458 / 486-525 / 552-593)"""
-        if getattr(self, "use_graph", False):
+        if getattr(self, "use_graph", False) and not (dist_util.world_info()[1] > 1 and getattr(self, "mat_shard", "pixel") == "pixel"):
             return self._graph_step(gt_item, stage)
         gt_color = gt_item["color"].float().cuda()
         h, w, c = gt_color.shape[-3:]
@@ -158,7 +160,18 @@ class MatTrainRunner:
         vid0 = vid[0] if isinstance(vid, (list, tuple)) else vid
         cam = gt_item["cam_position"].float().cuda()
         fm, seg = self.floor_max_mask[str(vid0)], self.seg_mask[str(vid0)]
-        preds = self.model(mvp[0] if mvp.dim() == 4 else mvp, vid0, cam[0] if cam.dim() == 2 else cam, stage)
+        rank, world, _ = dist_util.world_info()
+        if world > 1 and self.mat_shard == "pixel":
+            # parity mode: the P pixels of this ONE view are split across ranks; the rendered slices are
+            # all-gathered, every rank evaluates the (cheap, non-separable) loss on the full view, back-propagates its own slice,
+            # and the texture gradients are summed -- the optimisation trajectory is the single-GPU one
+            P = gt_color.shape[0] * h * w
+            pr = dist_util.pixel_range(P, rank, world)
+            local = self.model(mvp[0] if mvp.dim() == 4 else mvp, vid0, cam[0] if cam.dim() == 2 else cam, stage, pixel_range=pr)
+            preds = {k: dist_util.gather_pixels(local[k].reshape(pr[1] - pr[0], -1), P).reshape(gt_color.shape[0], h, w, -1)
+                     for k in ("rgb", "albedo", "roughness", "roughness_womipmap", "empty_mask")}
+        else:
+            preds = self.model(mvp[0] if mvp.dim() == 4 else mvp, vid0, cam[0] if cam.dim() == 2 else cam, stage)
         out = self.mat_loss(gt_color, preds, gt_mask, fm, seg, stage=stage, room_seg_mask=self.room_seg_mask[str(vid0)] if stage == 2 else None)
         loss = out[0]
         self.mat_optimizer.zero_grad()
@@ -184,7 +197,13 @@ class MatTrainRunner:
         for epoch in range(self.start_epoch, self.nepochs + 1):
             if stage > 0 and epoch % self.plot_freq == 0 and not self.cur_iter == 0:      # train_material.py:484-485, 550-551
                 self.validation_forward(stage)
+            rank, world, _ = dist_util.world_info()
+            if world > 1 and self.mat_shard == "view" and len(self.train_dataset) % world:
+                raise ValueError("train.mat_shard = view needs the number of views (%d) to be a multiple of the world size (%d)"
+                                 % (len(self.train_dataset), world))
             for data_index, gt_item in enumerate(self.train_dataloader):
+                if world > 1 and self.mat_shard == "view" and data_index % world != rank:
+                    continue                     # throughput mode: `world` different views per optimiser step (gradients summed)
                 t0 = time.time()
                 self.model.train()
                 loss, seg_item = self.train_step(gt_item, stage)
