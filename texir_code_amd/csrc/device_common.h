@@ -30,8 +30,15 @@ constexpr int kStackCap = 96;        // LDS part + private overflow; the host ch
 // ------------------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
 
-__device__ __forceinline__ float ham0(uint32_t i, uint32_t N) { return (float)((double)i / (double)N); }   // sample_util.py:41
-__device__ __forceinline__ float ham1(uint32_t i) { return (float)((double)__brev(i) * 2.3283064365386963e-10); }  // :28-38
+// sample_util.py:41  float32(double(i)/double(N)).  For N = 2^k (and i < 2^24) the quotient is exact in float32, so the
+// multiply by the exact reciprocal gives the identical value without a float64 division.
+__device__ __forceinline__ float ham0(uint32_t i, uint32_t N)
+{
+    if ((N & (N - 1u)) == 0u && i < (1u << 24)) return (float)i * (1.0f / (float)N);
+    return (float)((double)i / (double)N);
+}
+// :28-38  float32(double(bitrev(i)) * 2^-32): scaling by a power of two commutes with the rounding to 24 bits
+__device__ __forceinline__ float ham1(uint32_t i) { return __uint2float_rn(__brev(i)) * 2.3283064365386963e-10f; }
 
 __device__ __forceinline__ float shift_wrap_clamp(float s, float shift)
 {

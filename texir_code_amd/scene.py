@@ -59,7 +59,7 @@ class Scene:
 
     def __del__(self):
         h = getattr(self, "h", None)
-        if h and _lib._LIB is not None:
+        if h and _lib is not None and getattr(_lib, "_LIB", None) is not None:      # (module globals may be gone at interpreter exit)
             try:
                 if _DEFER[0] > 0:
                     _PENDING.append(h)
