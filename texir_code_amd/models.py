@@ -240,7 +240,8 @@ class MaterialModel(nn.Module):
     def forward(self, mvp, id, cam_position, stage=1, pixel_range=None):
         gb = self._gbuffer(mvp, id) if pixel_range is None else self._gbuffer_slice(mvp, id, pixel_range)
         self._pixel_range = pixel_range
-        self._view_pixels = 6 * self.cube_res * self.cube_res
+        if pixel_range is not None:
+            self._view_pixels = 6 * self.cube_res * self.cube_res
         pos, nrm, mask = gb["position"], gb["normal"], gb["mask"]
         albedo, roughness_womipmap, roughness, irr = self._fetch_materials(gb)
         cam_position = cam_position.to(self.device)
