@@ -172,14 +172,18 @@ int64_t mip_total_elems(int H, int W, int C, int levels)
     return o > 0 ? o : 1;
 }
 
-__global__ __launch_bounds__(256) void mip_down_kernel(const float* __restrict__ src, float* __restrict__ dst, int Hd, int Wd, int C)
+// one thread per output float; rows come from blockIdx.y, so the index math is 32-bit with a compile-time C (no 64-bit div/mod)
+// and consecutive lanes read consecutive floats of the two source rows
+template <int C>
+__global__ __launch_bounds__(256) void mip_down_kernel(const float* __restrict__ src, float* __restrict__ dst, int Hd, int Wd)
 {
-    int64_t n = (int64_t)Hd * Wd * C;
-    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < n; g += (int64_t)gridDim.x * 256) {
-        int ch = (int)(g % C); int64_t t = g / C; int x = (int)(t % Wd), y = (int)(t / Wd);
-        const int Ws = Wd * 2;
-        const float* s = src + ((int64_t)(2 * y) * Ws + 2 * x) * C + ch;
-        dst[g] = 0.25f * (s[0] + s[C] + s[(int64_t)Ws * C] + s[(int64_t)Ws * C + C]);
+    const int e = blockIdx.x * 256 + threadIdx.x;           // element inside an output row: texel * C + channel
+    if (e >= Wd * C) return;
+    const int tx = e / C, ch = e - tx * C;
+    for (int y = blockIdx.y; y < Hd; y += gridDim.y) {
+        const float* r0 = src + ((size_t)(2 * y) * (2 * Wd) + 2 * tx) * C + ch;
+        const float* r1 = r0 + (size_t)(2 * Wd) * C;
+        dst[(size_t)y * Wd * C + e] = 0.25f * (r0[0] + r0[C] + r1[0] + r1[C]);
     }
 }
 
@@ -201,14 +205,16 @@ __global__ __launch_bounds__(1024) void mip_down_tail_kernel(float* __restrict__
     }
 }
 
-// fold: grad[l-1][2y+a][2x+b] += 0.25 * grad[l][y][x]
-__global__ __launch_bounds__(256) void mip_fold_kernel(float* __restrict__ fine, const float* __restrict__ coarse, int Hf, int Wf, int C)
+// fold: grad[l-1][2y+a][2x+b] += 0.25 * grad[l][y][x].  One thread per FINE float (coalesced read-modify-write of the fine row),
+// rows from blockIdx.y, 32-bit index math with compile-time C.
+template <int C>
+__global__ __launch_bounds__(256) void mip_fold_kernel(float* __restrict__ fine, const float* __restrict__ coarse, int Hf, int Wf)
 {
-    int64_t n = (int64_t)Hf * Wf * C;
-    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < n; g += (int64_t)gridDim.x * 256) {
-        int ch = (int)(g % C); int64_t t = g / C; int x = (int)(t % Wf), y = (int)(t / Wf);
-        fine[g] += 0.25f * coarse[((int64_t)(y >> 1) * (Wf >> 1) + (x >> 1)) * C + ch];
-    }
+    const int e = blockIdx.x * 256 + threadIdx.x;           // element inside a fine row
+    if (e >= Wf * C) return;
+    const int tx = e / C, ch = e - tx * C;
+    for (int y = blockIdx.y; y < Hf; y += gridDim.y)
+        fine[(size_t)y * Wf * C + e] += 0.25f * coarse[((size_t)(y >> 1) * (Wf >> 1) + (tx >> 1)) * C + ch];
 }
 
 __global__ __launch_bounds__(1024) void mip_fold_tail_kernel(float* __restrict__ rest, MipDesc d, int l_end /* fold levels-1 .. l_end+1 into l_end */)
@@ -303,6 +309,24 @@ static int tail_begin(const MipDesc& d)
     return l;        // first level produced by the tail kernel (>= 1)
 }
 
+static void launch_down(const float* src, float* dst, int Hd, int Wd, int C, hipStream_t st)
+{
+    dim3 grid((Wd * C + 255) / 256, Hd > 4096 ? 4096 : Hd);
+    if (C == 1) hipLaunchKernelGGL(mip_down_kernel<1>, grid, dim3(256), 0, st, src, dst, Hd, Wd);
+    else if (C == 2) hipLaunchKernelGGL(mip_down_kernel<2>, grid, dim3(256), 0, st, src, dst, Hd, Wd);
+    else if (C == 3) hipLaunchKernelGGL(mip_down_kernel<3>, grid, dim3(256), 0, st, src, dst, Hd, Wd);
+    else hipLaunchKernelGGL(mip_down_kernel<4>, grid, dim3(256), 0, st, src, dst, Hd, Wd);
+}
+
+static void launch_fold(float* fine, const float* coarse, int Hf, int Wf, int C, hipStream_t st)
+{
+    dim3 grid((Wf * C + 255) / 256, Hf > 4096 ? 4096 : Hf);
+    if (C == 1) hipLaunchKernelGGL(mip_fold_kernel<1>, grid, dim3(256), 0, st, fine, coarse, Hf, Wf);
+    else if (C == 2) hipLaunchKernelGGL(mip_fold_kernel<2>, grid, dim3(256), 0, st, fine, coarse, Hf, Wf);
+    else if (C == 3) hipLaunchKernelGGL(mip_fold_kernel<3>, grid, dim3(256), 0, st, fine, coarse, Hf, Wf);
+    else hipLaunchKernelGGL(mip_fold_kernel<4>, grid, dim3(256), 0, st, fine, coarse, Hf, Wf);
+}
+
 // builds levels 1..levels-1 into `rest` from the caller's level-0 texture
 hipError_t launch_mip_build(const float* tex, float* rest, int H, int W, int C, int levels, hipStream_t st)
 {
@@ -313,7 +337,7 @@ hipError_t launch_mip_build(const float* tex, float* rest, int H, int W, int C, 
     for (int l = 1; l < lt && l < levels; l++) {
         int Hd = H >> l, Wd = W >> l;
         const float* src = l == 1 ? tex : rest + d.off[l - 1];
-        hipLaunchKernelGGL(mip_down_kernel, dim3(grid1d((int64_t)Hd * Wd * C, 256)), dim3(256), 0, st, src, rest + d.off[l], Hd, Wd, C);
+        launch_down(src, rest + d.off[l], Hd, Wd, C, st);
     }
     if (lt < levels) hipLaunchKernelGGL(mip_down_tail_kernel, dim3(1), dim3(1024), 0, st, rest, d, lt);
     return hipGetLastError();
@@ -344,7 +368,7 @@ hipError_t launch_tex_fetch_bwd(float* d_tex, float* grad_rest, int H, int W, in
         for (int l = (lt < levels ? lt : levels) - 1; l >= 1; l--) {
             int Hf = H >> (l - 1), Wf = W >> (l - 1);
             float* fine = l == 1 ? d_tex : grad_rest + d.off[l - 1];
-            hipLaunchKernelGGL(mip_fold_kernel, dim3(grid1d((int64_t)Hf * Wf * C, 256)), dim3(256), 0, st, fine, grad_rest + d.off[l], Hf, Wf, C);
+            launch_fold(fine, grad_rest + d.off[l], Hf, Wf, C, st);
         }
     }
     return hipGetLastError();
