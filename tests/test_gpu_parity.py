@@ -367,3 +367,50 @@ def test_irradiance_at_random_mesh_points_vs_oracle(room):
     irr = sc.irt_generate(torch.from_numpy(p), torch.from_numpy(n), torch.from_numpy(shift), 2048, "uniform").cpu().numpy()   # env_res 32x64 = 2048 dirs
     ref = osc.irt_generate(p, n, None, shift, 2048, "uniform", tracer="bvh")
     assert rel_l2(irr, ref) < 1e-4
+
+
+def test_pathological_meshes_vs_bruteforce(tx):
+    """builder/traversal robustness: coincident centroids (forced median splits), long thin slivers, degenerate triangles,
+    a single triangle -- closest hits must still agree with the f64 brute-force oracle"""
+    from oracle import oracle as O
+    rng = np.random.default_rng(42)
+    hdr = rng.uniform(0.1, 2.0, (8, 8, 3)).astype(np.float32)
+    cases = {}
+    # (a) 3000 copies of (nearly) the same triangle stacked along z: every centroid coincides in x,y
+    base = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    v = np.concatenate([base + np.array([0, 0, 1e-3 * k], np.float32) for k in range(3000)])
+    cases["stack"] = (v, np.arange(9000, dtype=np.int32).reshape(-1, 3))
+    # (b) a fan of long thin slivers sharing one apex
+    n = 2000
+    ang = np.linspace(0, 2 * np.pi, n + 1)
+    ring = np.stack([50 * np.cos(ang), 50 * np.sin(ang), np.zeros_like(ang)], -1).astype(np.float32)
+    v = np.concatenate([np.zeros((1, 3), np.float32), ring])
+    cases["fan"] = (v, np.stack([np.zeros(n, np.int32), np.arange(1, n + 1, dtype=np.int32), np.arange(2, n + 2, dtype=np.int32)], -1))
+    # (c) random soup with zero-area and duplicated triangles mixed in
+    v = rng.uniform(-1, 1, (600, 3)).astype(np.float32)
+    t = rng.integers(0, 600, (1500, 3)).astype(np.int32)
+    t[::50, 1] = t[::50, 0]                      # degenerate (two equal corners)
+    t[1::97] = t[0]                              # exact duplicates
+    cases["soup"] = (v, t)
+    # (d) one triangle
+    cases["single"] = (base.copy(), np.array([[0, 1, 2]], np.int32))
+    for name, (verts, tris) in cases.items():
+        uvs = rng.uniform(0, 1, (3 * tris.shape[0], 2)).astype(np.float32)
+        sc = tx.Scene(verts, tris, uvs, hdr)
+        osc = O.Scene(verts, tris, uvs, hdr)
+        lo, hi = verts.min(0), verts.max(0)
+        R = 3000
+        org = (lo + (hi - lo) * rng.uniform(-0.2, 1.2, (R, 3))).astype(np.float32) + np.array([0, 0, 2.0], np.float32)
+        tgt = (lo + (hi - lo) * rng.uniform(0, 1, (R, 3))).astype(np.float32)
+        d = tgt - org
+        rad, t_gpu, pid, uv = sc.trace_shade(torch.from_numpy(org), torch.from_numpy(d), return_hits=True)
+        t_ref, pid_ref, uv_ref = osc.cast_rays(org, d, tracer="brute")
+        tg = t_gpu.cpu().numpy()
+        hit_ref = np.isfinite(t_ref)
+        hit_gpu = np.isfinite(tg)
+        assert (hit_ref == hit_gpu).mean() > 0.995, name
+        both = hit_ref & hit_gpu
+        if both.any():
+            # duplicates / stacked copies make the primitive id ambiguous; the hit distance is not
+            assert np.abs(tg[both] - t_ref[both]).max() < 1e-3 * max(1.0, float(np.abs(t_ref[both]).max())), name
+        assert torch.isfinite(rad).all(), name
