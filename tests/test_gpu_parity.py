@@ -414,3 +414,33 @@ def test_pathological_meshes_vs_bruteforce(tx):
             # duplicates / stacked copies make the primitive id ambiguous; the hit distance is not
             assert np.abs(tg[both] - t_ref[both]).max() < 1e-3 * max(1.0, float(np.abs(t_ref[both]).max())), name
         assert torch.isfinite(rad).all(), name
+
+
+def test_full_size_c3_material_pixels_vs_oracle(tx):
+    """BASELINE.json configs[2] geometry at full size (1M-triangle mesh, 6x128^2 pixels x 16 GGX samples = 1.57 M traced rays):
+    G-buffer by primary-ray casting, then the fused specular forward against the CPU oracle on the SAME G-buffer."""
+    from texir_code_amd import synth, cameras, gbuffer as GB, scene as S
+    from oracle import oracle as O
+    sc0 = synth.make_scene(1000000, seed=666, tex_res=512)
+    sc = tx.Scene(sc0["verts"], sc0["tris"], sc0["tri_uvs"], sc0["hdr"])
+    osc = O.Scene(sc0["verts"], sc0["tris"], sc0["tri_uvs"], sc0["hdr"])
+    mvp, cam = cameras.cube_mvps(cameras.grid_cameras(4)[5])
+    gb = GB.cast_gbuffer(sc, mvp, 128, flip_v=True)
+    assert float(gb["mask"].mean()) > 0.999                       # closed room
+    P = 6 * 128 * 128
+    n = gb["normal"].reshape(P, 3)
+    pts = (gb["position"] + 1e-2 * gb["normal"]).reshape(P, 3)
+    g = torch.Generator().manual_seed(1)
+    alb = torch.rand(P, 3, generator=g).cuda()
+    r = (torch.rand(P, generator=g) * 0.79 + 0.01).cuda()
+    irr = (torch.rand(P, 3, generator=g) * 2).cuda()
+    shift = torch.rand(P, 2, generator=g).cuda()
+    rgb = S.spec_render(sc, n, alb, r, pts, irr, cam.cuda(), shift, 16)
+    c = lambda t: t.detach().cpu().numpy()
+    ref = osc.spec_forward(c(n), c(alb), c(r), c(pts), c(irr), cam.numpy(), c(shift), 16, tracer="bvh")
+    assert rel_l2(c(rgb), ref) < 1e-3
+    assert rel_l2(c(rgb), ref) < 2e-4
+    # hit points of the G-buffer lie on the mesh: re-cast from the eye and compare distances with the f32 BVH oracle
+    d = (gb["position"].reshape(P, 3) - cam.cuda()).cpu().numpy()
+    t_ref, _, _ = osc.cast_rays(np.tile(cam.numpy(), (4096, 1)), d[::24][:4096], tracer="bvh")
+    assert np.abs(t_ref - 1.0).max() < 1e-3
