@@ -86,7 +86,8 @@ TEXIR_API int texir_generate_dir(const float* normals /*dev*/, const float* roug
  *   texel_ids [n_ids] i32 dev: the texels to compute (NULL => all Nt, n_ids ignored).  Seam texels
  *     (index texture all-zero, :137-139,176-178) are simply not listed; irr must be zero-initialised by the caller.
  *   irr [Nt,3] dev: only listed texels are written.
- *   stats [4] u64 dev, nullable: += rays, 64-byte node fetches, triangle tests, hits. */
+ *   stats [8] u64 dev, nullable: += rays, 64-byte node fetches, triangle tests, hits, wave-level node steps, wave-level
+ *   triangle steps (how often a wavefront executed each loop body: lane utilisation = lane count / (64 * wave count)), 2 reserved. */
 TEXIR_API int texir_irt_generate(const texir_scene* scene, const float* pos /*dev*/, const float* nrm /*dev*/,
                        const float* shift /*dev*/, const int32_t* texel_ids /*dev, nullable*/, int64_t n_ids,
                        int64_t Nt, int32_t N, int32_t mode, float* irr /*dev*/, uint64_t* stats /*dev, nullable*/,

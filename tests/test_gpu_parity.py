@@ -85,7 +85,7 @@ def test_irt_matches_reference_forward(golden, tx, name):
     assert np.all(irr[g["valid"].reshape(-1) == 0] == 0)
     st = st.cpu().numpy()
     assert st[0] == ids.numel() * int(g["N"])
-    # the no-stats and no-id-list variants agree bit-for-bit on the listed texels
+    # the counting build and the production build of the kernel agree bit-for-bit on the listed texels
     irr2 = sc.irt_generate(torch.from_numpy(g["pos"]), torch.from_numpy(g["nrm"]), torch.from_numpy(g["shift"]), int(g["N"]), str(g["mode"]),
                            texel_ids=ids).cpu().numpy()
     assert np.array_equal(irr, irr2)

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtexir_hip.so")
+LIB_PATH = os.environ.get("TEXIR_HIP_LIB") or os.path.join(_HERE, "libtexir_hip.so")   # (override: A/B builds of the kernels)
 _LIB = None
 
 EXPORTS = [

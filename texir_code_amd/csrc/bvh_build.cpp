@@ -1,6 +1,7 @@
 // Binned-SAH BVH2 builder (host, multi-threaded over the top subtrees) emitting the 64-byte
 // two-child-box node layout consumed by the gfx950 traversal kernels (see bvh_build.h).
 #include "bvh_build.h"
+#include <cstdlib>
 
 #include <algorithm>
 #include <cfloat>
@@ -39,6 +40,14 @@ struct Ctx {
 
 constexpr int kBins = 32;
 
+// triangles per leaf (leaf codes hold count-1 in 3 bits); TEXIR_MAX_LEAF overrides the default for A/B measurements
+static int max_leaf()
+{
+    static int v = 0;
+    if (!v) { const char* e = getenv("TEXIR_MAX_LEAF"); v = e ? std::min(8, std::max(1, atoi(e))) : kMaxLeaf; }
+    return v;
+}
+
 std::unique_ptr<Tmp> build(const Ctx& c, int first, int count, int depth, int par_levels)
 {
     std::unique_ptr<Tmp> n(new Tmp);
@@ -49,7 +58,7 @@ std::unique_ptr<Tmp> build(const Ctx& c, int first, int count, int depth, int pa
         n->box.grow((*c.tb)[p]);
         cb.grow(&(*c.cen)[3 * (size_t)p]);
     }
-    if (count <= kMaxLeaf) { n->first = first; n->count = count; return n; }
+    if (count <= max_leaf()) { n->first = first; n->count = count; return n; }
 
     int mid = -1;
     // depth guard: a balanced split always terminates within ceil(log2(count)) further levels

@@ -136,18 +136,13 @@ __device__ __forceinline__ void shade_hit(const SceneDev& sc, int tri_slot, floa
 // ------------------------------------------------------------------------------------------------
 struct Hit { float t, u, v; int slot; };
 
-// workgroup-wide copy of the upper levels of the wide tree into LDS (call once per block, all threads)
-__device__ __forceinline__ void stage_top_levels(const SceneDev& sc, float4* lds_top)
-{
-    const int n16 = 4 * sc.top4;
-    for (int i = threadIdx.x; i < n16; i += blockDim.x) lds_top[i] = sc.nodes4[i];
-    __syncthreads();
-}
-
-template <bool STATS, int LSTK = kLdsStack, int WIDTH = 2, bool TOPLDS = false>
+template <bool STATS, int LSTK = kLdsStack, int WIDTH = 2>
 __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float oy, float oz, float dx, float dy, float dz,
-                                             uint32_t& n_nodes, uint32_t& n_tris, const float4* lds_top = nullptr)
+                                             uint32_t& n_nodes, uint32_t& n_tris, uint32_t* wave_iters = nullptr)
 {
+    // STATS: n_nodes / n_tris count this lane's node fetches and triangle tests; wave_iters[0/1] (if given) count, on the first
+    // active lane, how many times the wave executed the node-step and the triangle-step bodies (for lane-utilisation figures)
+    auto first_active = [&]() -> bool { unsigned long long m = __ballot(1); return (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1; };
     // the traversal stack: LSTK entries per lane in LDS ([entry][thread], one instance per kernel), deeper ones private
     __shared__ int lds_all[LSTK * kBlock];
     int* lds_stack = lds_all + threadIdx.x;
@@ -177,22 +172,12 @@ __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float
     while (node != kSentinel) {
         if (WIDTH == 4) {
             while (node >= 0 && node != kSentinel) {
-                float4 q0; uint4 q1; uint4 q2; int4 ch;
-                if (TOPLDS && node < sc.top4) {
-                    // upper levels: every ray passes through them -- served from LDS instead of the vector L1
-                    const float4* lp = lds_top + 4 * node;
-                    q0 = lp[0];
-                    q1 = *reinterpret_cast<const uint4*>(lp + 1);
-                    q2 = *reinterpret_cast<const uint4*>(lp + 2);
-                    ch = *reinterpret_cast<const int4*>(lp + 3);
-                } else {
-                    const float4* np = sc.nodes4 + 4 * (size_t)node;
-                    q0 = np[0];
-                    q1 = *reinterpret_cast<const uint4*>(np + 1);
-                    q2 = *reinterpret_cast<const uint4*>(np + 2);
-                    ch = *reinterpret_cast<const int4*>(np + 3);
-                }
-                if (STATS) n_nodes++;
+                const float4* np = sc.nodes4 + 4 * (size_t)node;
+                const float4 q0 = np[0];
+                const uint4 q1 = *reinterpret_cast<const uint4*>(np + 1);
+                const uint4 q2 = *reinterpret_cast<const uint4*>(np + 2);
+                const int4 ch = *reinterpret_cast<const int4*>(np + 3);
+                if (STATS) { n_nodes++; if (wave_iters && first_active()) wave_iters[0]++; }
                 // cell size folded into the reciprocal direction; origin folded into the offset
                 const float sx = q0.w * idx, sy = __uint_as_float(q2.z) * idy, sz = __uint_as_float(q2.w) * idz;
                 const float bx = q0.x * idx - oodx, by = q0.y * idy - oody, bz = q0.z * idz - oodz;
@@ -264,7 +249,7 @@ __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float
             for (int i = first; i < first + cnt; i++) {
                 const float4* tp = sc.tris + 3 * (size_t)i;
                 float4 v0 = tp[0], e1 = tp[1], e2 = tp[2];
-                if (STATS) n_tris++;
+                if (STATS) { n_tris++; if (wave_iters && first_active()) wave_iters[1]++; }
                 // Moeller-Trumbore, same operation order as the oracle
                 float px = dy * e2.z - dz * e2.y, py = dz * e2.x - dx * e2.z, pz = dx * e2.y - dy * e2.x;
                 float det = e1.x * px + e1.y * py + e1.z * pz;
@@ -281,145 +266,6 @@ __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float
         }
     }
     return h;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Resumable variant for persistent waves with lane refill: the per-lane traversal state lives in a struct, and
-// trace_resume() runs whole while-while rounds until at least `refill_min` lanes of the wave have finished their ray
-// (wave ballot), so the caller can compact: shade the finished rays in one batch and hand their lanes new rays.
-// ------------------------------------------------------------------------------------------------
-struct RayState {
-    float dx, dy, dz, idx, idy, idz, oodx, oody, oodz;
-    Hit h;
-    int node, sp;
-};
-
-__device__ __forceinline__ void ray_begin(RayState& r, float ox, float oy, float oz, float dx, float dy, float dz)
-{
-    const float ooeps = 8.271806e-25f;  // 2^-80
-    r.dx = dx; r.dy = dy; r.dz = dz;
-    r.idx = __builtin_amdgcn_rcpf(fabsf(dx) > ooeps ? dx : copysignf(ooeps, dx));
-    r.idy = __builtin_amdgcn_rcpf(fabsf(dy) > ooeps ? dy : copysignf(ooeps, dy));
-    r.idz = __builtin_amdgcn_rcpf(fabsf(dz) > ooeps ? dz : copysignf(ooeps, dz));
-    r.oodx = ox * r.idx; r.oody = oy * r.idy; r.oodz = oz * r.idz;
-    r.h.t = __builtin_inff(); r.h.u = 0.f; r.h.v = 0.f; r.h.slot = -1;
-    r.node = 0; r.sp = 0;
-}
-
-template <int LSTK, int WIDTH>
-__device__ __forceinline__ void trace_resume(const SceneDev& sc, RayState& r, int (&ovf)[kStackCap - LSTK], float ox, float oy, float oz,
-                                             bool more_rays, int refill_min)
-{
-    __shared__ int lds_all[LSTK * kBlock];
-    int* lds_stack = lds_all + threadIdx.x;
-    int sp = r.sp, node = r.node;
-    Hit h = r.h;
-    const float dx = r.dx, dy = r.dy, dz = r.dz, idx = r.idx, idy = r.idy, idz = r.idz, oodx = r.oodx, oody = r.oody, oodz = r.oodz;
-    auto push = [&](int x) {
-        if (sp < LSTK) lds_stack[sp * kBlock] = x;
-        if (__any(sp >= LSTK)) { if (sp >= LSTK) ovf[sp - LSTK] = x; }
-        sp++;
-    };
-    auto pop = [&]() -> int {
-        if (sp == 0) return kSentinel;
-        sp--;
-        int v = lds_stack[(sp < LSTK ? sp : LSTK - 1) * kBlock];
-        if (__any(sp >= LSTK)) { int b = ovf[sp >= LSTK ? sp - LSTK : 0]; v = sp >= LSTK ? b : v; }
-        return v;
-    };
-    for (;;) {
-        const int n_act = __popcll(__ballot(node != kSentinel));
-        if (n_act == 0) break;
-        if (more_rays && 64 - n_act >= refill_min) break;
-        if (WIDTH == 4) {
-            while (node >= 0 && node != kSentinel) {
-                const float4* np = sc.nodes4 + 4 * (size_t)node;
-                float4 q0 = np[0];
-                uint4 q1 = *reinterpret_cast<const uint4*>(np + 1);
-                uint4 q2 = *reinterpret_cast<const uint4*>(np + 2);
-                int4 ch = *reinterpret_cast<const int4*>(np + 3);
-                // cell size folded into the reciprocal direction; origin folded into the offset
-                const float sx = q0.w * idx, sy = __uint_as_float(q2.z) * idy, sz = __uint_as_float(q2.w) * idz;
-                const float bx = q0.x * idx - oodx, by = q0.y * idy - oody, bz = q0.z * idz - oodz;
-                float key[4]; int code[4] = {ch.x, ch.y, ch.z, ch.w};
-                // the ray's direction signs decide once per node (for all four children at a time: the bytes stay packed) which of
-                // the lo/hi planes is the entry and which the exit plane -- no per-child min/max of the two slab distances
-                const uint32_t nx_ = idx < 0.f ? q1.w : q1.x, fx_ = idx < 0.f ? q1.x : q1.w;
-                const uint32_t ny_ = idy < 0.f ? q2.x : q1.y, fy_ = idy < 0.f ? q1.y : q2.x;
-                const uint32_t nz_ = idz < 0.f ? q2.y : q1.z, fz_ = idz < 0.f ? q1.z : q2.y;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int sh = 8 * k;
-                    float nxt = (float)((nx_ >> sh) & 255u) * sx + bx, fxt = (float)((fx_ >> sh) & 255u) * sx + bx;
-                    float nyt = (float)((ny_ >> sh) & 255u) * sy + by, fyt = (float)((fy_ >> sh) & 255u) * sy + by;
-                    float nzt = (float)((nz_ >> sh) & 255u) * sz + bz, fzt = (float)((fz_ >> sh) & 255u) * sz + bz;
-                    float tn = fmaxf(fmaxf(nxt, nyt), fmaxf(nzt, 0.f));
-                    float tf = fminf(fminf(fxt, fyt), fminf(fzt, h.t));
-                    key[k] = tn <= tf ? tn : __builtin_inff();
-                }
-#define TEXIR_CSWAP(a, b) { bool s_ = key[b] < key[a]; float ka = s_ ? key[b] : key[a], kb = s_ ? key[a] : key[b]; int ca = s_ ? code[b] : code[a], cb = s_ ? code[a] : code[b]; key[a] = ka; key[b] = kb; code[a] = ca; code[b] = cb; }
-                TEXIR_CSWAP(0, 1) TEXIR_CSWAP(2, 3) TEXIR_CSWAP(0, 2) TEXIR_CSWAP(1, 3) TEXIR_CSWAP(1, 2)
-#undef TEXIR_CSWAP
-                const float inf = __builtin_inff();
-                if (!__any(sp + 3 > LSTK)) {
-                    // common case (one wave-uniform test per node): the whole update stays inside the LDS part of the stack
-                    if (key[3] < inf) { lds_stack[sp * kBlock] = code[3]; sp++; }
-                    if (key[2] < inf) { lds_stack[sp * kBlock] = code[2]; sp++; }
-                    if (key[1] < inf) { lds_stack[sp * kBlock] = code[1]; sp++; }
-                    if (key[0] < inf) node = code[0];
-                    else if (sp > 0) { sp--; node = lds_stack[sp * kBlock]; }
-                    else node = kSentinel;
-                } else {
-                    if (key[3] < inf) push(code[3]);
-                    if (key[2] < inf) push(code[2]);
-                    if (key[1] < inf) push(code[1]);
-                    node = key[0] < inf ? code[0] : pop();
-                }
-            }
-        } else {
-            while (node >= 0 && node != kSentinel) {
-                const float4* np = sc.nodes + 4 * (size_t)node;
-                float4 n0 = np[0], n1 = np[1], n2 = np[2];
-                int2 ch = *reinterpret_cast<const int2*>(np + 3);
-                float c0lox = n0.x * idx - oodx, c0hix = n0.y * idx - oodx, c0loy = n0.z * idy - oody, c0hiy = n0.w * idy - oody;
-                float c0loz = n2.x * idz - oodz, c0hiz = n2.y * idz - oodz;
-                float c1lox = n1.x * idx - oodx, c1hix = n1.y * idx - oodx, c1loy = n1.z * idy - oody, c1hiy = n1.w * idy - oody;
-                float c1loz = n2.z * idz - oodz, c1hiz = n2.w * idz - oodz;
-                float t0n = fmaxf(fmaxf(fminf(c0lox, c0hix), fminf(c0loy, c0hiy)), fmaxf(fminf(c0loz, c0hiz), 0.f));
-                float t0f = fminf(fminf(fmaxf(c0lox, c0hix), fmaxf(c0loy, c0hiy)), fminf(fmaxf(c0loz, c0hiz), h.t));
-                float t1n = fmaxf(fmaxf(fminf(c1lox, c1hix), fminf(c1loy, c1hiy)), fmaxf(fminf(c1loz, c1hiz), 0.f));
-                float t1f = fminf(fminf(fmaxf(c1lox, c1hix), fmaxf(c1loy, c1hiy)), fminf(fmaxf(c1loz, c1hiz), h.t));
-                bool h0 = t0n <= t0f, h1 = t1n <= t1f;
-                if (h0 && h1) {
-                    bool swp = t1n < t0n;
-                    push(swp ? ch.x : ch.y);
-                    node = swp ? ch.y : ch.x;
-                } else if (h0) node = ch.x;
-                else if (h1) node = ch.y;
-                else node = pop();
-            }
-        }
-        while (node < 0) {
-            uint32_t code = ~(uint32_t)node;
-            int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
-            for (int i = first; i < first + cnt; i++) {
-                const float4* tp = sc.tris + 3 * (size_t)i;
-                float4 v0 = tp[0], e1 = tp[1], e2 = tp[2];
-                float px = dy * e2.z - dz * e2.y, py = dz * e2.x - dx * e2.z, pz = dx * e2.y - dy * e2.x;
-                float det = e1.x * px + e1.y * py + e1.z * pz;
-                float inv = __builtin_amdgcn_rcpf(det);
-                float tx = ox - v0.x, ty = oy - v0.y, tz = oz - v0.z;
-                float u = (tx * px + ty * py + tz * pz) * inv;
-                float qx = ty * e1.z - tz * e1.y, qy = tz * e1.x - tx * e1.z, qz = tx * e1.y - ty * e1.x;
-                float v = (dx * qx + dy * qy + dz * qz) * inv;
-                float t = (e2.x * qx + e2.y * qy + e2.z * qz) * inv;
-                bool ok = (det != 0.f) & (u >= 0.f) & (u <= 1.f) & (v >= 0.f) & (u + v <= 1.f) & (t > 0.f) & (t < h.t);
-                if (ok) { h.t = t; h.u = u; h.v = v; h.slot = i; }
-            }
-            node = pop();
-        }
-    }
-    r.sp = sp; r.node = node; r.h = h;
 }
 
 __device__ __forceinline__ float wave_sum(float x)

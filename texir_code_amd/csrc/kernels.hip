@@ -26,39 +26,29 @@ __device__ __forceinline__ uint32_t sample_index(uint32_t pass, uint32_t lane, u
     return (th << (log2N - bth)) | (lane << bphi) | low;
 }
 
-// Cell-major schedule.  With N = 2^m >= 128 the samples of a texel fall into 2^(m-6) lattice cells of 64 samples; the
-// kernel is launched once per ABSOLUTE direction cell J and every texel contributes the lattice pass whose cell lies
-// nearest to J after its own Cranley-Patterson shift (a bijection J -> pass for a fixed shift, so every sample is traced
-// exactly once over the launches).  All rays in flight on the chip then leave neighbouring texels towards the same
-// ~1/32 of the hemisphere: the BVH/triangle/texel working set of a launch shrinks by the number of cells and fits the
-// per-XCD L2 instead of streaming from the Infinity Cache.
-__device__ __forceinline__ uint32_t cell_to_pass(uint32_t J, float sh0, float sh1, int log2N)
+// stats [8] (include/texir_hip.h): rays, node fetches, triangle tests, hits, wave-level node steps, wave-level triangle steps
+__device__ __forceinline__ void irt_stats_flush(unsigned long long* stats, int lane, uint32_t rays, uint32_t nodes, uint32_t tris,
+                                                uint32_t hits, uint32_t wnodes, uint32_t wtris)
 {
-    int cells = log2N - 6;
-    int bphi = (cells + 1) >> 1, bth = cells - bphi;
-    uint32_t nphi = 1u << bphi, nth = 1u << bth;
-    uint32_t Jphi = J & (nphi - 1u), Jth = J >> bphi;
-    uint32_t dphi = (uint32_t)(sh1 * (float)nphi + 0.5f), dth = (uint32_t)(sh0 * (float)nth + 0.5f);
-    uint32_t phibin = (Jphi + nphi - (dphi & (nphi - 1u))) & (nphi - 1u);
-    uint32_t th = (Jth + nth - (dth & (nth - 1u))) & (nth - 1u);
-    uint32_t low = __brev(phibin) >> (32 - bphi);          // phi's high bits are i's low bits reversed
-    if (bphi == 0) low = 0;
-    return (th << bphi) | low;
+    uint32_t v[6] = {rays, nodes, tris, hits, wnodes, wtris};
+    for (int q = 0; q < 6; q++) {
+        unsigned long long x = v[q];
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        if (lane == 0 && x) atomicAdd(&stats[q], x);
+    }
 }
 
-// MODE 0: all passes of a texel in one launch (any N).  MODE 1: one direction cell per launch (cell-major schedule);
-// irr accumulates the raw sum over launches and the last launch applies the 2*pi/N scale.
-template <bool STATS, int MODE, int LSTK, int MINW, int WIDTH, bool TOPLDS>
-__global__ __launch_bounds__(kBlock, MINW) void irt_kernel(SceneDev sc, const float* __restrict__ pos, const float* __restrict__ nrm,
+// One texel per wave: the 64 lanes trace 64 samples of the texel per pass (any N, binary or 4-wide tree).  Kept as the
+// fallback for binary trees and as TEXIR_IRT_VARIANT=1 (the A/B baseline of the multi-texel kernel below).
+template <bool STATS, int WIDTH>
+__global__ __launch_bounds__(kBlock) void irt_kernel(SceneDev sc, const float* __restrict__ pos, const float* __restrict__ nrm,
                                                      const float* __restrict__ shift, const int32_t* __restrict__ ids, int64_t n_ids,
-                                                     int N, int log2N, int mode, int cell, int last_cell, float* __restrict__ irr,
+                                                     int N, int log2N, int mode, float* __restrict__ irr,
                                                      unsigned long long* __restrict__ stats)
 {
-    __shared__ float4 lds_top[TOPLDS ? 4 * kTopMax : 1];
-    if (TOPLDS) stage_top_levels(sc, lds_top);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + wave, nw = (int64_t)gridDim.x * (kBlock / 64);
-    uint32_t c_nodes = 0, c_tris = 0, c_rays = 0, c_hits = 0;
+    uint32_t c_nodes = 0, c_tris = 0, c_rays = 0, c_hits = 0, wi[2] = {0, 0};
     const int passes = (N + 63) >> 6;
     for (int64_t k = gw; k < n_ids; k += nw) {
         const int64_t t = ids ? (int64_t)ids[k] : k;
@@ -67,16 +57,14 @@ __global__ __launch_bounds__(kBlock, MINW) void irt_kernel(SceneDev sc, const fl
         const float sh0 = shift[2 * t], sh1 = shift[2 * t + 1];
         const Frame f = make_frame(nx, ny, nz);
         float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
-        const int p_begin = MODE ? (int)cell_to_pass((uint32_t)cell, sh0, sh1, log2N) : 0;
-        const int p_end = MODE ? p_begin + 1 : passes;
-        for (int p = p_begin; p < p_end; p++) {
+        for (int p = 0; p < passes; p++) {
             uint32_t i = sample_index((uint32_t)p, (uint32_t)lane, (uint32_t)N, log2N);
             if (i < (uint32_t)N) {
                 float s0 = shift_wrap_clamp(ham0(i, (uint32_t)N), sh0);
                 float s1 = shift_wrap_clamp(ham1(i), sh1);
                 float d[3];
                 sample_dir(mode, s0, s1, 0.f, f, d);
-                Hit h = trace_closest<STATS, LSTK, WIDTH, TOPLDS>(sc, px, py, pz, d[0], d[1], d[2], c_nodes, c_tris, lds_top);
+                Hit h = trace_closest<STATS, kLdsStack, WIDTH>(sc, px, py, pz, d[0], d[1], d[2], c_nodes, c_tris, STATS ? wi : nullptr);
                 if (STATS) c_rays++;
                 if (h.slot >= 0 && h.t > 1e-4f) {          // tracer_o3d_irt.py:248
                     float L[3];
@@ -90,91 +78,93 @@ __global__ __launch_bounds__(kBlock, MINW) void irt_kernel(SceneDev sc, const fl
         }
         acc0 = wave_sum(acc0); acc1 = wave_sum(acc1); acc2 = wave_sum(acc2);
         if (lane == 0) {
-            if (MODE) {
-                if (cell != 0) { acc0 += irr[3 * t]; acc1 += irr[3 * t + 1]; acc2 += irr[3 * t + 2]; }
-            }
-            if (!MODE || last_cell) {
-                // :171  sum * 2 * np.pi / N
-                const float pi = 3.141592653589793f;
-                acc0 = ((acc0 * 2.f) * pi) / (float)N; acc1 = ((acc1 * 2.f) * pi) / (float)N; acc2 = ((acc2 * 2.f) * pi) / (float)N;
-            }
-            irr[3 * t] = acc0; irr[3 * t + 1] = acc1; irr[3 * t + 2] = acc2;
-        }
-    }
-    if (STATS) {
-        // integer wave reductions
-        uint32_t v[4] = {c_rays, c_nodes, c_tris, c_hits};
-        for (int q = 0; q < 4; q++) {
-            unsigned long long x = v[q];
-            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-            if (lane == 0 && x) atomicAdd(&stats[q], x);
-        }
-    }
-}
-
-// Persistent-wave variant with lane refill (wavefront ballot / prefix-sum ray compaction): a wave owns one texel at a time
-// and keeps its 64 lanes busy -- whenever >= refill_min lanes have finished their ray, the finished rays are shaded in one
-// batch and the idle lanes take the texel's next samples (rank among idle lanes = mbcnt of the ballot mask).
-template <int WIDTH>
-__global__ __launch_bounds__(kBlock) void irt_refill_kernel(SceneDev sc, const float* __restrict__ pos, const float* __restrict__ nrm,
-                                                            const float* __restrict__ shift, const int32_t* __restrict__ ids, int64_t n_ids,
-                                                            int N, int log2N, int mode, int refill_min, float* __restrict__ irr)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + wave, nw = (int64_t)gridDim.x * (kBlock / 64);
-    int ovf[kStackCap - kLdsStack];
-    for (int64_t k = gw; k < n_ids; k += nw) {
-        const int64_t t = ids ? (int64_t)ids[k] : k;
-        const float px = pos[3 * t], py = pos[3 * t + 1], pz = pos[3 * t + 2];
-        const float nx = nrm[3 * t], ny = nrm[3 * t + 1], nz = nrm[3 * t + 2];
-        const float sh0 = shift[2 * t], sh1 = shift[2 * t + 1];
-        const Frame f = make_frame(nx, ny, nz);
-        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
-        RayState r;
-        r.node = kSentinel; r.sp = 0; r.h.slot = -1; r.h.t = 0.f; r.h.u = r.h.v = 0.f;
-        r.dx = r.dy = r.dz = 0.f; r.idx = r.idy = r.idz = 0.f; r.oodx = r.oody = r.oodz = 0.f;
-        bool have_ray = false;
-        int q_next = 0;                                        // wave-uniform: samples handed out so far
-        for (;;) {
-            const bool idle = r.node == kSentinel;
-            // finished rays: hit shader + accumulate (batched over all lanes that finished since the last refill)
-            if (idle && have_ray) {
-                if (r.h.slot >= 0 && r.h.t > 1e-4f) {              // tracer_o3d_irt.py:248
-                    float L[3];
-                    shade_hit(sc, r.h.slot, r.h.u, r.h.v, L);
-                    float ndl = fminf(fmaxf(nx * r.dx + ny * r.dy + nz * r.dz, 0.f), 1.f);     // :170, RAW normal
-                    acc0 += L[0] * ndl; acc1 += L[1] * ndl; acc2 += L[2] * ndl;
-                }
-                have_ray = false;
-            }
-            // compaction: idle lanes take the next samples, rank = number of idle lanes below this one
-            const unsigned long long idle_mask = __ballot(idle);
-            if (q_next < N) {
-                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
-                const int q = q_next + rank;
-                if (idle && q < N) {
-                    uint32_t i = sample_index((uint32_t)(q >> 6), (uint32_t)(q & 63), (uint32_t)N, log2N);
-                    if (i >= (uint32_t)N) i = (uint32_t)q;          // (N not a multiple of 64: natural order already)
-                    float s0 = shift_wrap_clamp(ham0(i, (uint32_t)N), sh0);
-                    float s1 = shift_wrap_clamp(ham1(i), sh1);
-                    float d[3];
-                    sample_dir(mode, s0, s1, 0.f, f, d);
-                    ray_begin(r, px, py, pz, d[0], d[1], d[2]);
-                    have_ray = true;
-                }
-                q_next += __popcll(idle_mask);
-            }
-            if (__ballot(r.node != kSentinel) == 0ull) break;
-            trace_resume<kLdsStack, WIDTH>(sc, r, ovf, px, py, pz, q_next < N, refill_min);
-        }
-        acc0 = wave_sum(acc0); acc1 = wave_sum(acc1); acc2 = wave_sum(acc2);
-        if (lane == 0) {
+            // :171  sum * 2 * np.pi / N
             const float pi = 3.141592653589793f;
             irr[3 * t] = ((acc0 * 2.f) * pi) / (float)N;
             irr[3 * t + 1] = ((acc1 * 2.f) * pi) / (float)N;
             irr[3 * t + 2] = ((acc2 * 2.f) * pi) / (float)N;
         }
     }
+    if (STATS) irt_stats_flush(stats, lane, c_rays, c_nodes, c_tris, c_hits, wi[0], wi[1]);
+}
+
+// Multi-texel passes.  A wave traces GRP neighbouring texels at once: lane group g (64/GRP lanes) belongs to texel g and all groups
+// take, in the same pass, the lattice cell of THEIR texel that lies nearest to one absolute direction cell J (cell_to_pass_m).
+// The 64 rays of a pass then span 1/(32*GRP) of the hemisphere instead of 1/32 (for N = 2048) and start within a few
+// millimetres of each other: their traversals stay together much longer, which is what an issue-bound SIMT traversal needs.
+// Every sample of every texel is still traced exactly once (J -> cell is a bijection for a fixed shift).
+__device__ __forceinline__ uint32_t sample_index_m(uint32_t cell, uint32_t sub, int log2N, int log2m)
+{
+    int cells = log2N - log2m;
+    int bphi = (cells + 1) >> 1, bth = cells - bphi;
+    uint32_t low = cell & ((1u << bphi) - 1u);
+    uint32_t th = bth ? (cell >> bphi) : 0u;
+    return (th << (log2N - bth)) | (sub << bphi) | low;
+}
+
+__device__ __forceinline__ uint32_t cell_to_pass_m(uint32_t J, float sh0, float sh1, int log2N, int log2m)
+{
+    int cells = log2N - log2m;
+    int bphi = (cells + 1) >> 1, bth = cells - bphi;
+    uint32_t nphi = 1u << bphi, nth = 1u << bth;
+    uint32_t Jphi = J & (nphi - 1u), Jth = J >> bphi;
+    uint32_t dphi = (uint32_t)(sh1 * (float)nphi + 0.5f), dth = (uint32_t)(sh0 * (float)nth + 0.5f);
+    uint32_t phibin = (Jphi + nphi - (dphi & (nphi - 1u))) & (nphi - 1u);
+    uint32_t th = (Jth + nth - (dth & (nth - 1u))) & (nth - 1u);
+    uint32_t low = bphi ? (__brev(phibin) >> (32 - bphi)) : 0u;
+    return (th << bphi) | low;
+}
+
+template <bool STATS, int WIDTH, int LOG2GRP>
+__global__ __launch_bounds__(kBlock) void irt_group_kernel(SceneDev sc, const float* __restrict__ pos, const float* __restrict__ nrm,
+                                                           const float* __restrict__ shift, const int32_t* __restrict__ ids, int64_t n_ids,
+                                                           int N, int log2N, int mode, float* __restrict__ irr,
+                                                           unsigned long long* __restrict__ stats)
+{
+    constexpr int GRP = 1 << LOG2GRP, LOG2M = 6 - LOG2GRP, M = 64 >> LOG2GRP;       // texels per wave, samples per texel per pass
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> LOG2M, sub = lane & (M - 1);
+    const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + wave, nw = (int64_t)gridDim.x * (kBlock / 64);
+    const int n_cells = N >> LOG2M;
+    uint32_t cn = 0, ct = 0, c_rays = 0, c_hits = 0, wi[2] = {0, 0};
+    for (int64_t k0 = gw * GRP; k0 < n_ids; k0 += nw * GRP) {
+        const int64_t k = k0 + grp;
+        const bool live = k < n_ids;
+        const int64_t t = live ? (ids ? (int64_t)ids[k] : k) : 0;
+        const float px = pos[3 * t], py = pos[3 * t + 1], pz = pos[3 * t + 2];
+        const float nx = nrm[3 * t], ny = nrm[3 * t + 1], nz = nrm[3 * t + 2];
+        const float sh0 = shift[2 * t], sh1 = shift[2 * t + 1];
+        const Frame f = make_frame(nx, ny, nz);
+        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+        for (int J = 0; J < n_cells; J++) {
+            if (live) {
+                // (N not a power of two: only the one-sample-per-pass form is launched, in natural sample order)
+                const uint32_t i = log2N < 0 ? (uint32_t)J : sample_index_m(cell_to_pass_m((uint32_t)J, sh0, sh1, log2N, LOG2M), (uint32_t)sub, log2N, LOG2M);
+                float s0 = shift_wrap_clamp(ham0(i, (uint32_t)N), sh0);
+                float s1 = shift_wrap_clamp(ham1(i), sh1);
+                float d[3];
+                sample_dir(mode, s0, s1, 0.f, f, d);
+                Hit h = trace_closest<STATS, kLdsStack, WIDTH>(sc, px, py, pz, d[0], d[1], d[2], cn, ct, STATS ? wi : nullptr);
+                if (STATS) c_rays++;
+                if (h.slot >= 0 && h.t > 1e-4f) {          // tracer_o3d_irt.py:248
+                    float L[3];
+                    shade_hit(sc, h.slot, h.u, h.v, L);
+                    float ndl = fminf(fmaxf(nx * d[0] + ny * d[1] + nz * d[2], 0.f), 1.f);       // :170, RAW normal
+                    acc0 += L[0] * ndl; acc1 += L[1] * ndl; acc2 += L[2] * ndl;
+                    if (STATS) c_hits++;
+                }
+            }
+        }
+        // reduce over the M lanes of each texel
+        for (int o = M >> 1; o > 0; o >>= 1) { acc0 += __shfl_xor(acc0, o, 64); acc1 += __shfl_xor(acc1, o, 64); acc2 += __shfl_xor(acc2, o, 64); }
+        if (live && sub == 0) {
+            const float pi = 3.141592653589793f;
+            irr[3 * t] = ((acc0 * 2.f) * pi) / (float)N;
+            irr[3 * t + 1] = ((acc1 * 2.f) * pi) / (float)N;
+            irr[3 * t + 2] = ((acc2 * 2.f) * pi) / (float)N;
+        }
+    }
+    if (STATS) irt_stats_flush(stats, lane, c_rays, cn, ct, c_hits, wi[0], wi[1]);
 }
 
 template <int WIDTH>
@@ -372,58 +362,41 @@ static int resident_grid(K kernel, int block)
     return cus * per_cu;
 }
 
+// TEXIR_IRT_VARIANT (A/B switch, default 9): 1 = one texel per wave, 7 = 16 texels per wave, 9 = 64 texels per wave
 static int irt_variant()
 {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("TEXIR_IRT_VARIANT"); v = e ? atoi(e) : 1; }
+    if (v < 0) { const char* e = getenv("TEXIR_IRT_VARIANT"); v = e ? atoi(e) : 9; }
     return v;
 }
 
-int irt_launch_count(int N) { return (irt_variant() == 2 && ilog2_exact(N) >= 7) ? (N >> 6) : 1; }
+int irt_launch_count(int) { return 1; }
 
-template <bool STATS, int MODE, int LSTK, int MINW, int WIDTH, bool TOPLDS>
-static void irt_launch_w(bool resident, const SceneDev& sc, const float* pos, const float* nrm, const float* shift, const int32_t* ids, int64_t n_ids,
-                         int N, int l2, int mode, int cell, int last, float* irr, unsigned long long* stats, hipStream_t st)
+template <typename K>
+static void irt_launch(K kernel, int64_t waves_wanted, const SceneDev& sc, const float* pos, const float* nrm, const float* shift,
+                       const int32_t* ids, int64_t n_ids, int N, int l2, int mode, float* irr, unsigned long long* stats, hipStream_t st)
 {
-    int64_t want = (n_ids + (kBlock / 64) - 1) / (kBlock / 64);
-    int grid = resident ? resident_grid(irt_kernel<STATS, MODE, LSTK, MINW, WIDTH, TOPLDS>, kBlock) : 2048;
+    // persistent grid: exactly the workgroups that are co-resident, each wave strides over the texel list
+    const int64_t want = (waves_wanted + (kBlock / 64) - 1) / (kBlock / 64);
+    int grid = resident_grid(kernel, kBlock);
     if (want < grid) grid = (int)want;
-    hipLaunchKernelGGL((irt_kernel<STATS, MODE, LSTK, MINW, WIDTH, TOPLDS>), dim3(grid), dim3(kBlock), 0, st, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, cell, last, irr, stats);
-}
-
-template <bool STATS, int MODE, int LSTK, int MINW>
-static void irt_launch_one(bool resident, const SceneDev& sc, const float* pos, const float* nrm, const float* shift, const int32_t* ids, int64_t n_ids,
-                           int N, int l2, int mode, int cell, int last, float* irr, unsigned long long* stats, hipStream_t st)
-{
-    static const bool top_lds = getenv("TEXIR_TOP_LDS") ? atoi(getenv("TEXIR_TOP_LDS")) != 0 : false;
-    if (sc.nodes4 && top_lds) irt_launch_w<STATS, MODE, LSTK, MINW, 4, true>(resident, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, cell, last, irr, stats, st);
-    else if (sc.nodes4) irt_launch_w<STATS, MODE, LSTK, MINW, 4, false>(resident, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, cell, last, irr, stats, st);
-    else irt_launch_w<STATS, MODE, LSTK, MINW, 2, false>(resident, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, cell, last, irr, stats, st);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, irr, stats);
 }
 
 hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, const float* shift, const int32_t* ids, int64_t n_ids,
                       int N, int mode, float* irr, unsigned long long* stats, hipStream_t st)
 {
     if (n_ids <= 0) return hipSuccess;
-    // variants (TEXIR_IRT_VARIANT, default 1): 0 capped grid; 1 resident grid; 2 resident + cell-major launches
     const int variant = irt_variant();
-    int l2 = ilog2_exact(N);
-    if (stats) { irt_launch_one<true, 0, 24, 1>(variant >= 1, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, 0, 1, irr, stats, st); return hipGetLastError(); }
-    if (variant == 2 && l2 >= 7) {
-        const int cells = N >> 6;
-        for (int j = 0; j < cells; j++) irt_launch_one<false, 1, 24, 1>(true, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, j, j == cells - 1, irr, stats, st);
-    } else if (variant >= 5) {
-        // 5: persistent waves with lane refill; refill threshold from TEXIR_REFILL_MIN (default 16 idle lanes)
-        static const int refill_min = getenv("TEXIR_REFILL_MIN") ? atoi(getenv("TEXIR_REFILL_MIN")) : 16;
-        int64_t want = (n_ids + (kBlock / 64) - 1) / (kBlock / 64);
-        if (sc.nodes4) {
-            int grid = resident_grid(irt_refill_kernel<4>, kBlock); if (want < grid) grid = (int)want;
-            hipLaunchKernelGGL(irt_refill_kernel<4>, dim3(grid), dim3(kBlock), 0, st, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, refill_min, irr);
-        } else {
-            int grid = resident_grid(irt_refill_kernel<2>, kBlock); if (want < grid) grid = (int)want;
-            hipLaunchKernelGGL(irt_refill_kernel<2>, dim3(grid), dim3(kBlock), 0, st, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, refill_min, irr);
-        }
-    } else irt_launch_one<false, 0, 24, 1>(variant >= 1, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, 0, 1, irr, stats, st);
+    const bool pow2 = (N & (N - 1)) == 0;
+    const int l2 = ilog2_exact(N);
+#define TEXIR_IRT(WAVES, L2, NAME, ...) { if (stats) irt_launch(NAME<true, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, st); \
+                                        else irt_launch(NAME<false, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, st); }
+    if (!sc.nodes4) TEXIR_IRT(n_ids, l2, irt_kernel, 2)                                        // deep binary tree (capi.hip fallback)
+    else if (variant == 1) TEXIR_IRT(n_ids, l2, irt_kernel, 4)
+    else if (variant == 7 && pow2 && l2 >= 7) TEXIR_IRT((n_ids + 15) / 16, l2, irt_group_kernel, 4, 4)
+    else TEXIR_IRT((n_ids + 63) / 64, pow2 ? l2 : -1, irt_group_kernel, 4, 6)                  // any N (natural sample order if not 2^k)
+#undef TEXIR_IRT
     return hipGetLastError();
 }
 

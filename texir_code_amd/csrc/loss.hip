@@ -17,6 +17,11 @@
 
 namespace texir {
 
+// torch evaluates every product and difference of these formulas as a separately rounded float op; a contracted
+// fma(r, gc, -(tau*gc)) turns an exact 0 (r == tau: constant initial roughness) into a signed rounding residue and flips
+// sign() in the L1 gradient.  No contraction anywhere in this file.
+#pragma clang fp contract(off)
+
 constexpr int kLB = 256;
 constexpr uint8_t kNoClass = 255;
 

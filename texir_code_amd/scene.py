@@ -114,7 +114,7 @@ class Scene:
         if texel_ids is not None:
             ids = texel_ids.to(device=self.device, dtype=torch.int32).contiguous()
             n_ids = ids.numel()
-        st = torch.zeros(4, device=self.device, dtype=torch.int64) if stats else None
+        st = torch.zeros(8, device=self.device, dtype=torch.int64) if stats else None
         _lib.check(_lib.lib().texir_irt_generate(self.h, _lib.ptr(pos), _lib.ptr(nrm), _lib.ptr(shift), _lib.ptr(ids), n_ids, Nt,
                                                  int(n_samples), MODES[mode], _lib.ptr(out), _lib.ptr(st), _lib.stream_ptr()))
         return (out, st) if stats else out
