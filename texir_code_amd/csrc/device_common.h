@@ -136,43 +136,69 @@ __device__ __forceinline__ void shade_hit(const SceneDev& sc, int tri_slot, floa
 // ------------------------------------------------------------------------------------------------
 struct Hit { float t, u, v; int slot; };
 
-template <bool STATS, int LSTK = kLdsStack, int WIDTH = 2>
-__device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float oy, float oz, float dx, float dy, float dz,
-                                             uint32_t& n_nodes, uint32_t& n_tris, uint32_t* wave_iters = nullptr)
+// Per-lane traversal state.  A ray is started with ray_begin() and advanced with traverse(); node == kSentinel <=> finished.
+struct RayState {
+    float dx, dy, dz, idx, idy, idz, oodx, oody, oodz;
+    Hit h;
+    int node, sp;
+};
+
+__device__ __forceinline__ void ray_begin(RayState& r, float ox, float oy, float oz, float dx, float dy, float dz)
+{
+    const float ooeps = 8.271806e-25f;  // 2^-80
+    r.dx = dx; r.dy = dy; r.dz = dz;
+    r.idx = __builtin_amdgcn_rcpf(fabsf(dx) > ooeps ? dx : copysignf(ooeps, dx));
+    r.idy = __builtin_amdgcn_rcpf(fabsf(dy) > ooeps ? dy : copysignf(ooeps, dy));
+    r.idz = __builtin_amdgcn_rcpf(fabsf(dz) > ooeps ? dz : copysignf(ooeps, dz));
+    r.oodx = ox * r.idx; r.oody = oy * r.idy; r.oodz = oz * r.idz;
+    r.h.t = __builtin_inff(); r.h.u = 0.f; r.h.v = 0.f; r.h.slot = -1;
+    r.node = 0; r.sp = 0;
+}
+
+struct NeverLeave { static constexpr bool never = true; __device__ bool operator()(int) const { return false; } };
+
+// Advances the rays of a wave in whole while-while rounds (node steps until every lane is at a leaf, then triangle steps
+// until every lane is back at a node) until all lanes have finished, or until leave(node) -- evaluated once per round with
+// the lane's current node -- is true (it must be wave-uniform and define `static constexpr bool never = false`; a persistent
+// kernel can use it to hand finished lanes their next ray -- measured slower than lock-step passes).  One instance per kernel (it owns the LDS part of the stacks); `ovf` is the caller's private overflow.
+template <bool STATS, int LSTK, int WIDTH, typename Leave>
+__device__ __forceinline__ void traverse(const SceneDev& sc, RayState& r, int (&ovf)[kStackCap - LSTK], float ox, float oy, float oz,
+                                         uint32_t& n_nodes, uint32_t& n_tris, uint32_t* wave_iters, Leave leave)
 {
     // STATS: n_nodes / n_tris count this lane's node fetches and triangle tests; wave_iters[0/1] (if given) count, on the first
     // active lane, how many times the wave executed the node-step and the triangle-step bodies (for lane-utilisation figures)
     auto first_active = [&]() -> bool { unsigned long long m = __ballot(1); return (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1; };
-    // the traversal stack: LSTK entries per lane in LDS ([entry][thread], one instance per kernel), deeper ones private
+    // the traversal stack: LSTK entries per lane in LDS ([entry][thread]), deeper ones private.  The stack pointer is kept as
+    // the LDS address of the next free entry (push = ds_write + one add, no index scaling in the node step).
     __shared__ int lds_all[LSTK * kBlock];
-    int* lds_stack = lds_all + threadIdx.x;
-    const float ooeps = 8.271806e-25f;  // 2^-80
-    float idx = __builtin_amdgcn_rcpf(fabsf(dx) > ooeps ? dx : copysignf(ooeps, dx));
-    float idy = __builtin_amdgcn_rcpf(fabsf(dy) > ooeps ? dy : copysignf(ooeps, dy));
-    float idz = __builtin_amdgcn_rcpf(fabsf(dz) > ooeps ? dz : copysignf(ooeps, dz));
-    float oodx = ox * idx, oody = oy * idy, oodz = oz * idz;
-    Hit h; h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f; h.slot = -1;
-    int ovf[kStackCap - LSTK];
-    int sp = 0;
-    int node = 0;
+    int* const base = lds_all + threadIdx.x;
+    int* const lim = base + LSTK * kBlock;
+    int* top = base + r.sp * kBlock;
+    const float dx = r.dx, dy = r.dy, dz = r.dz, idx = r.idx, idy = r.idy, idz = r.idz, oodx = r.oodx, oody = r.oody, oodz = r.oodz;
+    Hit h = r.h;
+    int node = r.node;
     // LDS part and private overflow are kept in separate, wave-uniformly guarded code paths: the overflow is almost never
     // touched (depth > LSTK), and hipcc must not merge the two address spaces into one flat access
     auto push = [&](int x) {
-        if (sp < LSTK) lds_stack[sp * kBlock] = x;
-        if (__any(sp >= LSTK)) { if (sp >= LSTK) ovf[sp - LSTK] = x; }
-        sp++;
+        if (top < lim) *top = x;
+        if (__any(top >= lim)) { if (top >= lim) ovf[(top - lim) / kBlock] = x; }
+        top += kBlock;
     };
     auto pop = [&]() -> int {
-        if (sp == 0) return kSentinel;
-        sp--;
-        int v = lds_stack[(sp < LSTK ? sp : LSTK - 1) * kBlock];
-        if (__any(sp >= LSTK)) { int b = ovf[sp >= LSTK ? sp - LSTK : 0]; v = sp >= LSTK ? b : v; }
+        if (top == base) return kSentinel;
+        top -= kBlock;
+        int v = *(top < lim ? top : lim - kBlock);
+        if (__any(top >= lim)) { int b = ovf[top >= lim ? (top - lim) / kBlock : 0]; v = top >= lim ? b : v; }
         return v;
     };
-    while (node != kSentinel) {
+    for (;;) {
+        // run-to-completion callers: plain per-lane loop.  Resumable callers: wave-uniform loop control -- finished lanes stay in
+        // the loop, masked off by the inner loops, so that leave() sees them
+        if (Leave::never ? node == kSentinel : (!__any(node != kSentinel) || leave(node))) break;
         if (WIDTH == 4) {
             while (node >= 0 && node != kSentinel) {
-                const float4* np = sc.nodes4 + 4 * (size_t)node;
+                // (uniform base + 32-bit byte offset: one VALU op of address arithmetic, saddr-form loads)
+                const float4* np = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.nodes4) + ((uint32_t)node << 6));
                 const float4 q0 = np[0];
                 const uint4 q1 = *reinterpret_cast<const uint4*>(np + 1);
                 const uint4 q2 = *reinterpret_cast<const uint4*>(np + 2);
@@ -203,13 +229,13 @@ __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float
                 TEXIR_CSWAP(0, 1) TEXIR_CSWAP(2, 3) TEXIR_CSWAP(0, 2) TEXIR_CSWAP(1, 3) TEXIR_CSWAP(1, 2)
 #undef TEXIR_CSWAP
                 const float inf = __builtin_inff();
-                if (!__any(sp + 3 > LSTK)) {
+                if (!__any(top + 3 * kBlock > lim)) {
                     // common case (one wave-uniform test per node): the whole update stays inside the LDS part of the stack
-                    if (key[3] < inf) { lds_stack[sp * kBlock] = code[3]; sp++; }
-                    if (key[2] < inf) { lds_stack[sp * kBlock] = code[2]; sp++; }
-                    if (key[1] < inf) { lds_stack[sp * kBlock] = code[1]; sp++; }
+                    if (key[3] < inf) { *top = code[3]; top += kBlock; }
+                    if (key[2] < inf) { *top = code[2]; top += kBlock; }
+                    if (key[1] < inf) { *top = code[1]; top += kBlock; }
                     if (key[0] < inf) node = code[0];
-                    else if (sp > 0) { sp--; node = lds_stack[sp * kBlock]; }
+                    else if (top != base) { top -= kBlock; node = *top; }
                     else node = kSentinel;
                 } else {
                     if (key[3] < inf) push(code[3]);
@@ -244,10 +270,11 @@ __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float
             }
 }
         while (node < 0) {
-            uint32_t code = ~(uint32_t)node;
+            const uint32_t code = ~(uint32_t)node;
+            node = pop();
             int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
             for (int i = first; i < first + cnt; i++) {
-                const float4* tp = sc.tris + 3 * (size_t)i;
+                const float4* tp = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.tris) + (uint32_t)i * 48u);
                 float4 v0 = tp[0], e1 = tp[1], e2 = tp[2];
                 if (STATS) { n_tris++; if (wave_iters && first_active()) wave_iters[1]++; }
                 // Moeller-Trumbore, same operation order as the oracle
@@ -262,10 +289,21 @@ __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float
                 bool ok = (det != 0.f) & (u >= 0.f) & (u <= 1.f) & (v >= 0.f) & (u + v <= 1.f) & (t > 0.f) & (t < h.t);
                 if (ok) { h.t = t; h.u = u; h.v = v; h.slot = i; }
             }
-            node = pop();
         }
     }
-    return h;
+    r.h = h; r.sp = (int)(top - base) / kBlock; r.node = node;
+}
+
+// closest hit of one ray per lane, run to completion
+template <bool STATS, int LSTK = kLdsStack, int WIDTH = 2>
+__device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float oy, float oz, float dx, float dy, float dz,
+                                             uint32_t& n_nodes, uint32_t& n_tris, uint32_t* wave_iters = nullptr)
+{
+    RayState r;
+    ray_begin(r, ox, oy, oz, dx, dy, dz);
+    int ovf[kStackCap - LSTK];
+    traverse<STATS, LSTK, WIDTH>(sc, r, ovf, ox, oy, oz, n_nodes, n_tris, wave_iters, NeverLeave());
+    return r.h;
 }
 
 __device__ __forceinline__ float wave_sum(float x)
