@@ -278,7 +278,7 @@ def main():
                 traffic = tj.get("hbm_bytes_per_step", 0) / launches if "hbm_bytes_per_step" in tj else tj.get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                               "kernel": "irt_kernel", "launches_per_step": launches, "kernel_ms": round(kern_ms / launches, 4),
+                               "kernel": "irt_group_kernel<false, 4, 6>", "launches_per_step": launches, "kernel_ms": round(kern_ms / launches, 4),
                                "kernel_ms_per_step": round(kern_ms, 3), "bytes_per_ray": round(bpr, 1),
                                "nodes_per_ray": round(nbar, 2), "tris_per_ray": round(tbar, 2), "p_hit": round(phit, 4),
                                "rays_per_launch": rays_this_rank // launches}
