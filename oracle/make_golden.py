@@ -13,6 +13,7 @@ Fixtures (SURVEY.md 8c pins):
   render_loss.npz  models/loss.py:81-115,214-295 RenderLoss stages 0/1/2, values + grads
   cube2pano.npz    utils/Cube2Pano.py:119-144 ToPano
   mat_trajectory.npz  trainer/train_material.py:245-356,408-605 the trainer loop itself (3 steps per stage) on a pixel-parameter model
+  nirf.npz         models/tracer_o3d_irrf.py:72-136 forward (GT irradiance at mesh points + MatNetwork prediction), models/loss.py:28-52 IRFLoss
 """
 import os
 import sys
@@ -364,7 +365,53 @@ def mat_trajectory():
     print("steps:", len(log["loss"]), "losses:", np.round(log["loss"], 5))
 
 
+def nirf():
+    """the reference's NIrF model forward (tracer_o3d_irrf.py:72-136): traced GT irradiance at random mesh points + the
+    PE-10 MLP's prediction (weights saved with the fixture), and IRFLoss on the result"""
+    import models.tracer_o3d_irrf as ref_irrf
+    import models.incidentNet as ref_net
+    sc = synth.make_scene(2000, seed=31, tex_res=128)
+    rng = np.random.default_rng(3)
+    b, res = 96, [8, 16]
+    # points on the mesh, offset along the face normal like MeshPoint.sample_mesh (datasets/dataset.py:72-80)
+    tri = sc["tris"][rng.integers(0, len(sc["tris"]), b)]
+    w = rng.dirichlet([1, 1, 1], b).astype(np.float32)
+    v = sc["verts"][tri]
+    p = (v * w[:, :, None]).sum(1)
+    n = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    inward = np.sign(((sc["verts"].mean(0)[None] - p) * n).sum(-1, keepdims=True))
+    n = (n * inward).astype(np.float32)
+    p = (p + 1e-2 * n).astype(np.float32)
+    osc = O.Scene(sc["verts"], sc["tris"], sc["tri_uvs"], sc["hdr"])
+    m = object.__new__(ref_irrf.TracerO3d)
+    torch.nn.Module.__init__(m)
+    torch.manual_seed(77)
+    m.ir_radiance_network = ref_net.MatNetwork(points_multires=10, p_input_dim=3, p_out_dim=3, dims=[64, 64, 64, 64])
+    m.std_jit = 5e-2
+    m.scene = IR.FakeScene(osc, "brute")
+    m.triangle_uvs = sc["tri_uvs"].astype(np.float64)
+    m.texture = torch.from_numpy(sc["hdr"]).permute(2, 0, 1).unsqueeze(0).float()
+    # the reference samples the jitter with device="cuda": CPU stand-in that consumes the same generator stream
+    real_normal = torch.normal
+    torch.normal = lambda mean=0, std=1, size=None, device=None, **k: real_normal(mean, std, size)
+    real_get_device = torch.Tensor.get_device
+    torch.Tensor.get_device = lambda self: "cpu"          # (tensor.get_device() is -1 on the CPU; the reference passes it as device=)
+    torch.manual_seed(123)
+    out = m(torch.from_numpy(p), torch.from_numpy(n), res)
+    torch.normal = real_normal
+    torch.Tensor.get_device = real_get_device
+    torch.manual_seed(123)
+    shift = torch.rand(b, 1, 1, 2).reshape(b, 2)
+    loss_l1 = ref_loss.IRFLoss("L1")(out)
+    loss_l2 = ref_loss.IRFLoss("L2")(out)
+    sd = {("w_" + k.replace(".", "_")): v.numpy() for k, v in m.ir_radiance_network.state_dict().items()}
+    save("nirf.npz", verts=sc["verts"], tris=sc["tris"], tri_uvs=sc["tri_uvs"], hdr=sc["hdr"], points=p, normals=n, res=np.array(res),
+         shift=shift.numpy(), gt=out["gt"].detach().numpy(), pred=out["pred"].detach().numpy(), loss_l1=loss_l1.item(), loss_l2=loss_l2.item(),
+         **sd)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gen_dir", "spec_render", "query_irf", "irt_box", "irt_room", "render_loss", "cube2pano", "mat_trajectory"]
+    which = sys.argv[1:] or ["gen_dir", "spec_render", "query_irf", "irt_box", "irt_room", "render_loss", "cube2pano", "mat_trajectory", "nirf"]
     for w in which:
         globals()[w]()

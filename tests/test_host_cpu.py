@@ -142,8 +142,10 @@ def test_plugin_registry_and_cli_surface():
     assert (o.conf, o.exps_folder_name, o.expname, o.trainstage, o.frame_skip, o.max_niter, o.is_continue, o.timestamp, o.checkpoint, o.gpu) == \
         ("", "exps", "", "IRF", 1, 200001, False, "latest", "latest", "auto")
     assert set(ER.ALL_STAGES) == {"IRF", "Mat", "IRRF", "PIL", "Inv", "Neilf", "IrrT", "RecMLP", "MatSyn", "RecMLPSyn", "NeilfSyn", "InvSyn"}
-    for st in ("IrrT", "Mat", "MatSyn"):
-        assert ER.runner_class(st).__name__ in ("IrrTextureRunner", "MatTrainRunner", "MatTrainSynRunner")
+    for st in ("IrrT", "Mat", "MatSyn", "IRRF"):
+        assert ER.runner_class(st).__name__ in ("IrrTextureRunner", "MatTrainRunner", "MatTrainSynRunner", "IRRFTrainRunner")
+    assert plugin.get_class("models.tracer_o3d_irrf.TracerO3d").__name__ == "TracerO3dIrrF"
+    assert plugin.get_class("models.loss.IRFLoss").__name__ == "IRFLoss"
     with pytest.raises(NotImplementedError):
         ER.runner_class("Neilf")
 

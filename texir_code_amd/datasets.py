@@ -161,3 +161,102 @@ def render_gt_views(root, conf, sc, albedo_res, rough_res, seed=666):
             np.savez_compressed(os.path.join(root, "cube", "%s.npz" % vid), color=res["rgb"].cpu().numpy(),
                                 mask=res["empty_mask"].cpu().numpy(), segs=segs.cpu().numpy())
     return alb, rgh
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# NIrF datasets
+# ---------------------------------------------------------------------------------------------------------------------
+def _vertex_normals(vertices, indices):
+    """area-weighted vertex normals (Open3D compute_vertex_normals: sum of un-normalised face normals, then normalise)"""
+    v = vertices[indices]
+    fn = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+    vn = np.zeros_like(vertices, dtype=np.float64)
+    for k in range(3):
+        np.add.at(vn, indices[:, k], fn)
+    ln = np.linalg.norm(vn, axis=-1, keepdims=True)
+    return (vn / np.maximum(ln, 1e-20)).astype(np.float32), fn
+
+
+class MeshPoint(Dataset):
+    """datasets/dataset.py:39-92: `num_sample` points drawn uniformly (by area) on the mesh with interpolated vertex normals,
+    moved `delta` along the normal; change_points() redraws them (called once per epoch, train_irrf.py:237).
+    Open3D's sample_points_uniformly uses its own RNG; here numpy's global generator (the runners seed it)."""
+
+    def __init__(self, path_mesh, num_sample, delta=1e-2):
+        super().__init__()
+        self.path_mesh, self.num_sample, self.delta = path_mesh, int(num_sample), delta
+        obj = IO.load_obj(path_mesh)
+        self.vertices, self.indices = obj["vertices"].astype(np.float32), obj["indices"]
+        self.vertex_normals, fn = _vertex_normals(self.vertices.astype(np.float64), self.indices)
+        area = 0.5 * np.linalg.norm(fn, axis=-1)
+        self.cdf = np.cumsum(area / area.sum())
+        self.AABB = np.stack([self.vertices.min(0), self.vertices.max(0)], axis=0)
+        self.points = self.normals = None
+
+    def __len__(self):
+        return self.num_sample
+
+    def sample_mesh(self):
+        t = np.minimum(np.searchsorted(self.cdf, np.random.rand(self.num_sample)), len(self.indices) - 1)
+        r1, r2 = np.sqrt(np.random.rand(self.num_sample, 1)), np.random.rand(self.num_sample, 1)
+        w = np.concatenate([1 - r1, r1 * (1 - r2), r1 * r2], axis=-1)            # uniform barycentrics
+        tri = self.indices[t]
+        p = (self.vertices[tri] * w[..., None]).sum(1)
+        n = (self.vertex_normals[tri] * w[..., None]).sum(1)
+        n = n / np.maximum(np.linalg.norm(n, axis=-1, keepdims=True), 1e-20)
+        return (p + n * self.delta).astype(np.float32), n.astype(np.float32)
+
+    def change_points(self):
+        self.points, self.normals = self.sample_mesh()
+
+    def get_AABB(self):
+        return self.AABB
+
+    def __getitem__(self, index):
+        return {"point": torch.from_numpy(self.points[index]), "normal": torch.from_numpy(self.normals[index])}
+
+
+class ImageMeshPoint(Dataset):
+    """datasets/dataset.py:96-260: the validation set is the G-buffer (position + delta*normal, normal) of ONE equirectangular
+    view, one sample per pixel.  The reference rasterises it with pyredner from a hard-coded capture of its private scene;
+    here the view is the first row of `<root>/cameras.txt` when present, else the AABB centre, and the G-buffer is ray cast
+    (texir_trace_shade hit records) when arrange_buffers() is first called."""
+
+    def __init__(self, path_mesh, resolution=(128, 256), delta=1e-2, scene=None, eye=None):
+        super().__init__()
+        self.path_mesh, self.resolution, self.delta = path_mesh, [int(resolution[0]), int(resolution[1])], delta
+        self.scene, self.eye = scene, eye
+        self.points = self.normals = None
+
+    def __len__(self):
+        return self.resolution[0] * self.resolution[1]
+
+    def arrange_buffers(self):
+        if self.points is not None:
+            return
+        from .scene import Scene
+        obj = IO.load_obj(self.path_mesh)
+        if self.scene is None:
+            self.scene = Scene(obj["vertices"], obj["indices"], IO.triangle_uvs_open3d(obj), np.zeros((2, 2, 3), np.float32))
+        if self.eye is None:
+            self.eye = 0.5 * (obj["vertices"].min(0) + obj["vertices"].max(0))
+        h, w = self.resolution
+        # equirectangular directions, y up: row 0 = zenith, column 0 = -x ... (utils/Cube2Pano.py convention)
+        theta = (torch.arange(h, dtype=torch.float32) + 0.5) / h * np.pi
+        phi = (torch.arange(w, dtype=torch.float32) + 0.5) / w * 2 * np.pi - np.pi
+        theta, phi = torch.meshgrid(theta, phi, indexing="ij")
+        d = torch.stack([torch.sin(theta) * torch.sin(phi), torch.cos(theta), -torch.sin(theta) * torch.cos(phi)], -1).reshape(-1, 3)
+        o = torch.from_numpy(np.asarray(self.eye, np.float32)).expand_as(d).contiguous()
+        _, t, pid, _ = self.scene.trace_shade(o, d, return_hits=True)
+        t, pid = t.cpu(), pid.cpu().long()
+        hit = torch.isfinite(t) & (pid >= 0)
+        p = o + d * torch.where(hit, t, torch.zeros_like(t))[:, None]
+        v = torch.from_numpy(obj["vertices"].astype(np.float32))[torch.from_numpy(obj["indices"].astype(np.int64))[pid.clamp(min=0)]]
+        n = torch.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0], dim=-1)
+        n = n / n.norm(dim=-1, keepdim=True).clamp(min=1e-20)
+        n = torch.where(((n * d).sum(-1, keepdim=True) > 0), -n, n)                  # face the viewer
+        n = torch.where(hit[:, None], n, torch.zeros_like(n))
+        self.points, self.normals = (p + self.delta * n).numpy(), n.numpy()
+
+    def __getitem__(self, index):
+        return {"point": torch.from_numpy(self.points[index]), "normal": torch.from_numpy(self.normals[index])}

@@ -230,3 +230,39 @@ def write_obj(path, vertices, indices, tri_uvs, tri_normals=None):
                 f.write("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (a, k, k, b, k + 1, k + 1, c, k + 2, k + 2))
             else:
                 f.write("f %d/%d %d/%d %d/%d\n" % (a, k, b, k + 1, c, k + 2))
+
+
+def obj_texture_path(path_obj):
+    """the diffuse texture map an OBJ refers to: last `map_Kd` of its `mtllib` (Open3D: trianglemesh.textures, used by
+    models/tracer_o3d_irrf.py:59 when the scene has no HDR texture).  None if the OBJ names no material library/map."""
+    import os
+    mtl = None
+    with open(path_obj, "r", errors="replace") as f:
+        for line in f:
+            if line.startswith("mtllib"):
+                mtl = line.split(None, 1)[1].strip()
+                break
+    if mtl is None:
+        return None
+    mtl = os.path.join(os.path.dirname(path_obj), mtl)
+    if not os.path.exists(mtl):
+        return None
+    tex = None
+    with open(mtl, "r", errors="replace") as f:
+        for line in f:
+            t = line.strip()
+            if t.startswith("map_Kd"):
+                tex = t.split()[-1]
+    return os.path.join(os.path.dirname(mtl), tex) if tex else None
+
+
+def read_ldr(path):
+    """8/16-bit image -> [H,W,3] uint array, RGB.  PNG through the in-tree decoder; other formats need Pillow."""
+    if path.lower().endswith(".png"):
+        return read_png(path)[..., :3]
+    try:
+        from PIL import Image
+    except ImportError as e:
+        raise ValueError("%s: only PNG textures can be decoded without Pillow" % path) from e
+    import numpy as np
+    return np.asarray(Image.open(path).convert("RGB"))

@@ -10,11 +10,17 @@ _REGISTRY = {
     "models.loss.RenderLoss": "texir_code_amd.loss.RenderLoss",
     "datasets.dataset.ImageCubeDerived": "texir_code_amd.datasets.SynCubeDataset",
     "datasets.dataset.ImageCubeSyn": "texir_code_amd.datasets.SynCubeDataset",
+    # NIrF slice
+    "models.tracer_o3d_irrf.TracerO3d": "texir_code_amd.nirf.TracerO3dIrrF",
+    "models.incidentNet.MatNetwork": "texir_code_amd.nirf.MatNetwork",
+    "models.loss.IRFLoss": "texir_code_amd.nirf.IRFLoss",
+    "datasets.dataset.MeshPoint": "texir_code_amd.datasets.MeshPoint",
+    "datasets.dataset.ImageMeshPoint": "texir_code_amd.datasets.ImageMeshPoint",
 }
 
 # everything else the reference registers is a baseline / alternative lighting representation: out of scope
 _OUT_OF_SCOPE = ("models.mat_nvdiffrast_", "models.mat_redner", "models.mat_mlp", "models.tracer_o3d.", "models.tracer_o3d_pil",
-                 "models.tracer_o3d_irrf", "models.incidentNet", "models.test_")
+                 "models.incidentNet", "models.test_")
 
 
 def get_class(kls):

@@ -8,7 +8,7 @@ import os
 
 import torch
 
-IN_SCOPE = ("IrrT", "Mat", "MatSyn")
+IN_SCOPE = ("IrrT", "Mat", "MatSyn", "IRRF")
 ALL_STAGES = ("IRF", "Mat", "IRRF", "PIL", "Inv", "Neilf", "IrrT", "RecMLP", "MatSyn", "RecMLPSyn", "NeilfSyn", "InvSyn")
 
 
@@ -49,8 +49,9 @@ def runner_class(stage):
         raise NotImplementedError("--trainstage %s is outside the IrT + material-estimation hot path this build covers (in scope: %s)"
                                   % (stage, ", ".join(IN_SCOPE)))
     from .generate_ir_texture import IrrTextureRunner
+    from .train_irrf import IRRFTrainRunner
     from .train_material import MatTrainRunner, MatTrainSynRunner
-    return {"IrrT": IrrTextureRunner, "Mat": MatTrainRunner, "MatSyn": MatTrainSynRunner}[stage]
+    return {"IrrT": IrrTextureRunner, "Mat": MatTrainRunner, "MatSyn": MatTrainSynRunner, "IRRF": IRRFTrainRunner}[stage]
 
 
 def main(argv=None):
