@@ -73,6 +73,13 @@ class FakeScene:
                 "primitive_uvs": FakeO3dTensor(uv.reshape(shp + (2,)))}
 
 
+def patch_cv2_rodrigues():
+    """utils/Pano2Cube.py:41-47 calls cv2.Rodrigues on axis-angle vectors: answer it with scipy's rotation-vector conversion
+    (an implementation independent of texir_code_amd.pano2cube.rodrigues)"""
+    from scipy.spatial.transform import Rotation
+    sys.modules["cv2"].Rodrigues = lambda v: (Rotation.from_rotvec(np.asarray(v, np.float64)).as_matrix().astype(np.float32), None)
+
+
 def patch_o3d_tensor():
     """o3d.core.Tensor(ndarray, dtype=...) -> FakeO3dTensor"""
     o3d = sys.modules["open3d"]

@@ -13,6 +13,7 @@ Fixtures (SURVEY.md 8c pins):
   render_loss.npz  models/loss.py:81-115,214-295 RenderLoss stages 0/1/2, values + grads
   cube2pano.npz    utils/Cube2Pano.py:119-144 ToPano
   mat_trajectory.npz  trainer/train_material.py:245-356,408-605 the trainer loop itself (3 steps per stage) on a pixel-parameter model
+  pano2cube.npz    utils/Pano2Cube.py:24-102 grids + Tocube (nearest and bilinear); cv2.Rodrigues answered by scipy
   nirf.npz         models/tracer_o3d_irrf.py:72-136 forward (GT irradiance at mesh points + MatNetwork prediction), models/loss.py:28-52 IRFLoss
 """
 import os
@@ -365,6 +366,16 @@ def mat_trajectory():
     print("steps:", len(log["loss"]), "losses:", np.round(log["loss"], 5))
 
 
+def pano2cube():
+    IR.patch_cv2_rodrigues()
+    import utils.Pano2Cube as ref_p2c
+    torch.manual_seed(9)
+    p2c = ref_p2c.Pano2Cube(1, 64, 32, 8, 5)
+    pano = torch.randn(1, 5, 32, 64)
+    save("pano2cube.npz", pano=pano.numpy(), uv=torch.stack([u[0] for u in p2c.uv]).numpy(),
+         cube_nearest=p2c.Tocube(pano, mode="nearest").numpy(), cube_bilinear=p2c.Tocube(pano, mode="bilinear").numpy())
+
+
 def nirf():
     """the reference's NIrF model forward (tracer_o3d_irrf.py:72-136): traced GT irradiance at random mesh points + the
     PE-10 MLP's prediction (weights saved with the fixture), and IRFLoss on the result"""
@@ -412,6 +423,6 @@ def nirf():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gen_dir", "spec_render", "query_irf", "irt_box", "irt_room", "render_loss", "cube2pano", "mat_trajectory", "nirf"]
+    which = sys.argv[1:] or ["gen_dir", "spec_render", "query_irf", "irt_box", "irt_room", "render_loss", "cube2pano", "mat_trajectory", "pano2cube", "nirf"]
     for w in which:
         globals()[w]()

@@ -15,11 +15,20 @@ from torch.utils.data import Dataset
 from . import cameras, io_formats as IO
 
 
+def find_root(path_mesh):
+    """the directory that holds info/aligned.txt: the reference uses dirname(dirname(path_mesh)) (datasets/dataset.py:356, mesh at
+    <root>/hdr_texture/out1.obj); write_synthetic_dataset() nests the mesh one level deeper (<root>/vrproc/hdr_texture/out1.obj)"""
+    two = os.path.dirname(os.path.dirname(path_mesh))
+    if os.path.exists(os.path.join(two, "info", "aligned.txt")):
+        return two
+    return os.path.dirname(two)
+
+
 class SynCubeDataset(Dataset):
     def __init__(self, path_mesh, resolution=[1000, 2000], hdr_exposure=1.0):
         super().__init__()
         self.path_mesh = path_mesh
-        self.path_root = os.path.dirname(os.path.dirname(os.path.dirname(path_mesh)))     # <root>/vrproc/hdr_texture/out1.obj
+        self.path_root = find_root(path_mesh)
         self.resolution = resolution
         self.cube_res = int(resolution[1] / 4)
         self.hdr_exposure = hdr_exposure
@@ -64,6 +73,105 @@ class SynCubeDataset(Dataset):
             items.append({"color": torch.from_numpy(z["color"]) * (2 ** self.hdr_exposure), "mask": torch.from_numpy(z["mask"]),
                           "segs": torch.from_numpy(z["segs"])})
         return items
+
+
+def _read_pano_rgba(path):
+    """cv2.imread(path, -1) of the (4-channel) panorama; the reference's file is named .jpg, so decode by content"""
+    with open(path, "rb") as f:
+        magic = f.read(8)
+    if magic.startswith(b"\x89PNG"):
+        return IO.read_png(path)
+    try:
+        from PIL import Image
+    except ImportError as e:
+        raise ValueError("%s is not a PNG: Pillow is needed to decode it" % path) from e
+    return np.asarray(Image.open(path))
+
+
+class ImageCubeDerived(SynCubeDataset):
+    """datasets/dataset.py:352-549 on the reference's raw layout:
+        <root>/info/aligned.txt, final_extrinsics.txt
+        <root>/derived/<id>/panoImage_orig.jpg (RGBA, alpha = validity), panoImage_gray.png (class ids)
+        <root>/hdr/<id>/ccm.hdr (Radiance RGBE)
+    Per view: colour * 2^exposure, alpha eroded 5x5 and /255, class ids nearest-resized to the panorama, Sobel gradient magnitude
+    of the grey image -- all warped to six cube faces with Pano2Cube (nearest).  Falls back to the cube/<id>.npz files of
+    write_synthetic_dataset() when the raw directories are absent."""
+
+    pano_hw = (4000, 8000)               # Pano2Cube(1, 4000, 8000, ...): only stored, the warp grid is resolution-free (:361)
+
+    def _raw_path(self, i):
+        return os.path.join(self.path_root, "derived", i, "panoImage_orig.jpg")
+
+    def read_images(self, ids):
+        if not ids or not os.path.exists(self._raw_path(ids[0])):
+            return super().read_images(ids)
+        from . import imgops as cv
+        from .pano2cube import Pano2Cube
+        self.pano2cube = Pano2Cube(1, self.pano_hw[0], self.pano_hw[1], self.cube_res, 6)
+        items = []
+        for i in ids:
+            rgba = _read_pano_rgba(self._raw_path(i))
+            h, w = rgba.shape[:2]
+            mask = rgba[:, :, 3:4]
+            color = IO.read_hdr(os.path.join(self.path_root, "hdr", i, "ccm.hdr"))              # RGB
+            color = np.clip(color, 0.0, np.finfo(np.float32).max) * np.float32(2 ** self.hdr_exposure)
+            gx, gy = cv.sobel3(cv.gray(color, "RGB"))
+            rgb_grad = cv.magnitude(gx, gy)
+            mask = cv.erode(mask, 5).astype(np.float32) / 255.0                                     # [h, w]
+            segs = IO.read_png(os.path.join(self.path_root, "derived", i, "panoImage_gray.png"))
+            if segs.ndim == 3:
+                segs = segs[..., 0]
+            segs = cv.resize_nearest(segs, (w, h)).astype(np.float32)
+            img = np.concatenate([color, mask[..., None], segs[..., None], rgb_grad[..., None]], axis=-1)
+            c = img.shape[-1]
+            cube = self.pano2cube.Tocube(torch.from_numpy(img).permute(2, 0, 1).reshape(1, c, h, w), mode="nearest")
+            faces = cube[0].reshape(6, c, self.cube_res, self.cube_res).permute(0, 2, 3, 1)
+            item = {"color": faces[..., 0:3].contiguous(), "mask": faces[..., 3:4].contiguous(), "segs": faces[..., 4:5].contiguous(),
+                    "rgb_grad": faces[..., 5:6].contiguous()}
+            item.update(self._extra(i, segs))
+            items.append(item)
+        return items
+
+    def _extra(self, i, segs):
+        return {}
+
+    def __getitem__(self, index):
+        it = super().__getitem__(index)
+        for k in ("rgb_grad", "gt_albedo", "gt_roughness"):
+            if k in self.images_items[index]:
+                it[k] = self.images_items[index][k]
+        return it
+
+
+class ImageCubeSyn(ImageCubeDerived):
+    """datasets/dataset.py:669-893: as above plus ground-truth albedo.png / roughness.png panoramas (resized to 4c x 2c, albedo
+    sRGB -> linear) and the novel-view list (info/novel.txt, info/novel_extrinsics.txt) when present"""
+
+    pano_hw = (512, 1024)
+
+    def __init__(self, path_mesh, resolution=[1000, 2000], hdr_exposure=1.0):
+        super().__init__(path_mesh, resolution, hdr_exposure)
+        self.novel_ids, self.novel_extrinsics_list, self.novel_cam_position_list, self.novel_images_items = [], [], [], []
+        if os.path.exists(os.path.join(self.path_root, "info", "novel.txt")):
+            self.novel_ids = self.read_id("novel.txt")
+            self.novel_extrinsics_list, self.novel_cam_position_list = self.read_extrinsic("novel_extrinsics.txt")
+            self.novel_images_items = self.read_images(self.novel_ids)
+
+    def _extra(self, i, segs):
+        from . import imgops as cv
+        size = (self.cube_res * 4, self.cube_res * 2)
+        out = {"segs_pano": torch.from_numpy(cv.resize_nearest(segs, size)[..., None])}
+        pa = os.path.join(self.path_root, "derived", i, "albedo.png")
+        if os.path.exists(pa):
+            alb = cv.resize_linear(IO.read_png(pa)[..., :3], size).astype(np.float32) / 255.0
+            out["gt_albedo"] = torch.from_numpy(alb ** np.float32(2.2))
+        pr = os.path.join(self.path_root, "derived", i, "roughness.png")
+        if os.path.exists(pr):
+            rough = IO.read_png(pr)
+            if rough.ndim == 3 and rough.shape[2] == 1:
+                rough = rough[..., 0]                        # cv2.imread(-1) returns [h, w] for a single-channel file
+            out["gt_roughness"] = torch.from_numpy(cv.resize_linear(rough, size).astype(np.float32) / 255.0)
+        return out
 
 
 def parse_roomseg(path):

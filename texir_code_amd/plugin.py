@@ -8,8 +8,8 @@ _REGISTRY = {
     "models.tracer_o3d_irt.TracerO3d": "texir_code_amd.models.TracerO3d",
     "models.mat_nvdiffrast.MaterialModel": "texir_code_amd.models.MaterialModel",
     "models.loss.RenderLoss": "texir_code_amd.loss.RenderLoss",
-    "datasets.dataset.ImageCubeDerived": "texir_code_amd.datasets.SynCubeDataset",
-    "datasets.dataset.ImageCubeSyn": "texir_code_amd.datasets.SynCubeDataset",
+    "datasets.dataset.ImageCubeDerived": "texir_code_amd.datasets.ImageCubeDerived",
+    "datasets.dataset.ImageCubeSyn": "texir_code_amd.datasets.ImageCubeSyn",
     # NIrF slice
     "models.tracer_o3d_irrf.TracerO3d": "texir_code_amd.nirf.TracerO3dIrrF",
     "models.incidentNet.MatNetwork": "texir_code_amd.nirf.MatNetwork",
