@@ -281,7 +281,10 @@ def main():
                                "kernel": "irt_group_kernel<false, 4, 6>", "launches_per_step": launches, "kernel_ms": round(kern_ms / launches, 4),
                                "kernel_ms_per_step": round(kern_ms, 3), "bytes_per_ray": round(bpr, 1),
                                "nodes_per_ray": round(nbar, 2), "tris_per_ray": round(tbar, 2), "p_hit": round(phit, 4),
-                               "rays_per_launch": rays_this_rank // launches}
+                               "rays_per_launch": rays_this_rank // launches,
+                               # frac > 1 = the canonical algorithm's bytes are served from cache; the measured fabric-side rate is:
+                               "traffic_gbs": round(traffic / (kern_ms / launches * 1e-3) / 1e9, 1) if traffic else None,
+                               "limiter": "VALU issue in the traversal loop (DESIGN.md section 4)"}
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
