@@ -70,9 +70,12 @@ def test_trace_shade_query_irf_edge_cases(golden, tx):
     assert int(pid[3]) == -1 and math.isinf(float(t[3]))
 
 
+@pytest.mark.parametrize("per_wave", ["0", "1", "16", "64"])
 @pytest.mark.parametrize("name", ["irt_box.npz", "irt_room.npz"])
-def test_irt_matches_reference_forward(golden, tx, name):
-    """whole TracerO3d.forward loop (reference code, stub-imported) vs texir_irt_generate on identical shifts"""
+def test_irt_matches_reference_forward(golden, tx, name, per_wave, monkeypatch):
+    """whole TracerO3d.forward loop (reference code, stub-imported) vs texir_irt_generate on identical shifts, for the automatic
+    choice and for every kernel form (1 / 16 / 64 texels per wave)"""
+    monkeypatch.setenv("TEXIR_IRT_TEXELS_PER_WAVE", per_wave)
     g = golden(name)
     sc = tx.Scene(g["verts"], g["tris"], g["tri_uvs"], g["hdr"])
     ids = torch.nonzero(torch.from_numpy(g["valid"].reshape(-1)) > 0)[:, 0].cuda()

@@ -39,7 +39,7 @@ __device__ __forceinline__ void irt_stats_flush(unsigned long long* stats, int l
 }
 
 // One texel per wave: the 64 lanes trace 64 samples of the texel per pass (any N, binary or 4-wide tree).  Kept as the
-// fallback for binary trees and as TEXIR_IRT_VARIANT=1 (the A/B baseline of the multi-texel kernel below).
+// form for short texel lists (a 1024-point NIrF batch), for binary-tree scenes, and TEXIR_IRT_TEXELS_PER_WAVE=1.
 template <bool STATS, int WIDTH>
 __global__ __launch_bounds__(kBlock) void irt_kernel(SceneDev sc, const float* __restrict__ pos, const float* __restrict__ nrm,
                                                      const float* __restrict__ shift, const int32_t* __restrict__ ids, int64_t n_ids,
@@ -362,12 +362,13 @@ static int resident_grid(K kernel, int block)
     return cus * per_cu;
 }
 
-// TEXIR_IRT_VARIANT (A/B switch, default 9): 1 = one texel per wave, 7 = 16 texels per wave, 9 = 64 texels per wave
-static int irt_variant()
+// TEXIR_IRT_TEXELS_PER_WAVE = 1 | 16 | 64 forces the kernel form (A/B measurements, parity tests of each form); unset or 0 = automatic.
+// Read on every call, so a test can switch it between launches.
+static int irt_forced_texels_per_wave()
 {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("TEXIR_IRT_VARIANT"); v = e ? atoi(e) : 9; }
-    return v;
+    const char* e = getenv("TEXIR_IRT_TEXELS_PER_WAVE");
+    const int v = e ? atoi(e) : 0;
+    return (v == 1 || v == 16 || v == 64) ? v : 0;
 }
 
 int irt_launch_count(int) { return 1; }
@@ -387,14 +388,19 @@ hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, co
                       int N, int mode, float* irr, unsigned long long* stats, hipStream_t st)
 {
     if (n_ids <= 0) return hipSuccess;
-    const int variant = irt_variant();
+    const int forced = irt_forced_texels_per_wave();
     const bool pow2 = (N & (N - 1)) == 0;
     const int l2 = ilog2_exact(N);
 #define TEXIR_IRT(WAVES, L2, NAME, ...) { if (stats) irt_launch(NAME<true, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, st); \
                                         else irt_launch(NAME<false, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, st); }
+    // texels per wave: 64 when the list is long enough to fill the chip that way (5 waves x 4 SIMDs x 256 CUs), else 16, else 1 --
+    // a 1024-point NIrF batch would otherwise occupy 16 wavefronts
+    const int64_t fill = 4096;
+    int per_wave = forced ? forced : (n_ids >= 64 * fill ? 64 : (n_ids >= 16 * fill ? 16 : 1));
+    if (per_wave == 16 && !(pow2 && l2 >= 7)) per_wave = forced ? 64 : 1;
     if (!sc.nodes4) TEXIR_IRT(n_ids, l2, irt_kernel, 2)                                        // deep binary tree (capi.hip fallback)
-    else if (variant == 1) TEXIR_IRT(n_ids, l2, irt_kernel, 4)
-    else if (variant == 7 && pow2 && l2 >= 7) TEXIR_IRT((n_ids + 15) / 16, l2, irt_group_kernel, 4, 4)
+    else if (per_wave == 1) TEXIR_IRT(n_ids, l2, irt_kernel, 4)
+    else if (per_wave == 16) TEXIR_IRT((n_ids + 15) / 16, l2, irt_group_kernel, 4, 4)
     else TEXIR_IRT((n_ids + 63) / 64, pow2 ? l2 : -1, irt_group_kernel, 4, 6)                  // any N (natural sample order if not 2^k)
 #undef TEXIR_IRT
     return hipGetLastError();

@@ -1,0 +1,93 @@
+"""BASELINE.json configs[4] on one GPU: the joint NIrF -> IrT -> Mat pipeline on a 2M-triangle synthetic mesh, each stage timed.
+(The 8-GPU form shards the IrT texels / the views across ranks exactly as bench.py does; this script is the single-GPU walk-through.)
+usage: python tools/run_c5.py [--tris 2000000] [--res 4096] [--spp 2048] [--nirf-steps 50]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from texir_code_amd import conf as C, dist_util, scene as S, synth, tools  # noqa: E402
+from texir_code_amd.nirf import IRFLoss, TracerO3dIrrF  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tris", type=int, default=2000000)
+    ap.add_argument("--res", type=int, default=4096)
+    ap.add_argument("--spp", type=int, default=2048)
+    ap.add_argument("--nirf-steps", type=int, default=50)
+    ap.add_argument("--mat-steps", type=int, default=50)
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(666)
+    np.random.seed(666)
+    out = {"config": "C5 joint pipeline: %d-tri synthetic mesh, %dx%d texels, %d spp" % (a.tris, a.res, a.res, a.spp)}
+    t0 = time.perf_counter()
+    sc0 = synth.make_scene(a.tris, seed=666, tex_res=a.res)
+    out["scene_gen_s"] = round(time.perf_counter() - t0, 2)
+    t0 = time.perf_counter()
+    sc = S.Scene(sc0["verts"], sc0["tris"], sc0["tri_uvs"], sc0["hdr"], device=0)
+    out["bvh_build_upload_s"] = round(time.perf_counter() - t0, 2)
+    out["scene"] = sc.info()
+
+    # 1. NIrF: GT irradiance at random mesh points (IrT kernel) + MLP fit (stock torch)
+    cf = C.parse_string("train{ path_mesh_open3d = none\n std_jit = 5e-2 }\nmodels{ irrf_network{ dims = [512,512,512,512]\n p_input_dim = 3\n p_out_dim = 3 } }")
+    m = TracerO3dIrrF(cf, scene=sc).cuda()
+    opt = torch.optim.Adam(m.ir_radiance_network.parameters(), lr=5e-4)
+    lossf = IRFLoss("L1")
+    pos, nrm, valid = synth.make_texel_gbuffer(sc0, a.res)
+    vid = np.flatnonzero(valid.reshape(-1) > 0)
+    P, N = torch.from_numpy(pos.reshape(-1, 3)), torch.from_numpy(nrm.reshape(-1, 3))
+    b, losses, gt_ms = 1024, [], []
+    for it in range(a.nirf_steps + 5):
+        sel = torch.from_numpy(np.random.choice(vid, b, replace=False))
+        p, n = P[sel].to(dev), N[sel].to(dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gt = m.trace_gt(p, n, [8, 16])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        res = {"gt": gt, "pred": m.ir_radiance_network(p)}
+        loss = lossf(res)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+        if it >= 5:
+            gt_ms.append((t1 - t0) * 1e3)
+            losses.append((time.perf_counter() - t0) * 1e3)
+    out["nirf"] = {"batch_points": b, "spp": 128, "gt_trace_ms": round(float(np.median(gt_ms)), 3), "step_ms": round(float(np.median(losses)), 3),
+                   "gt_Mrays_s": round(b * 128 / (np.median(gt_ms) * 1e-3) / 1e6, 1), "final_loss": round(float(loss), 4)}
+
+    # 2. IrT
+    d_pos, d_nrm = P.to(dev), N.to(dev)
+    d_shift = torch.from_numpy(synth.make_shifts(a.res * a.res)).to(dev)
+    ids = dist_util.morton_order(torch.from_numpy(vid).to(torch.int32), a.res).to(dev)
+    irr = torch.zeros((a.res * a.res, 3), device=dev)
+    sc.irt_generate(d_pos, d_nrm, d_shift, 64, "uniform", texel_ids=ids, out=irr)      # warm-up at low spp
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    irr.zero_()
+    sc.irt_generate(d_pos, d_nrm, d_shift, a.spp, "uniform", texel_ids=ids, out=irr)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["irt"] = {"valid_texels": int(ids.numel()), "seconds": round(dt, 3), "Mrays_s": round(ids.numel() * a.spp / dt / 1e6, 1)}
+
+    # 3. the asset step in between (tools/padding_texture.py) + material step
+    t0 = time.perf_counter()
+    padded = tools.padding_texture(irr.reshape(a.res, a.res, 3).cpu().numpy())
+    out["padding_s"] = round(time.perf_counter() - t0, 2)
+    mat = bench.mat_leg(sc, sc0, torch.from_numpy(padded).to(dev).reshape(-1, 3), a.res, dev, 0, 1, steps=a.mat_steps)
+    out["material_step"] = mat
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
