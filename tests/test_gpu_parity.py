@@ -103,10 +103,14 @@ def test_irt_all_texels_without_id_list(golden, tx):
     assert np.all(irr[~v] == 0)            # zero normal -> zero direction -> miss
 
 
-@pytest.mark.parametrize("N,mode", [(100, "uniform"), (128, "cosine"), (2048, "uniform"), (1, "uniform")])
-def test_irt_vs_oracle_various_N(room, N, mode):
+@pytest.mark.parametrize("per_wave", ["1", "16", "64"])
+@pytest.mark.parametrize("N,mode", [(100, "uniform"), (128, "cosine"), (2048, "uniform"), (1, "uniform"), (2, "cosine")])
+def test_irt_vs_oracle_various_N(room, N, mode, per_wave, monkeypatch):
+    """power-of-two and other sample counts (natural sample order), a ragged texel list (70 = one full + one partial 64-texel
+    wave), every kernel form"""
+    monkeypatch.setenv("TEXIR_IRT_TEXELS_PER_WAVE", per_wave)
     g, sc, osc = room
-    v = np.argwhere(g["valid"].reshape(-1) > 0)[:, 0][::37][:64]
+    v = np.argwhere(g["valid"].reshape(-1) > 0)[:, 0][::37][:70]
     ids = torch.from_numpy(v.astype(np.int32)).cuda()
     irr = sc.irt_generate(torch.from_numpy(g["pos"]), torch.from_numpy(g["nrm"]), torch.from_numpy(g["shift"]), N, mode, texel_ids=ids).cpu().numpy()
     valid = np.zeros(g["valid"].size, np.uint8)
