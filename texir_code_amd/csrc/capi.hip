@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -25,6 +26,11 @@ struct texir_scene {
     size_t tex_bytes = 0;
     std::vector<uint32_t> slot_prim;     // leaf slot -> primitive id (host copy, for per-corner attribute uploads)
     void* d_cnrm = nullptr;              // leaf-ordered corner normals, 3 x float4 per triangle
+    // chunk counters of the persistent IrT kernel: one slot per launch, handed out round-robin so that launches of one scene that
+    // overlap on different streams do not share a counter (kWorkSlots launches would have to be in flight at once)
+    static constexpr int kWorkSlots = 64;
+    unsigned long long* d_work = nullptr;
+    std::atomic<unsigned> work_next{0};
 };
 
 static thread_local std::string g_err;
@@ -81,6 +87,7 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
     if ((e = hipMalloc(&s->d_tris, h.tris.size() * sizeof(GpuTri))) != hipSuccess) return bail(e, "hipMalloc tris");
     if ((e = hipMalloc(&s->d_uvs, h.uvs.size() * sizeof(GpuTriUV))) != hipSuccess) return bail(e, "hipMalloc uvs");
     if ((e = hipMalloc((void**)&s->d_tex, s->tex_bytes)) != hipSuccess) return bail(e, "hipMalloc texture");
+    if ((e = hipMalloc((void**)&s->d_work, texir_scene::kWorkSlots * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc work counters");
     if ((e = hipMemcpy(s->d_nodes, h.nodes.data(), h.nodes.size() * sizeof(GpuNode), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload nodes");
     if ((e = hipMemcpy(s->d_tris, h.tris.data(), h.tris.size() * sizeof(GpuTri), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload tris");
     if ((e = hipMemcpy(s->d_uvs, h.uvs.data(), h.uvs.size() * sizeof(GpuTriUV), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload uvs");
@@ -102,6 +109,7 @@ int texir_scene_destroy(texir_scene* s)
     if (s->d_uvs) (void)hipFree(s->d_uvs);
     if (s->d_tex) (void)hipFree(s->d_tex);
     if (s->d_cnrm) (void)hipFree(s->d_cnrm);
+    if (s->d_work) (void)hipFree(s->d_work);
     delete s;
     return TEXIR_OK;
 }
@@ -150,7 +158,9 @@ int texir_irt_generate(const texir_scene* s, const float* pos, const float* nrm,
     if (N <= 0 || Nt < 0 || n_ids < 0) return fail(TEXIR_ERR_INVALID, "texir_irt_generate: bad sizes N=%d Nt=%lld n_ids=%lld", N, (long long)Nt, (long long)n_ids);
     if (Nt >= (1ll << 31)) return fail(TEXIR_ERR_INVALID, "texir_irt_generate: Nt too large");
     int64_t n = texel_ids ? n_ids : Nt;
-    HIP_TRY(launch_irt(s->dev, pos, nrm, shift, texel_ids, n, N, mode, irr, (unsigned long long*)stats, (hipStream_t)stream));
+    texir_scene* ms = const_cast<texir_scene*>(s);
+    unsigned long long* work = ms->d_work + (ms->work_next.fetch_add(1) % texir_scene::kWorkSlots);
+    HIP_TRY(launch_irt(s->dev, pos, nrm, shift, texel_ids, n, N, mode, irr, (unsigned long long*)stats, work, (hipStream_t)stream));
     return TEXIR_OK;
 }
 

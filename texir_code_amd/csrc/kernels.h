@@ -7,7 +7,8 @@
 
 namespace texir {
 hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, const float* shift, const int32_t* ids, int64_t n_ids,
-                      int N, int mode, float* irr, unsigned long long* stats, hipStream_t st);
+                      int N, int mode, float* irr, unsigned long long* stats, unsigned long long* work /*dev: chunk counter of this launch*/,
+                      hipStream_t st);
 int irt_launch_count(int N);
 hipError_t launch_trace_shade(const SceneDev& sc, const float* org, const float* dir, int64_t R, float t_min, float* rad, float* t_hit,
                               uint32_t* prim, float* puv, hipStream_t st);

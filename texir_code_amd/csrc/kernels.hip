@@ -44,7 +44,7 @@ template <bool STATS, int WIDTH>
 __global__ __launch_bounds__(kBlock) void irt_kernel(SceneDev sc, const float* __restrict__ pos, const float* __restrict__ nrm,
                                                      const float* __restrict__ shift, const int32_t* __restrict__ ids, int64_t n_ids,
                                                      int N, int log2N, int mode, float* __restrict__ irr,
-                                                     unsigned long long* __restrict__ stats)
+                                                     unsigned long long* __restrict__ stats, unsigned long long* /*work: unused, static stride*/)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + wave, nw = (int64_t)gridDim.x * (kBlock / 64);
@@ -119,15 +119,22 @@ template <bool STATS, int WIDTH, int LOG2GRP>
 __global__ __launch_bounds__(kBlock) void irt_group_kernel(SceneDev sc, const float* __restrict__ pos, const float* __restrict__ nrm,
                                                            const float* __restrict__ shift, const int32_t* __restrict__ ids, int64_t n_ids,
                                                            int N, int log2N, int mode, float* __restrict__ irr,
-                                                           unsigned long long* __restrict__ stats)
+                                                           unsigned long long* __restrict__ stats, unsigned long long* __restrict__ work)
 {
     constexpr int GRP = 1 << LOG2GRP, LOG2M = 6 - LOG2GRP, M = 64 >> LOG2GRP;       // texels per wave, samples per texel per pass
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const int grp = lane >> LOG2M, sub = lane & (M - 1);
-    const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + wave, nw = (int64_t)gridDim.x * (kBlock / 64);
     const int n_cells = N >> LOG2M;
     uint32_t cn = 0, ct = 0, c_rays = 0, c_hits = 0, wi[2] = {0, 0};
-    for (int64_t k0 = gw * GRP; k0 < n_ids; k0 += nw * GRP) {
+    for (;;) {
+        // persistent waves pull GRP-texel chunks from a global counter: a chunk is tens of milliseconds of work, so a static
+        // round-robin would leave the slowest wave's surplus (the sum of ~40 chunk-time deviations) as an idle tail
+        unsigned long long chunk = 0;
+        if (lane == 0) chunk = atomicAdd(work, 1ull);
+        chunk = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(chunk >> 32)) << 32) |
+                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)chunk);
+        const int64_t k0 = (int64_t)chunk * GRP;
+        if (k0 >= n_ids) break;
         const int64_t k = k0 + grp;
         const bool live = k < n_ids;
         const int64_t t = live ? (ids ? (int64_t)ids[k] : k) : 0;
@@ -375,24 +382,27 @@ int irt_launch_count(int) { return 1; }
 
 template <typename K>
 static void irt_launch(K kernel, int64_t waves_wanted, const SceneDev& sc, const float* pos, const float* nrm, const float* shift,
-                       const int32_t* ids, int64_t n_ids, int N, int l2, int mode, float* irr, unsigned long long* stats, hipStream_t st)
+                       const int32_t* ids, int64_t n_ids, int N, int l2, int mode, float* irr, unsigned long long* stats,
+                       unsigned long long* work, hipStream_t st)
 {
     // persistent grid: exactly the workgroups that are co-resident, each wave strides over the texel list
     const int64_t want = (waves_wanted + (kBlock / 64) - 1) / (kBlock / 64);
     int grid = resident_grid(kernel, kBlock);
     if (want < grid) grid = (int)want;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, irr, stats);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, irr, stats, work);
 }
 
 hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, const float* shift, const int32_t* ids, int64_t n_ids,
-                      int N, int mode, float* irr, unsigned long long* stats, hipStream_t st)
+                      int N, int mode, float* irr, unsigned long long* stats, unsigned long long* work, hipStream_t st)
 {
     if (n_ids <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(work, 0, sizeof(unsigned long long), st);       // chunk counter of this launch
+    if (e != hipSuccess) return e;
     const int forced = irt_forced_texels_per_wave();
     const bool pow2 = (N & (N - 1)) == 0;
     const int l2 = ilog2_exact(N);
-#define TEXIR_IRT(WAVES, L2, NAME, ...) { if (stats) irt_launch(NAME<true, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, st); \
-                                        else irt_launch(NAME<false, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, st); }
+#define TEXIR_IRT(WAVES, L2, NAME, ...) { if (stats) irt_launch(NAME<true, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, work, st); \
+                                        else irt_launch(NAME<false, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, work, st); }
     // texels per wave: 64 when the list is long enough to fill the chip that way (5 waves x 4 SIMDs x 256 CUs), else 16, else 1 --
     // a 1024-point NIrF batch would otherwise occupy 16 wavefronts
     const int64_t fill = 4096;
