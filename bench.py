@@ -62,6 +62,7 @@ def cpu_leg(sc0, pos, nrm, valid, shift, spp, budget_s=15.0):
         osc.irt_generate(pos.reshape(-1, 3)[pick], nrm.reshape(-1, 3)[pick], None, shift[pick], spp, "uniform", tracer="bvh", counters=c)
         return time.perf_counter() - t0, c, pick.size
 
+    O.set_num_threads(os.cpu_count() or 1)       # all host cores (main() pinned torch's own host ops to one thread)
     cores = O.num_threads()
     run(cores)                                   # warm the thread pool / page in the BVH
     dt, c, n = run(max(cores * 8, 64))           # calibration sample (dynamic schedule needs >> cores texels)
@@ -181,6 +182,9 @@ def main():
     ap.add_argument("--no-mat", action="store_true")
     args = ap.parse_args()
 
+    # host torch ops on the path are tiny (the per-step CPU-generator draw of 2P floats): one intra-op thread, like the reference's
+    # runners (trainer/train_material.py:34).  With the default (= all cores) the draw's OpenMP fork/join jitters by milliseconds.
+    torch.set_num_threads(1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -248,7 +252,9 @@ def main():
 
     mat = None
     if not args.no_mat and args.workload == "c4":
-        mat = mat_leg(sc, sc0, irr, res, dev, rank, world)
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):          # (constructors print like the reference's; stdout carries the JSON line only)
+            mat = mat_leg(sc, sc0, irr, res, dev, rank, world)
 
     if rank == 0:
         rays_per_step = n_valid * spp

@@ -41,6 +41,8 @@ def lib():
         L.txo_irt_generate.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp]
         L.txo_spec_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]
         L.txo_num_threads.restype = i32
+        L.txo_set_num_threads.argtypes = [i32]
+        L.txo_set_num_threads.restype = None
         _LIB = L
     return _LIB
 
@@ -159,3 +161,8 @@ def new_counters():
 
 def num_threads():
     return lib().txo_num_threads()
+
+
+def set_num_threads(n):
+    """OpenMP threads of the following oracle calls (torch.set_num_threads() lowers the process-wide default)"""
+    lib().txo_set_num_threads(int(n))

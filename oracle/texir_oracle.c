@@ -582,6 +582,16 @@ TXO_API void txo_spec_forward(const TxoScene *s, const float *normal, const floa
     free(ham);
 }
 
+/* number of OpenMP threads the following calls use (PyTorch's torch.set_num_threads() changes the process-wide default) */
+TXO_API void txo_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 TXO_API int txo_num_threads(void)
 {
 #ifdef _OPENMP

@@ -18,6 +18,7 @@ from ..plugin import get_class
 class IRRFTrainRunner:
     def __init__(self, **kwargs):
         torch.set_default_dtype(torch.float32)
+        torch.set_num_threads(1)                 # as the reference's runners (e.g. trainer/train_material.py:34): host torch ops are tiny
         self.conf = ConfigFactory.parse_file(kwargs["conf"])
         self.exps_folder_name = kwargs["exps_folder_name"]
         self.train_batch_size = self.conf.get_int("train.batch_size")
