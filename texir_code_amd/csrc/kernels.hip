@@ -115,8 +115,13 @@ __device__ __forceinline__ uint32_t cell_to_pass_m(uint32_t J, float sh0, float 
     return (th << bphi) | low;
 }
 
+// Occupancy: 7 waves/SIMD (<= 72 VGPRs; the compiler parks the per-texel frame in scratch across the traversal loop) with a
+// 16-entry LDS stack (16 KiB per block) measured best: 5 waves / 24 entries 13.85, 6 / 24 14.79, 7 / 16 15.11, 8 / 16 15.06 Grays/s (c4).
+constexpr int kGroupLstk = 16;
+constexpr int kGroupWaves = 7;
+
 template <bool STATS, int WIDTH, int LOG2GRP>
-__global__ __launch_bounds__(kBlock) void irt_group_kernel(SceneDev sc, const float* __restrict__ pos, const float* __restrict__ nrm,
+__global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev sc, const float* __restrict__ pos, const float* __restrict__ nrm,
                                                            const float* __restrict__ shift, const int32_t* __restrict__ ids, int64_t n_ids,
                                                            int N, int log2N, int mode, float* __restrict__ irr,
                                                            unsigned long long* __restrict__ stats, unsigned long long* __restrict__ work)
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(kBlock) void irt_group_kernel(SceneDev sc, const fl
                 float s1 = shift_wrap_clamp(ham1(i), sh1);
                 float d[3];
                 sample_dir(mode, s0, s1, 0.f, f, d);
-                Hit h = trace_closest<STATS, kLdsStack, WIDTH>(sc, px, py, pz, d[0], d[1], d[2], cn, ct, STATS ? wi : nullptr);
+                Hit h = trace_closest<STATS, kGroupLstk, WIDTH>(sc, px, py, pz, d[0], d[1], d[2], cn, ct, STATS ? wi : nullptr);
                 if (STATS) c_rays++;
                 if (h.slot >= 0 && h.t > 1e-4f) {          // tracer_o3d_irt.py:248
                     float L[3];
