@@ -44,7 +44,7 @@ template <bool STATS, int WIDTH>
 __global__ __launch_bounds__(kBlock) void irt_kernel(SceneDev sc, const float* __restrict__ pos, const float* __restrict__ nrm,
                                                      const float* __restrict__ shift, const int32_t* __restrict__ ids, int64_t n_ids,
                                                      int N, int log2N, int mode, float* __restrict__ irr,
-                                                     unsigned long long* __restrict__ stats, unsigned long long* /*work: unused, static stride*/)
+                                                     unsigned long long* __restrict__ stats, unsigned long long* /*work*/, float* /*partial*/, int /*log2parts*/)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + wave, nw = (int64_t)gridDim.x * (kBlock / 64);
@@ -124,21 +124,26 @@ template <bool STATS, int WIDTH, int LOG2GRP>
 __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev sc, const float* __restrict__ pos, const float* __restrict__ nrm,
                                                            const float* __restrict__ shift, const int32_t* __restrict__ ids, int64_t n_ids,
                                                            int N, int log2N, int mode, float* __restrict__ irr,
-                                                           unsigned long long* __restrict__ stats, unsigned long long* __restrict__ work)
+                                                           unsigned long long* __restrict__ stats, unsigned long long* __restrict__ work,
+                                                           float* __restrict__ partial, int log2parts)
 {
     constexpr int GRP = 1 << LOG2GRP, LOG2M = 6 - LOG2GRP, M = 64 >> LOG2GRP;       // texels per wave, samples per texel per pass
     const int lane = threadIdx.x & 63;
     const int grp = lane >> LOG2M, sub = lane & (M - 1);
     const int n_cells = N >> LOG2M;
     uint32_t cn = 0, ct = 0, c_rays = 0, c_hits = 0, wi[2] = {0, 0};
+    // A chunk = GRP texels x (all passes / 2^log2parts).  With parts > 1 the raw partial sums go to partial[part][k][3] and
+    // irt_combine_kernel adds them in part order: the result depends on N only, never on how the texel list is cut or scheduled.
+    const int part_cells = n_cells >> log2parts;
     for (;;) {
-        // persistent waves pull GRP-texel chunks from a global counter: a chunk is tens of milliseconds of work, so a static
-        // round-robin would leave the slowest wave's surplus (the sum of ~40 chunk-time deviations) as an idle tail
+        // persistent waves pull chunks from a global counter: a chunk is milliseconds of work, so a static round-robin would
+        // leave the slowest wave's surplus (the sum of its chunk-time deviations) as an idle tail
         unsigned long long chunk = 0;
         if (lane == 0) chunk = atomicAdd(work, 1ull);
         chunk = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(chunk >> 32)) << 32) |
                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)chunk);
-        const int64_t k0 = (int64_t)chunk * GRP;
+        const int part = (int)(chunk & ((1ull << log2parts) - 1ull));
+        const int64_t k0 = (int64_t)(chunk >> log2parts) * GRP;
         if (k0 >= n_ids) break;
         const int64_t k = k0 + grp;
         const bool live = k < n_ids;
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
         const float sh0 = shift[2 * t], sh1 = shift[2 * t + 1];
         const Frame f = make_frame(nx, ny, nz);
         float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
-        for (int J = 0; J < n_cells; J++) {
+        for (int J = part * part_cells; J < (part + 1) * part_cells; J++) {
             if (live) {
                 // (N not a power of two: only the one-sample-per-pass form is launched, in natural sample order)
                 const uint32_t i = log2N < 0 ? (uint32_t)J : sample_index_m(cell_to_pass_m((uint32_t)J, sh0, sh1, log2N, LOG2M), (uint32_t)sub, log2N, LOG2M);
@@ -170,13 +175,33 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
         // reduce over the M lanes of each texel
         for (int o = M >> 1; o > 0; o >>= 1) { acc0 += __shfl_xor(acc0, o, 64); acc1 += __shfl_xor(acc1, o, 64); acc2 += __shfl_xor(acc2, o, 64); }
         if (live && sub == 0) {
-            const float pi = 3.141592653589793f;
-            irr[3 * t] = ((acc0 * 2.f) * pi) / (float)N;
-            irr[3 * t + 1] = ((acc1 * 2.f) * pi) / (float)N;
-            irr[3 * t + 2] = ((acc2 * 2.f) * pi) / (float)N;
+            if (log2parts) {
+                float* o = partial + ((int64_t)part * n_ids + k) * 3;
+                o[0] = acc0; o[1] = acc1; o[2] = acc2;
+            } else {
+                const float pi = 3.141592653589793f;
+                irr[3 * t] = ((acc0 * 2.f) * pi) / (float)N;
+                irr[3 * t + 1] = ((acc1 * 2.f) * pi) / (float)N;
+                irr[3 * t + 2] = ((acc2 * 2.f) * pi) / (float)N;
+            }
         }
     }
     if (STATS) irt_stats_flush(stats, lane, c_rays, cn, ct, c_hits, wi[0], wi[1]);
+}
+
+// irr[t] = (2 pi / N) * (partial sums of the texel's pass ranges, added in part order)          (tracer_o3d_irt.py:171)
+__global__ __launch_bounds__(256) void irt_combine_kernel(const float* __restrict__ partial, const int32_t* __restrict__ ids, int64_t n_ids,
+                                                          int parts, int N, float* __restrict__ irr)
+{
+    const float pi = 3.141592653589793f;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < 3 * n_ids; e += (int64_t)gridDim.x * 256) {
+        const int64_t k = e / 3;
+        const int c = (int)(e - 3 * k);
+        float a = partial[e];
+        for (int p = 1; p < parts; p++) a += partial[(int64_t)p * n_ids * 3 + e];
+        const int64_t t = ids ? (int64_t)ids[k] : k;
+        irr[3 * t + c] = ((a * 2.f) * pi) / (float)N;
+    }
 }
 
 template <int WIDTH>
@@ -388,13 +413,13 @@ int irt_launch_count(int) { return 1; }
 template <typename K>
 static void irt_launch(K kernel, int64_t waves_wanted, const SceneDev& sc, const float* pos, const float* nrm, const float* shift,
                        const int32_t* ids, int64_t n_ids, int N, int l2, int mode, float* irr, unsigned long long* stats,
-                       unsigned long long* work, hipStream_t st)
+                       unsigned long long* work, float* partial, int log2parts, hipStream_t st)
 {
     // persistent grid: exactly the workgroups that are co-resident, each wave strides over the texel list
     const int64_t want = (waves_wanted + (kBlock / 64) - 1) / (kBlock / 64);
     int grid = resident_grid(kernel, kBlock);
     if (want < grid) grid = (int)want;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, irr, stats, work);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, irr, stats, work, partial, log2parts);
 }
 
 hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, const float* shift, const int32_t* ids, int64_t n_ids,
@@ -406,18 +431,44 @@ hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, co
     const int forced = irt_forced_texels_per_wave();
     const bool pow2 = (N & (N - 1)) == 0;
     const int l2 = ilog2_exact(N);
-#define TEXIR_IRT(WAVES, L2, NAME, ...) { if (stats) irt_launch(NAME<true, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, work, st); \
-                                        else irt_launch(NAME<false, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, work, st); }
+#define TEXIR_IRT(WAVES, L2, NAME, ...) { if (stats) irt_launch(NAME<true, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, work, partial, log2parts, st); \
+                                        else irt_launch(NAME<false, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, work, partial, log2parts, st); }
     // texels per wave: 64 when the list is long enough to fill the chip that way (5 waves x 4 SIMDs x 256 CUs), else 16, else 1 --
     // a 1024-point NIrF batch would otherwise occupy 16 wavefronts
     const int64_t fill = 4096;
     int per_wave = forced ? forced : (n_ids >= 64 * fill ? 64 : (n_ids >= 16 * fill ? 16 : 1));
     if (per_wave == 16 && !(pow2 && l2 >= 7)) per_wave = forced ? 64 : 1;
+    // 64 texels per wave: the passes of a texel are cut into 2^log2parts ranges of >= 256 passes (N = 2048: 8 parts), each range its own
+    // chunk -- at 8 GPUs a rank's share is only ~3 whole-texel chunks per wave, and the idle tail is half a chunk on average.  The
+    // number of parts depends on N alone, so results do not depend on the sharding.
+    float* partial = nullptr;
+    int log2parts = 0;
+    if (sc.nodes4 && per_wave == 64 && pow2) { while (log2parts < 3 && (N >> (log2parts + 1)) >= 256) log2parts++; }
+    if (const char* cap = getenv("TEXIR_IRT_LOG2PARTS")) { if (log2parts > atoi(cap)) log2parts = atoi(cap) < 0 ? 0 : atoi(cap); }   // A/B switch
+    if (log2parts) {
+        const size_t bytes = sizeof(float) * 3 * (size_t)n_ids << log2parts;
+        // stream-ordered scratch (1.2 GB at 4k^2 texels); keep it cached in the device's pool between calls instead of
+        // returning it to the OS at every synchronisation
+        static bool pool_set = false;
+        if (!pool_set) {
+            int dev = 0; hipMemPool_t pool;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+                uint64_t keep = ~0ull;
+                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            }
+            pool_set = true;
+        }
+        if ((e = hipMallocAsync((void**)&partial, bytes, st)) != hipSuccess) return e;
+    }
     if (!sc.nodes4) TEXIR_IRT(n_ids, l2, irt_kernel, 2)                                        // deep binary tree (capi.hip fallback)
     else if (per_wave == 1) TEXIR_IRT(n_ids, l2, irt_kernel, 4)
     else if (per_wave == 16) TEXIR_IRT((n_ids + 15) / 16, l2, irt_group_kernel, 4, 4)
-    else TEXIR_IRT((n_ids + 63) / 64, pow2 ? l2 : -1, irt_group_kernel, 4, 6)                  // any N (natural sample order if not 2^k)
+    else TEXIR_IRT(((n_ids + 63) / 64) << log2parts, pow2 ? l2 : -1, irt_group_kernel, 4, 6)   // any N (natural sample order if not 2^k)
 #undef TEXIR_IRT
+    if (log2parts) {
+        hipLaunchKernelGGL(irt_combine_kernel, dim3(grid_for(256, 3 * n_ids)), dim3(256), 0, st, partial, ids, n_ids, 1 << log2parts, N, irr);
+        if ((e = hipFreeAsync(partial, st)) != hipSuccess) return e;
+    }
     return hipGetLastError();
 }
 
