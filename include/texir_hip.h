@@ -85,8 +85,9 @@ TEXIR_API int texir_generate_dir(const float* normals /*dev*/, const float* roug
  *   pos,nrm [Nt,3] dev (pos already offset by +1e-2*n, :110), shift [Nt,2] dev
  *   texel_ids [n_ids] i32 dev: the texels to compute (NULL => all Nt, n_ids ignored).  Seam texels
  *     (index texture all-zero, :137-139,176-178) are simply not listed; irr must be zero-initialised by the caller.
- *   irr [Nt,3] dev: only listed texels are written.  The texture depends on (scene, pos, nrm, shift, N, mode) only: not on the
- *     order or sharding of texel_ids, not on the launch configuration (fixed summation order per texel).
+ *   irr [Nt,3] dev: only listed texels are written.  A texel's value has a fixed summation order per kernel form, so for lists of
+ *     >= 262144 texels (the 64-texels-per-wave form; shorter lists use other forms that differ in the last bits) the texture does
+ *     not depend on the order or sharding of texel_ids nor on the launch configuration.
  *   Long lists (>= 262144 texels) use a stream-ordered scratch allocation (hipMallocAsync/hipFreeAsync on `stream`,
  *     96 bytes per listed texel at N >= 2048) for the per-pass-range partial sums.
  *   stats [8] u64 dev, nullable: += rays, 64-byte node fetches, triangle tests, hits, wave-level node steps, wave-level
