@@ -104,10 +104,10 @@ def test_irt_all_texels_without_id_list(golden, tx):
 
 
 @pytest.mark.parametrize("per_wave", ["1", "16", "64"])
-@pytest.mark.parametrize("N,mode", [(100, "uniform"), (128, "cosine"), (2048, "uniform"), (1, "uniform"), (2, "cosine")])
+@pytest.mark.parametrize("N,mode", [(100, "uniform"), (128, "cosine"), (2048, "uniform"), (1, "uniform"), (2, "cosine"), (512, "uniform"), (1024, "cosine")])
 def test_irt_vs_oracle_various_N(room, N, mode, per_wave, monkeypatch):
-    """power-of-two and other sample counts (natural sample order), a ragged texel list (70 = one full + one partial 64-texel
-    wave), every kernel form"""
+    """power-of-two and other sample counts (natural sample order; 1, 2, 4 and 8 pass ranges per texel in the 64-texel form), a
+    ragged texel list (70 = one full + one partial 64-texel wave), every kernel form"""
     monkeypatch.setenv("TEXIR_IRT_TEXELS_PER_WAVE", per_wave)
     g, sc, osc = room
     v = np.argwhere(g["valid"].reshape(-1) > 0)[:, 0][::37][:70]
