@@ -30,7 +30,7 @@ struct texir_scene {
     // overlap on different streams do not share a counter (kWorkSlots launches would have to be in flight at once)
     static constexpr int kWorkSlots = 64;
     unsigned long long* d_work = nullptr;
-    std::atomic<unsigned> work_next{0};
+    mutable std::atomic<unsigned> work_next{0};      // (launching on an immutable scene still advances the slot)
 };
 
 static thread_local std::string g_err;
@@ -158,8 +158,7 @@ int texir_irt_generate(const texir_scene* s, const float* pos, const float* nrm,
     if (N <= 0 || Nt < 0 || n_ids < 0) return fail(TEXIR_ERR_INVALID, "texir_irt_generate: bad sizes N=%d Nt=%lld n_ids=%lld", N, (long long)Nt, (long long)n_ids);
     if (Nt >= (1ll << 31)) return fail(TEXIR_ERR_INVALID, "texir_irt_generate: Nt too large");
     int64_t n = texel_ids ? n_ids : Nt;
-    texir_scene* ms = const_cast<texir_scene*>(s);
-    unsigned long long* work = ms->d_work + (ms->work_next.fetch_add(1) % texir_scene::kWorkSlots);
+    unsigned long long* work = s->d_work + (s->work_next.fetch_add(1) % texir_scene::kWorkSlots);
     HIP_TRY(launch_irt(s->dev, pos, nrm, shift, texel_ids, n, N, mode, irr, (unsigned long long*)stats, work, (hipStream_t)stream));
     return TEXIR_OK;
 }
