@@ -176,3 +176,18 @@ def test_padding_texture_fills_zero_texels_from_nearest():
     # only the two source colours ever appear
     cols = {tuple(c) for c in out.reshape(-1, 3).round(3).tolist()}
     assert cols == {(1.0, 2.0, 3.0), (5.0, 5.0, 5.0)}
+
+
+def test_denoise_standin_removes_noise_keeps_edges_and_seams():
+    from texir_code_amd.tools import denoise_atrous
+    rng = np.random.default_rng(2)
+    clean = np.ones((48, 64, 3), np.float32)
+    clean[:, 32:] = 4.0                                   # a step edge
+    clean[20:24, 8:12] = 0.0                              # an unpadded seam block
+    noisy = clean * (1 + 0.1 * rng.standard_normal(clean.shape)).astype(np.float32)
+    noisy[clean == 0] = 0
+    out = denoise_atrous(noisy, device=torch.device("cpu"))
+    assert out.shape == noisy.shape and np.all(out[20:24, 8:12] == 0)
+    v = clean > 0
+    assert np.abs(out - clean)[v].mean() < 0.4 * np.abs(noisy - clean)[v].mean()          # noise down by > 2.5x
+    assert abs(out[:, :28].mean() - 1.0) < 0.05 and abs(out[:, 36:].mean() - 4.0) < 0.1   # the edge did not bleed
