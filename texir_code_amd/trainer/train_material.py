@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .. import dist_util
+from .. import dist_util, io_formats as IO
 from ..conf import ConfigFactory
 from ..datasets import parse_roomseg
 from ..models import rgb_to_intensity
@@ -135,6 +135,17 @@ class MatTrainRunner:
         torch.save({"epoch": epoch, "model_state_dict": self.model.state_dict()},
                    os.path.join(self.checkpoints_path, "ModelParameters", "latest.pth"))
 
+    def plot_materials(self):
+        """the user-facing output of plot_to_disk_cube (train_material.py:352-353): the current material textures as
+        plots/mat_albedo-1_<iter>.hdr and plots/mat_roughness-1_<iter>.hdr (Radiance RGBE, roughness replicated to 3 channels)"""
+        plots = getattr(self, "plots_dir", None)
+        if int(os.environ.get("RANK", "0")) != 0 or not plots or not os.path.isdir(plots):
+            return
+        a = self.model.materials_a.detach().cpu().numpy()[:, :, 0:3]
+        r = self.model.materials_r.detach().cpu().numpy()[:, :, 0:1]
+        IO.write_hdr(os.path.join(self.plots_dir, "mat_albedo-1_%d.hdr" % self.cur_iter), np.ascontiguousarray(a, np.float32))
+        IO.write_hdr(os.path.join(self.plots_dir, "mat_roughness-1_%d.hdr" % self.cur_iter), np.ascontiguousarray(np.repeat(r, 3, axis=2), np.float32))
+
     # first-validation branch of plot_to_disk_cube (train_material.py:251-296): per-view masks from a stage -1 render
     def build_view_masks(self):
         self.model.eval()
@@ -147,6 +158,7 @@ class MatTrainRunner:
                 self.seg_mask[str(vid)], self.floor_max_mask[str(vid)], self.room_seg_mask[str(vid)] = seg, fm, room
         self.model.train()
         self.first_val = False
+        self.plot_materials()
 
     def train_step(self, gt_item, stage):
         """one optimiser step (train_material.py:424-458 / 486-525 / 552-593)"""
@@ -193,6 +205,7 @@ class MatTrainRunner:
             for i, vid in enumerate(self.train_dataset.ids):
                 self.model(self.train_dataset.extrinsics_list[i], vid, self.train_dataset.cam_position_list[i].cuda(), stage)
         self.model.train()
+        self.plot_materials()
 
     def _stage(self, stage, max_steps=None):
         for epoch in range(self.start_epoch, self.nepochs + 1):
@@ -239,6 +252,7 @@ class MatTrainRunner:
         self._stage(2)
         if int(os.environ.get("RANK", "0")) == 0 and os.path.isdir(os.path.join(self.checkpoints_path, "ModelParameters")):
             self.save_checkpoints(self.nepochs)
+        self.plot_materials()                                    # final textures (the reference's last plot is one plot_freq earlier)
 
 
 class MatTrainSynRunner(MatTrainRunner):
