@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--mat-steps", type=int, default=50)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
+    torch.set_num_threads(1)                    # as the runners and bench.py (tiny host torch ops; avoids OpenMP fork/join jitter)
     torch.manual_seed(666)
     np.random.seed(666)
     out = {"config": "C5 joint pipeline: %d-tri synthetic mesh, %dx%d texels, %d spp" % (a.tris, a.res, a.res, a.spp)}
