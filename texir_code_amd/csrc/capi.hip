@@ -59,7 +59,8 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
 {
     if (!verts || !tris || !tri_uvs || !hdr_tex || !out) return fail(TEXIR_ERR_INVALID, "texir_scene_create: null argument");
     if (V <= 0 || T <= 0 || Ht <= 0 || Wt <= 0) return fail(TEXIR_ERR_INVALID, "texir_scene_create: empty mesh or texture");
-    if (T >= (1 << 28) - 1) return fail(TEXIR_ERR_INVALID, "texir_scene_create: too many triangles");
+    // the traversal addresses nodes and triangles with 32-bit byte offsets (64-byte nodes, 48-byte triangle records)
+    if ((uint64_t)(T + 1) * 48u >= (1ull << 32)) return fail(TEXIR_ERR_INVALID, "texir_scene_create: too many triangles (%d; limit 89 M)", (int)T);
     for (int64_t i = 0; i < 3 * (int64_t)T; i++)
         if (tris[i] < 0 || tris[i] >= V) return fail(TEXIR_ERR_INVALID, "texir_scene_create: triangle index %d out of range", (int)tris[i]);
     HIP_TRY(hipSetDevice(device));
