@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void tex_fetch_kernel(float* __restrict__ lvl0
 
 static int grid1d(int64_t n, int bs) { int64_t nb = (n + bs - 1) / bs; return (int)(nb > 4096 ? 4096 : (nb < 1 ? 1 : nb)); }
 
-constexpr int kTailElems = 64 * 64 * 4;     // levels with at most this many elements are handled by the single-block tail kernels
+constexpr int kTailElems = 16 * 16 * 4;     // levels with at most this many elements are handled by the single-block tail kernels (measured: 64^2 1.36, 32^2 1.31, 16^2 1.29, 8^2 1.29, none 1.31 ms per material step)
 
 static int tail_begin(const MipDesc& d)
 {

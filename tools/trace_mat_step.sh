@@ -1,0 +1,21 @@
+#!/bin/bash
+# kernel sequence of ONE replayed material step (name, duration), from a rocprofv3 kernel trace of bench.py's material leg
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ktm -- python $R/bench.py --no-cpu --steps 1 --warmup 0 > /tmp/ktm.log 2>&1
+f=$(find /tmp/ktm -name '*kernel_trace.csv' | head -1)
+python - "$f" <<'PY'
+import csv,sys
+rows=list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r:int(r['Start_Timestamp']))
+# the last adam launch ends a step; take the kernels between the two last "step boundaries" (second adam of a step)
+idx=[i for i,r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
+end=idx[-1]; start=idx[-3]+1            # two adam launches per step
+seg=rows[start:end+1]
+t0=int(seg[0]['Start_Timestamp']); tot=0
+for r in seg:
+    d=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3
+    tot+=d
+    print('%8.1f us @%8.1f  %s'%(d,(int(r['Start_Timestamp'])-t0)/1e3,r['Kernel_Name'][:100]))
+print('kernels',len(seg),'busy %.1f us'%tot,'span %.1f us'%((int(seg[-1]['End_Timestamp'])-t0)/1e3))
+PY
