@@ -106,7 +106,7 @@ def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5):
         model.materials_a.copy_(a0)
         model.materials_r.copy_(r0)
     loss_fn = RenderLoss("L1", 1, lazy_item=True)
-    opt = FusedAdam([model.materials_a, model.materials_r], lr=3e-2)
+    opt = FusedAdam([model.materials_a, model.materials_r], lr=3e-2, fuse_mip_fold=world == 1)
     opt.set_clamp(model.materials_r, 1e-2, 0.8)
     opt.set_clamp(model.materials_a, 0.0, float("inf"))
     if world > 1:

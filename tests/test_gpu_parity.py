@@ -316,6 +316,64 @@ def c2_workload(tx):
     return sc0, sc, d(pos).reshape(-1, 3), d(nrm).reshape(-1, 3), d(shift), ids, valid
 
 
+def test_fused_mip_fold_adam_is_bit_identical(tx):
+    """FusedAdam(fuse_mip_fold=True): the texture backward leaves level 1 un-folded and the optimiser adds 0.25 * level 1 while it reads
+    the gradient.  (a) the kernel pair equals fold + plain step bit for bit on the same gradient buffers; (b) end to end the two
+    optimisers agree to the float-atomics tolerance of the scatter."""
+    from texir_code_amd import _lib
+    from texir_code_amd.optim import FusedAdam
+    from texir_code_amd.texture import texture
+    L = _lib.lib()
+    torch.manual_seed(4)
+    H = W = 64
+    C, levels = 3, int(L.texir_mip_levels(H, W, 6))
+    uv = torch.rand(3000, 2, device="cuda")
+    da = (torch.rand(3000, 4, device="cuda") - 0.5) * 0.2
+    tgt = torch.rand(3000, 3, device="cuda")
+    # (a) deferred backward -> (g0, g1 | coarser levels already folded into g1)
+    d_out = torch.randn(3000, 3, device="cuda")
+    n_rest = int(L.texir_mip_elems(H, W, C, levels))
+    g0 = torch.zeros(H, W, C, device="cuda")
+    rest = torch.zeros(n_rest, device="cuda")
+    _lib.check(L.texir_tex_fetch_backward_deferred(_lib.ptr(g0), _lib.ptr(rest), H, W, C, levels, _lib.ptr(uv), _lib.ptr(da), 3000, _lib.ptr(d_out),
+                                                   _lib.stream_ptr()))
+    g1 = rest[:(H // 2) * (W // 2) * C].clone()
+    # the library's own last fold on copies of the same buffers (P = 0: no scatter, folds only; levels = 2 so that only level 1 -> 0 runs)
+    folded, r2 = g0.clone(), g1.clone()
+    _lib.check(L.texir_tex_fetch_backward(_lib.ptr(folded), _lib.ptr(r2), H, W, C, 2, _lib.ptr(uv), _lib.ptr(da), 1, 0, _lib.ptr(d_out), _lib.stream_ptr()))
+    assert not torch.equal(folded, g0)
+    outs = []
+    for fused in (False, True):
+        torch.manual_seed(9)
+        p = torch.rand(H, W, C, device="cuda")
+        m, v = torch.rand_like(p) * 0.1, torch.rand_like(p) * 0.01
+        if fused:
+            _lib.check(L.texir_adam_step_tex(_lib.ptr(p), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(m), _lib.ptr(v), H, W, C, 3e-2, 0.9, 0.999, 1e-8, 3, 0.0, 0.8,
+                                             _lib.stream_ptr()))
+        else:
+            _lib.check(L.texir_adam_step(_lib.ptr(p), _lib.ptr(folded), _lib.ptr(m), _lib.ptr(v), p.numel(), 3e-2, 0.9, 0.999, 1e-8, 3, 0.0, 0.8,
+                                         _lib.stream_ptr()))
+        outs.append((p, m, v))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # (b) end to end
+    res = []
+    for fuse in (False, True):
+        torch.manual_seed(5)
+        t = torch.nn.Parameter(torch.rand(H, W, 3, device="cuda"))
+        opt = FusedAdam([t], lr=3e-2, fuse_mip_fold=fuse)
+        opt.set_clamp(t, 0.0, float("inf"))
+        for _ in range(3):
+            loss = (texture(t, uv, da, "linear-mipmap-linear", 6) - tgt).abs().mean()
+            opt.zero_grad()
+            loss.backward()
+            assert (getattr(t, "_texir_grad_l1", None) is not None) == fuse
+            opt.step()
+            assert getattr(t, "_texir_grad_l1", None) is None
+        res.append(t.detach().cpu().numpy())
+    assert rel_l2(res[1], res[0]) < 1e-5
+
+
 def test_full_size_c2_properties(c2_workload, tx):
     """size-independent properties at BASELINE full size (the oracle cannot run 6.4 G rays): exact linearity in the radiance
     texture, superposition, determinism, shard-union == whole, and the closed-room constant-radiance limit E -> pi*L"""

@@ -241,7 +241,26 @@ int texir_tex_fetch_backward(float* d_tex, float* grad_rest, int32_t H, int32_t 
     if (!d_tex || !uv || !d_out || (filter_mode == 1 && (!uv_da || (levels > 1 && !grad_rest)))) return fail(TEXIR_ERR_INVALID, "texir_tex_fetch_backward: null argument");
     if (filter_mode < 0 || filter_mode > 1 || P < 0) return fail(TEXIR_ERR_INVALID, "texir_tex_fetch_backward: bad filter_mode/P");
     if (int rc = check_tex("texir_tex_fetch_backward", H, W, C, levels)) return rc;
-    HIP_TRY(launch_tex_fetch_bwd(d_tex, grad_rest, H, W, C, levels, uv, uv_da, filter_mode, P, d_out, (hipStream_t)stream));
+    HIP_TRY(launch_tex_fetch_bwd(d_tex, grad_rest, H, W, C, levels, uv, uv_da, filter_mode, P, d_out, 0, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
+int texir_tex_fetch_backward_deferred(float* d_tex, float* grad_rest, int32_t H, int32_t W, int32_t C, int32_t levels, const float* uv,
+                                      const float* uv_da, int64_t P, const float* d_out, void* stream)
+{
+    if (!d_tex || !uv || !d_out || !uv_da || !grad_rest) return fail(TEXIR_ERR_INVALID, "texir_tex_fetch_backward_deferred: null argument");
+    if (P < 0 || levels < 2) return fail(TEXIR_ERR_INVALID, "texir_tex_fetch_backward_deferred: needs P >= 0 and at least two mip levels");
+    if (int rc = check_tex("texir_tex_fetch_backward_deferred", H, W, C, levels)) return rc;
+    HIP_TRY(launch_tex_fetch_bwd(d_tex, grad_rest, H, W, C, levels, uv, uv_da, 1, P, d_out, 1, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
+int texir_adam_step_tex(float* param, const float* grad, const float* grad_level1, float* exp_avg, float* exp_avg_sq, int32_t H, int32_t W,
+                        int32_t C, float lr, float beta1, float beta2, float eps, int32_t step, float clamp_lo, float clamp_hi, void* stream)
+{
+    if (!param || !grad || !grad_level1 || !exp_avg || !exp_avg_sq) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex: null argument");
+    if (H < 2 || W < 2 || (H & 1) || (W & 1) || C < 1 || C > 4 || step < 1) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex: bad H/W/C/step");
+    HIP_TRY(launch_adam_tex(param, grad, grad_level1, exp_avg, exp_avg_sq, H, W, C, lr, beta1, beta2, eps, step, clamp_lo, clamp_hi, (hipStream_t)stream));
     return TEXIR_OK;
 }
 

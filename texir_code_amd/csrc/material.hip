@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void mip_fold_kernel(float* __restrict__ fine,
     if (e >= Wf * C) return;
     const int tx = e / C, ch = e - tx * C;
     for (int y = blockIdx.y; y < Hf; y += gridDim.y)
-        fine[(size_t)y * Wf * C + e] += 0.25f * coarse[((size_t)(y >> 1) * (Wf >> 1) + (tx >> 1)) * C + ch];
+        fine[(size_t)y * Wf * C + e] = __builtin_fmaf(0.25f, coarse[((size_t)(y >> 1) * (Wf >> 1) + (tx >> 1)) * C + ch], fine[(size_t)y * Wf * C + e]);
 }
 
 __global__ __launch_bounds__(1024) void mip_fold_tail_kernel(float* __restrict__ rest, MipDesc d, int l_end /* fold levels-1 .. l_end+1 into l_end */)
@@ -355,7 +355,7 @@ hipError_t launch_tex_fetch(const float* tex, const float* rest, int H, int W, i
 
 // d_tex [H,W,C] and grad_rest [mip_total_elems] must be zero on entry; on return d_tex holds d loss / d texture
 hipError_t launch_tex_fetch_bwd(float* d_tex, float* grad_rest, int H, int W, int C, int levels, const float* uv, const float* uvda, int trilinear,
-                                int64_t P, const float* d_out, hipStream_t st)
+                                int64_t P, const float* d_out, int fold_to_level, hipStream_t st)
 {
     MipDesc d = make_desc(H, W, C, levels);
     if (P > 0)
@@ -365,7 +365,8 @@ hipError_t launch_tex_fetch_bwd(float* d_tex, float* grad_rest, int H, int W, in
         if (lt < 2) lt = 2;
         // small levels: levels-1 .. lt folded down to level lt-1 inside one block
         if (lt < levels) hipLaunchKernelGGL(mip_fold_tail_kernel, dim3(1), dim3(1024), 0, st, grad_rest, d, lt - 1);
-        for (int l = (lt < levels ? lt : levels) - 1; l >= 1; l--) {
+        // fold_to_level = 1: leave level 1 un-folded (texir_adam_step_tex adds 0.25 * level 1 while it reads the gradient)
+        for (int l = (lt < levels ? lt : levels) - 1; l >= 1 + fold_to_level; l--) {
             int Hf = H >> (l - 1), Wf = W >> (l - 1);
             float* fine = l == 1 ? d_tex : grad_rest + d.off[l - 1];
             launch_fold(fine, grad_rest + d.off[l], Hf, Wf, C, st);
@@ -379,21 +380,59 @@ hipError_t launch_tex_fetch_bwd(float* d_tex, float* grad_rest, int H, int W, in
 // with the trainer's clamp (materials_r in [1e-2, 0.8], materials_a >= 0; train_material.py:458,592-593)
 // ------------------------------------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
+// one Adam update with explicitly placed roundings (shared by both optimiser kernels so that they agree bit for bit):
+//   exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2); param.addcdiv_(exp_avg, denom, value = -step_size)
+__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float beta1, float beta2, float eps, float step_size,
+                                            float bc2_sqrt, float lo, float hi)
+{
+    const float mi = __builtin_fmaf(g - m, 1.f - beta1, m);
+    const float vi = __builtin_fmaf(g * g, 1.f - beta2, v * beta2);
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    const float pi = __builtin_fmaf(mi / denom, -step_size, p);
+    m = mi; v = vi; p = fminf(fmaxf(pi, lo), hi);
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n, float beta1, float beta2, float eps, float step_size, float bc2_sqrt,
                                                    float lo, float hi)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float gi = g[i];
-        float mi = m[i] + (gi - m[i]) * (1.f - beta1);                 // exp_avg.lerp_(grad, 1 - beta1)
-        float vi = v[i] * beta2 + (gi * gi) * (1.f - beta2);            // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
-        float denom = sqrtf(vi) / bc2_sqrt + eps;
-        float pi = p[i] + (mi / denom) * (-step_size);                  // param.addcdiv_(exp_avg, denom, value=-step_size)
-        pi = fminf(fmaxf(pi, lo), hi);
-        m[i] = mi; v[i] = vi; p[i] = pi;
+        adam_update(p[i], g[i], m[i], v[i], beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
     }
 }
 #pragma clang fp contract(fast)
+
+// Adam over a texture [H,W,C] whose gradient is level 0 + 0.25 * (level-1 gradient of the 2x2 block): the last fold of the mip
+// backward happens here, while the gradient is read anyway (saves one read-modify-write of the finest level per step).
+// Same arithmetic as mip_fold_kernel followed by adam_kernel, bit for bit.
+template <int C>
+__global__ __launch_bounds__(256) void adam_tex_kernel(float* __restrict__ p, const float* __restrict__ g, const float* __restrict__ g1,
+                                                       float* __restrict__ m, float* __restrict__ v, int H, int W, float beta1, float beta2,
+                                                       float eps, float step_size, float bc2_sqrt, float lo, float hi)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;           // element inside a row: texel * C + channel
+    if (e >= W * C) return;
+    const int tx = e / C, ch = e - tx * C;
+    for (int y = blockIdx.y; y < H; y += gridDim.y) {
+        const size_t i = (size_t)y * W * C + e;
+        const float gi = __builtin_fmaf(0.25f, g1[((size_t)(y >> 1) * (W >> 1) + (tx >> 1)) * C + ch], g[i]);
+        adam_update(p[i], gi, m[i], v[i], beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+    }
+}
+
+hipError_t launch_adam_tex(float* p, const float* g, const float* g1, float* m, float* v, int H, int W, int C, float lr, float beta1, float beta2,
+                           float eps, int step, float lo, float hi, hipStream_t st)
+{
+    double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    float step_size = (float)((double)lr / bc1);
+    float bc2_sqrt = (float)sqrt(bc2);
+    dim3 grid((W * C + 255) / 256, H > 4096 ? 4096 : H);
+    if (C == 1) hipLaunchKernelGGL(adam_tex_kernel<1>, grid, dim3(256), 0, st, p, g, g1, m, v, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+    else if (C == 2) hipLaunchKernelGGL(adam_tex_kernel<2>, grid, dim3(256), 0, st, p, g, g1, m, v, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+    else if (C == 3) hipLaunchKernelGGL(adam_tex_kernel<3>, grid, dim3(256), 0, st, p, g, g1, m, v, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+    else hipLaunchKernelGGL(adam_tex_kernel<4>, grid, dim3(256), 0, st, p, g, g1, m, v, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+    return hipGetLastError();
+}
 
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step,
                        float lo, float hi, hipStream_t st)

@@ -17,6 +17,9 @@ class GraphedMatStep:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
         self.static_shift = None
+        self.grads = {}
+        for p in self.params:
+            p._texir_l1_static = True          # FusedAdam(fuse_mip_fold=True): the parked level-1 gradients are graph-pool buffers too
 
     def _fwd_bwd(self, inp, stage):
         mvp, cam, gt, gmask, seg, fm, room, key = inp
@@ -60,6 +63,10 @@ class GraphedMatStep:
             if gc_was:
                 gc.enable()
         self.pool = g.pool()
+        # Each graph writes its gradients into its OWN pool buffers (the first capture of an empty pool lays them out differently from
+        # the later ones), so the tensors autograd assigned during this capture are remembered per graph and re-attached to the
+        # parameters before every optimiser step.
+        self.grads[(key, stage)] = [(p.grad, getattr(p, "_texir_grad_l1", None)) for p in self.params]
         self.graphs[(key, stage)] = g
         self.losses[(key, stage)] = loss.detach()      # keep no autograd graph of the captured region alive
         self.outs[(key, stage)] = self._last_out
@@ -80,8 +87,12 @@ class GraphedMatStep:
             self._pinned.copy_(shift)
             self.static_shift.copy_(self._pinned, non_blocking=True)
         self.graphs[(key, stage)].replay()
+        for p, (g, g1) in zip(self.params, self.grads[(key, stage)]):
+            p.grad = g
+            p._texir_grad_l1 = g1
         if all_reduce is not None:
             for p in self.params:
-                all_reduce(p.grad)
+                if p.grad is not None:
+                    all_reduce(p.grad)
         self.opt.step()
         return self.losses[(key, stage)]

@@ -8,9 +8,32 @@ from . import _lib
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    """fuse_mip_fold=True: the [H,W,C] texture parameters ask texture.py's backward to leave the last mip fold (level 1 -> level 0) out
+    and this optimiser adds 0.25 * level-1 gradient while it reads the gradient (bit-identical to fold + step; saves one
+    read-modify-write of every texture per step).  Until step() has run, `p.grad` then lacks that term -- do not combine with code
+    that reads or reduces `p.grad` in between (the multi-GPU paths leave it off)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, fuse_mip_fold=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._clamps = {}
+        self.fuse_mip_fold = bool(fuse_mip_fold)
+        for group in self.param_groups:
+            for p in group["params"]:
+                p._texir_defer_fold = self.fuse_mip_fold and p.dim() == 3 and p.shape[0] % 2 == 0 and p.shape[1] % 2 == 0
+                p._texir_grad_l1 = None
+
+    def zero_grad(self, set_to_none=True):
+        for group in self.param_groups:
+            for p in group["params"]:
+                p._texir_grad_l1 = None
+        super().zero_grad(set_to_none=set_to_none)
+
+    def release(self):
+        """stop deferring (call before handing the parameters to another optimiser that does not fuse the fold)"""
+        for group in self.param_groups:
+            for p in group["params"]:
+                p._texir_defer_fold = False
+                p._texir_grad_l1 = None
 
     def set_clamp(self, param, lo=-math.inf, hi=math.inf):
         """fuse `param.data.clamp_(lo, hi)` into every step of this parameter"""
@@ -38,7 +61,16 @@ class FusedAdam(torch.optim.Optimizer):
                 st["step"] += 1
                 lo, hi = self._clamps.get(id(p), (-math.inf, math.inf))
                 g = p.grad.contiguous()
-                _lib.check(L.texir_adam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]), p.numel(),
-                                             float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]), lo, hi,
-                                             _lib.stream_ptr()))
+                g1 = getattr(p, "_texir_grad_l1", None)
+                if g1 is not None:
+                    H, W, C = p.shape
+                    _lib.check(L.texir_adam_step_tex(_lib.ptr(p), _lib.ptr(g), _lib.ptr(g1), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]),
+                                                     H, W, C, float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]),
+                                                     lo, hi, _lib.stream_ptr()))
+                    if not getattr(p, "_texir_l1_static", False):      # (hipGraph replay re-fills the same buffer: keep it)
+                        p._texir_grad_l1 = None
+                else:
+                    _lib.check(L.texir_adam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]), p.numel(),
+                                                 float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]), lo, hi,
+                                                 _lib.stream_ptr()))
         return loss

@@ -41,7 +41,7 @@ def _mips_for(owner, t0, levels):
 
 class _TexFetch(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, tex, rest, uv, uv_da, mode, levels):
+    def forward(ctx, tex, rest, uv, uv_da, mode, levels, owner=None):
         L = _lib.lib()
         H, W, C = tex.shape
         P = uv.shape[0]
@@ -51,6 +51,7 @@ class _TexFetch(torch.autograd.Function):
                                              _lib.stream_ptr()))
         ctx.save_for_backward(uv, uv_da)
         ctx.meta = (H, W, C, levels, mode)
+        ctx.owner = owner
         return out
 
     @staticmethod
@@ -58,14 +59,24 @@ class _TexFetch(torch.autograd.Function):
         uv, uv_da = ctx.saved_tensors
         H, W, C, levels, mode = ctx.meta
         if not ctx.needs_input_grad[0]:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         L = _lib.lib()
         d_tex = torch.zeros((H, W, C), device=d_out.device, dtype=torch.float32)
         g_rest = torch.zeros(int(L.texir_mip_elems(H, W, C, levels)), device=d_out.device, dtype=torch.float32) if levels > 1 else None
         d_out = d_out.contiguous()
-        _lib.check(L.texir_tex_fetch_backward(_lib.ptr(d_tex), _lib.ptr(g_rest), H, W, C, levels, _lib.ptr(uv), _lib.ptr(uv_da), mode, uv.shape[0],
-                                              _lib.ptr(d_out), _lib.stream_ptr()))
-        return d_tex, None, None, None, None, None
+        owner = ctx.owner
+        # FusedAdam(fuse_mip_fold=True) asks for the last fold (level 1 -> level 0, a read-modify-write of the whole texture) to be
+        # left to its own read of the gradient: the level-1 gradient is parked on the parameter.  Only the first trilinear fetch of a
+        # parameter per backward pass defers; a further one folds completely and autograd adds its d_tex as usual.
+        if (mode == 1 and levels > 1 and owner is not None and getattr(owner, "_texir_defer_fold", False)
+                and getattr(owner, "_texir_grad_l1", None) is None):
+            _lib.check(L.texir_tex_fetch_backward_deferred(_lib.ptr(d_tex), _lib.ptr(g_rest), H, W, C, levels, _lib.ptr(uv), _lib.ptr(uv_da),
+                                                           uv.shape[0], _lib.ptr(d_out), _lib.stream_ptr()))
+            owner._texir_grad_l1 = g_rest[:(H // 2) * (W // 2) * C]
+        else:
+            _lib.check(L.texir_tex_fetch_backward(_lib.ptr(d_tex), _lib.ptr(g_rest), H, W, C, levels, _lib.ptr(uv), _lib.ptr(uv_da), mode, uv.shape[0],
+                                                  _lib.ptr(d_out), _lib.stream_ptr()))
+        return d_tex, None, None, None, None, None, None
 
 
 def texture(tex, uv, uv_da=None, filter_mode="linear", max_mip_level=13):
@@ -84,5 +95,5 @@ def texture(tex, uv, uv_da=None, filter_mode="linear", max_mip_level=13):
     H, W, C = tex.shape
     levels = int(_lib.lib().texir_mip_levels(H, W, int(max_mip_level))) if mode == 1 else 1
     rest = _mips_for(owner, tex.detach(), levels) if levels > 1 else None
-    out = _TexFetch.apply(tex, rest, uvf, daf, mode, levels)
+    out = _TexFetch.apply(tex, rest, uvf, daf, mode, levels, owner if isinstance(owner, torch.nn.Parameter) else None)
     return out.reshape(*lead, C)

@@ -126,7 +126,10 @@ class MatTrainRunner:
     def _new_optimizer(self):
         """fresh Adam + StepLR over ALL model parameters (train_material.py:122-128, 472-476, 539-543); the post-step
         clamps of :458/:592-593 are fused into the optimiser kernel"""
-        self.mat_optimizer = FusedAdam(self.model.parameters(), lr=self.conf.get_float("train.mat_learning_rate"))
+        # single process: the last mip fold of the texture backward is fused into the optimiser's read of the gradient (bit-identical);
+        # with several ranks the gradients are all-reduced in between, so they must be complete
+        self.mat_optimizer = FusedAdam(self.model.parameters(), lr=self.conf.get_float("train.mat_learning_rate"),
+                                       fuse_mip_fold=dist_util.world_info()[1] == 1)
         self.mat_optimizer.set_clamp(self.model.materials_r, 1e-2, 0.8)
         self.mat_scheduler = torch.optim.lr_scheduler.StepLR(self.mat_optimizer, self.conf.get_int("train.mat_sched_step", default=100),
                                                             gamma=self.conf.get_float("train.mat_sched_factor", default=0.0))
