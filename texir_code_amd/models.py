@@ -219,7 +219,12 @@ class MaterialModel(nn.Module):
         albedo = tex_fetch(self.materials_a, texc, texd, "linear-mipmap-linear", self.max_mip_level)
         roughness_womipmap = tex_fetch(self.materials_r, texc, texd, "linear")
         roughness = tex_fetch(self.materials_r, texc, texd, "linear-mipmap-linear", self.max_mip_level)
-        irr = tex_fetch(self.irrt, texc, texd, "linear-mipmap-linear", self.max_mip_level)
+        # the irradiance texture is frozen and the view's uvs are constant: fetch once per view
+        irr = gb.get("_irr")
+        if irr is None or gb.get("_irr_version") != self.irrt._version or self.irrt.requires_grad:
+            irr = tex_fetch(self.irrt, texc, texd, "linear-mipmap-linear", self.max_mip_level)
+            if not self.irrt.requires_grad:
+                gb["_irr"], gb["_irr_version"] = irr.detach(), self.irrt._version
         return albedo, roughness_womipmap, roughness, irr
 
     def _gbuffer_slice(self, mvp, view_id, pixel_range):
@@ -232,6 +237,8 @@ class MaterialModel(nn.Module):
             p0, p1 = pixel_range
             gb = {}
             for k, v in full.items():
+                if k.startswith("_"):
+                    continue                     # per-view derived caches are rebuilt for the slice
                 flat = v.reshape(v.shape[0] * v.shape[1] * v.shape[2], -1)[p0:p1]
                 gb[k] = flat.reshape(1, 1, p1 - p0, -1).contiguous() if k != "tri_id" else flat.reshape(1, 1, p1 - p0).contiguous()
             self._gb_cache[key] = gb
@@ -243,6 +250,10 @@ class MaterialModel(nn.Module):
         if pixel_range is not None:
             self._view_pixels = 6 * self.cube_res * self.cube_res
         pos, nrm, mask = gb["position"], gb["normal"], gb["mask"]
+        if "_points" not in gb:
+            # per-view constants: the offset ray origins (mat_nvdiffrast.py:179,182) and the position the render reports
+            gb["_points"] = pos + 1e-2 * nrm
+            gb["_position_out"] = (gb["_points"] + 2e-2 * nrm).detach()
         albedo, roughness_womipmap, roughness, irr = self._fetch_materials(gb)
         cam_position = cam_position.to(self.device)
         if stage == -1:
@@ -251,21 +262,21 @@ class MaterialModel(nn.Module):
             inten = rgb_to_intensity(src * (2 ** -self.conf.get_float("train.hdr_exposure")))
             self.scene.set_texture(torch.where(inten >= 0.5, src, torch.zeros_like(src)).contiguous())
             try:
-                res = self.render(nrm, torch.zeros_like(albedo), torch.ones_like(roughness) * 0.01, pos + 1e-2 * nrm, cam_position, irr)
+                res = self.render(nrm, torch.zeros_like(albedo), torch.ones_like(roughness) * 0.01, gb["_points"], cam_position, irr, gb["_position_out"])
             finally:
                 self.scene.set_texture(src.contiguous())
         elif stage == 0:
             res = {"rgb": irr * albedo / np.pi, "albedo": albedo, "normal": nrm, "position": pos + 1e-1 * nrm}
         elif stage == 1:
-            res = self.render(nrm, albedo.detach(), roughness_womipmap, pos + 1e-2 * nrm, cam_position, irr)
+            res = self.render(nrm, albedo.detach(), roughness_womipmap, gb["_points"], cam_position, irr, gb["_position_out"])
         elif stage == 2:
-            res = self.render(nrm, albedo, roughness, pos + 1e-2 * nrm, cam_position, irr)
+            res = self.render(nrm, albedo, roughness, gb["_points"], cam_position, irr, gb["_position_out"])
         else:
             raise ValueError("MaterialModel.forward: unknown stage %r" % (stage,))
         res.update({"empty_mask": mask, "roughness_womipmap": roughness_womipmap, "roughness": roughness})
         return res
 
-    def render(self, normal, albedo, roughness, points, cam_position, irr):
+    def render(self, normal, albedo, roughness, points, cam_position, irr, position_out=None):
         """mat_nvdiffrast.py:201-249: fused GGX-importance sampling + trace + BRDF (texir_spec_forward/backward)"""
         face, h, w, _ = normal.shape
         P = face * h * w
@@ -286,7 +297,7 @@ class MaterialModel(nn.Module):
         rgb = spec_render(self.scene, normal.reshape(P, 3), albedo.reshape(P, 3), roughness.reshape(P), points.reshape(P, 3),
                           irr.reshape(P, 3), cam_position, shift, S)
         return {"rgb": rgb.reshape(face, h, w, 3), "albedo": albedo.reshape(face, h, w, 3), "normal": normal.reshape(face, h, w, 3).detach(),
-                "position": (points + 2e-2 * normal).reshape(face, h, w, 3).detach()}
+                "position": (position_out if position_out is not None else (points + 2e-2 * normal).detach()).reshape(face, h, w, 3)}
 
     # -- API-complete helpers (dead on the default path, mat_nvdiffrast.py:252-258) ---------------------------------
     def diffuse_reflectance(self, lighting, l, n, albedo, sample_type="uniform"):
