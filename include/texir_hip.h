@@ -175,6 +175,19 @@ TEXIR_API int texir_tex_fetch_backward(float* d_tex /*dev*/, float* grad_rest /*
 TEXIR_API int texir_tex_fetch_backward_deferred(float* d_tex /*dev*/, float* grad_rest /*dev*/, int32_t H, int32_t W, int32_t C,
                        int32_t levels, const float* uv, const float* uv_da, int64_t P, const float* d_out /*dev [P,C]*/, void* stream);
 
+/* Atomics-free backward for fetches whose (uv, uv_da) never change (a cached view: geometry and cameras are constant).
+ * texir_tex_taps lists the taps of every pixel: keys/weights [P*8] (4 bilinear taps x 2 mip levels; bilinear mode uses the first 4),
+ * key = texel index in the unified order [level 0 | levels 1.. as in mips_rest], -1 for unused slots, weight = bilinear x level blend.
+ * The caller sorts them by key once (stable), forms segments (key, start, count) + the sorted (pixel, weight) lists, and then every
+ * backward is texir_tex_gather_backward: one thread per touched texel adds its list in order (deterministic), followed by the
+ * same folds as texir_tex_fetch_backward (defer_last_fold = 1: as texir_tex_fetch_backward_deferred).  d_tex / grad_rest zero on entry. */
+TEXIR_API int texir_tex_taps(int32_t H, int32_t W, int32_t C, int32_t levels, const float* uv, const float* uv_da, int32_t filter_mode,
+                       int64_t P, int64_t* keys /*dev [P*8]*/, float* weights /*dev [P*8]*/, void* stream);
+TEXIR_API int texir_tex_gather_backward(float* d_tex, float* grad_rest, int32_t H, int32_t W, int32_t C, int32_t levels,
+                       const int64_t* seg_key /*dev [n_seg]*/, const int32_t* seg_start, const int32_t* seg_count, int32_t n_seg,
+                       const int32_t* pix /*dev, sorted*/, const float* weights /*dev, sorted*/, const float* d_out /*dev [P,C]*/,
+                       int32_t filter_mode, int32_t defer_last_fold, void* stream);
+
 /* ---- optimiser step of the material textures: torch.optim.Adam(lr, betas, eps) (trainer/train_material.py:122-123,448-450)
  * fused with the clamp the trainer applies right after it (:458, :592-593).  step >= 1; lo/hi = clamp range (+-inf = none). */
 TEXIR_API int texir_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

@@ -316,6 +316,33 @@ def c2_workload(tx):
     return sc0, sc, d(pos).reshape(-1, 3), d(nrm).reshape(-1, 3), d(shift), ids, valid
 
 
+def test_gather_backward_matches_atomic_scatter_and_is_deterministic(tx):
+    """texture(..., cache=dict): tap lists sorted once, backward = gather.  Same gradient as the float-atomic scatter (to summation
+    order), identical bits from run to run, for both filter modes"""
+    from texir_code_amd.texture import texture
+    torch.manual_seed(8)
+    uv = torch.rand(5000, 2, device="cuda")
+    da = (torch.rand(5000, 4, device="cuda") - 0.5) * 0.3
+    g = torch.randn(5000, 3, device="cuda")
+    for mode in ("linear", "linear-mipmap-linear"):
+        grads = []
+        for cache in (None, {}, {}):
+            t = torch.rand(128, 64, 3, device="cuda", requires_grad=True)
+            torch.manual_seed(1)
+            with torch.no_grad():
+                t.copy_(torch.rand(128, 64, 3, device="cuda"))
+            out = texture(t, uv, da, mode, 7, cache=cache)
+            out.backward(g)
+            grads.append(t.grad.clone())
+            if cache is not None:
+                out2 = texture(t, uv, da, mode, 7, cache=cache)         # second use of the cached lists
+                t.grad = None
+                out2.backward(g)
+                assert torch.equal(t.grad, grads[-1])
+        assert rel_l2(grads[1].cpu().numpy(), grads[0].cpu().numpy()) < 1e-5
+        assert torch.equal(grads[1], grads[2])
+
+
 def test_fused_mip_fold_adam_is_bit_identical(tx):
     """FusedAdam(fuse_mip_fold=True): the texture backward leaves level 1 un-folded and the optimiser adds 0.25 * level 1 while it reads
     the gradient.  (a) the kernel pair equals fold + plain step bit for bit on the same gradient buffers; (b) end to end the two

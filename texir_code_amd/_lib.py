@@ -14,6 +14,7 @@ EXPORTS = [
     "texir_scene_info", "texir_trace_shade", "texir_generate_dir", "texir_irt_generate", "texir_spec_forward",
     "texir_spec_backward", "texir_loss_forward", "texir_loss_backward", "texir_tex_fetch_forward", "texir_tex_fetch_backward",
     "texir_adam_step", "texir_raster_cube", "texir_tex_fetch_backward_deferred", "texir_adam_step_tex",
+    "texir_tex_taps", "texir_tex_gather_backward",
 ]
 
 
@@ -64,6 +65,8 @@ def lib():
         sig["texir_tex_fetch_backward"] = [vp, vp, i32, i32, i32, i32, vp, vp, i32, i64, vp, vp]
         sig["texir_adam_step"] = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, f32, vp]
         sig["texir_tex_fetch_backward_deferred"] = [vp, vp, i32, i32, i32, i32, vp, vp, i64, vp, vp]
+        sig["texir_tex_taps"] = [i32, i32, i32, i32, vp, vp, i32, i64, vp, vp, vp]
+        sig["texir_tex_gather_backward"] = [vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp]
         sig["texir_adam_step_tex"] = [vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, i32, f32, f32, vp]
         L.texir_irt_launch_count.argtypes = [i32]
         L.texir_irt_launch_count.restype = i32

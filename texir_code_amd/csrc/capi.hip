@@ -255,6 +255,30 @@ int texir_tex_fetch_backward_deferred(float* d_tex, float* grad_rest, int32_t H,
     return TEXIR_OK;
 }
 
+int texir_tex_taps(int32_t H, int32_t W, int32_t C, int32_t levels, const float* uv, const float* uv_da, int32_t filter_mode, int64_t P,
+                   int64_t* keys, float* weights, void* stream)
+{
+    if (!uv || !keys || !weights || (filter_mode == 1 && !uv_da)) return fail(TEXIR_ERR_INVALID, "texir_tex_taps: null argument");
+    if (filter_mode < 0 || filter_mode > 1 || P < 0) return fail(TEXIR_ERR_INVALID, "texir_tex_taps: bad filter_mode/P");
+    if (int rc = check_tex("texir_tex_taps", H, W, C, levels)) return rc;
+    HIP_TRY(launch_tex_taps(H, W, C, levels, uv, uv_da, filter_mode, P, (long long*)keys, weights, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
+int texir_tex_gather_backward(float* d_tex, float* grad_rest, int32_t H, int32_t W, int32_t C, int32_t levels, const int64_t* seg_key,
+                              const int32_t* seg_start, const int32_t* seg_count, int32_t n_seg, const int32_t* pix, const float* weights,
+                              const float* d_out, int32_t filter_mode, int32_t defer_last_fold, void* stream)
+{
+    if (!d_tex || !d_out || (n_seg > 0 && (!seg_key || !seg_start || !seg_count || !pix || !weights)) || (filter_mode == 1 && levels > 1 && !grad_rest))
+        return fail(TEXIR_ERR_INVALID, "texir_tex_gather_backward: null argument");
+    if (filter_mode < 0 || filter_mode > 1 || n_seg < 0 || (defer_last_fold && (filter_mode != 1 || levels < 2)))
+        return fail(TEXIR_ERR_INVALID, "texir_tex_gather_backward: bad filter_mode/n_seg/defer_last_fold");
+    if (int rc = check_tex("texir_tex_gather_backward", H, W, C, levels)) return rc;
+    HIP_TRY(launch_tex_gather_bwd(d_tex, grad_rest, H, W, C, levels, (const long long*)seg_key, seg_start, seg_count, n_seg, pix, weights, d_out,
+                                  filter_mode, defer_last_fold ? 1 : 0, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
 int texir_adam_step_tex(float* param, const float* grad, const float* grad_level1, float* exp_avg, float* exp_avg_sq, int32_t H, int32_t W,
                         int32_t C, float lr, float beta1, float beta2, float eps, int32_t step, float clamp_lo, float clamp_hi, void* stream)
 {

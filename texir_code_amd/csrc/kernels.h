@@ -31,6 +31,11 @@ hipError_t launch_tex_fetch(const float* tex, const float* rest, int H, int W, i
                             int64_t P, float* out, hipStream_t st);
 hipError_t launch_tex_fetch_bwd(float* d_tex, float* grad_rest, int H, int W, int C, int levels, const float* uv, const float* uvda, int trilinear,
                                 int64_t P, const float* d_out, int fold_to_level, hipStream_t st);
+hipError_t launch_tex_taps(int H, int W, int C, int levels, const float* uv, const float* uvda, int trilinear, int64_t P, long long* keys,
+                           float* weights, hipStream_t st);
+hipError_t launch_tex_gather_bwd(float* d_tex, float* grad_rest, int H, int W, int C, int levels, const long long* seg_key, const int* seg_start,
+                                 const int* seg_count, int n_seg, const int* pix, const float* w, const float* d_out, int trilinear,
+                                 int fold_to_level, hipStream_t st);
 hipError_t launch_adam_tex(float* p, const float* g, const float* g1, float* m, float* v, int H, int W, int C, float lr, float beta1, float beta2,
                            float eps, int step, float lo, float hi, hipStream_t st);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step,

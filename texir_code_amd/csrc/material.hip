@@ -327,6 +327,56 @@ static void launch_fold(float* fine, const float* coarse, int Hf, int Wf, int C,
     else hipLaunchKernelGGL(mip_fold_kernel<4>, grid, dim3(256), 0, st, fine, coarse, Hf, Wf);
 }
 
+// ---- atomics-free texture backward for FIXED (uv, uv_da): the taps of a view never change, so they are enumerated once, sorted by
+// texel on the host side (torch.sort) and replayed as a gather: one thread per touched texel sums its (pixel, weight) list in a fixed
+// order -- deterministic, and ~10x faster than the float-atomic scatter of tex_fetch_kernel<true>.
+// key = unified texel index over [level 0 | levels 1.. in `rest` order]; skipped taps (blend weight 0) get key -1.
+__global__ __launch_bounds__(256) void tex_taps_kernel(MipDesc d, const float* __restrict__ uv, const float* __restrict__ uvda, int trilinear,
+                                                       int64_t P, long long* __restrict__ keys, float* __restrict__ weights)
+{
+    const int64_t n0 = (int64_t)d.H * d.W;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
+        const float u = uv[2 * p], v = uv[2 * p + 1];
+        int l0 = 0, l1 = 0; float f = 0.f;
+        if (trilinear && d.levels > 1) {
+            float4 da = *reinterpret_cast<const float4*>(uvda + 4 * p);
+            float lv = mip_level_from_da(da, d.W, d.H, d.levels - 1);
+            l0 = (int)floorf(lv); l1 = min(l0 + 1, d.levels - 1); f = lv - (float)l0;
+        }
+        for (int pass = 0; pass < 2; pass++) {
+            const int l = pass ? l1 : l0;
+            const float wl = pass ? f : 1.f - f;
+            long long* k = keys + 8 * p + 4 * pass;
+            float* w = weights + 8 * p + 4 * pass;
+            if (wl == 0.f) { k[0] = k[1] = k[2] = k[3] = -1; w[0] = w[1] = w[2] = w[3] = 0.f; continue; }
+            Tap t = bilinear_wrap(u, v, d.W >> l, d.H >> l);
+            const int64_t base = l == 0 ? 0 : n0 + d.off[l] / d.C;
+            k[0] = base + t.i00; k[1] = base + t.i10; k[2] = base + t.i01; k[3] = base + t.i11;
+            w[0] = wl * t.w00; w[1] = wl * t.w10; w[2] = wl * t.w01; w[3] = wl * t.w11;
+        }
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void tex_gather_kernel(float* __restrict__ lvl0, float* __restrict__ rest, int64_t n0, const long long* __restrict__ seg_key,
+                                                         const int* __restrict__ seg_start, const int* __restrict__ seg_count, int n_seg,
+                                                         const int* __restrict__ pix, const float* __restrict__ w, const float* __restrict__ d_out)
+{
+    for (int s = blockIdx.x * 256 + threadIdx.x; s < n_seg; s += gridDim.x * 256) {
+        const long long key = seg_key[s];
+        const int b = seg_start[s], e = b + seg_count[s];
+        float acc[C];
+        for (int c = 0; c < C; c++) acc[c] = 0.f;
+        for (int i = b; i < e; i++) {
+            const float wi = w[i];
+            const float* g = d_out + (int64_t)pix[i] * C;
+            for (int c = 0; c < C; c++) acc[c] = __builtin_fmaf(g[c], wi, acc[c]);
+        }
+        float* o = key < n0 ? lvl0 + key * C : rest + (key - n0) * C;
+        for (int c = 0; c < C; c++) o[c] = acc[c];
+    }
+}
+
 // builds levels 1..levels-1 into `rest` from the caller's level-0 texture
 hipError_t launch_mip_build(const float* tex, float* rest, int H, int W, int C, int levels, hipStream_t st)
 {
@@ -340,6 +390,35 @@ hipError_t launch_mip_build(const float* tex, float* rest, int H, int W, int C, 
         launch_down(src, rest + d.off[l], Hd, Wd, C, st);
     }
     if (lt < levels) hipLaunchKernelGGL(mip_down_tail_kernel, dim3(1), dim3(1024), 0, st, rest, d, lt);
+    return hipGetLastError();
+}
+
+hipError_t launch_tex_taps(int H, int W, int C, int levels, const float* uv, const float* uvda, int trilinear, int64_t P, long long* keys,
+                           float* weights, hipStream_t st)
+{
+    if (P <= 0) return hipSuccess;
+    MipDesc d = make_desc(H, W, C, levels);
+    hipLaunchKernelGGL(tex_taps_kernel, dim3(grid1d(P, 256)), dim3(256), 0, st, d, uv, uvda, trilinear, P, keys, weights);
+    return hipGetLastError();
+}
+
+static void launch_folds(float* d_tex, float* grad_rest, const MipDesc& d, int H, int W, int C, int levels, int fold_to_level, hipStream_t st);
+
+// d_tex and grad_rest zero on entry; gather of the sorted tap lists, then the same folds as launch_tex_fetch_bwd
+hipError_t launch_tex_gather_bwd(float* d_tex, float* grad_rest, int H, int W, int C, int levels, const long long* seg_key, const int* seg_start,
+                                 const int* seg_count, int n_seg, const int* pix, const float* w, const float* d_out, int trilinear,
+                                 int fold_to_level, hipStream_t st)
+{
+    MipDesc d = make_desc(H, W, C, levels);
+    const int64_t n0 = (int64_t)H * W;
+    if (n_seg > 0) {
+        dim3 grid(grid1d(n_seg, 256));
+        if (C == 1) hipLaunchKernelGGL(tex_gather_kernel<1>, grid, dim3(256), 0, st, d_tex, grad_rest, n0, seg_key, seg_start, seg_count, n_seg, pix, w, d_out);
+        else if (C == 2) hipLaunchKernelGGL(tex_gather_kernel<2>, grid, dim3(256), 0, st, d_tex, grad_rest, n0, seg_key, seg_start, seg_count, n_seg, pix, w, d_out);
+        else if (C == 3) hipLaunchKernelGGL(tex_gather_kernel<3>, grid, dim3(256), 0, st, d_tex, grad_rest, n0, seg_key, seg_start, seg_count, n_seg, pix, w, d_out);
+        else hipLaunchKernelGGL(tex_gather_kernel<4>, grid, dim3(256), 0, st, d_tex, grad_rest, n0, seg_key, seg_start, seg_count, n_seg, pix, w, d_out);
+    }
+    if (trilinear && levels > 1) launch_folds(d_tex, grad_rest, d, H, W, C, levels, fold_to_level, st);
     return hipGetLastError();
 }
 
@@ -360,19 +439,22 @@ hipError_t launch_tex_fetch_bwd(float* d_tex, float* grad_rest, int H, int W, in
     MipDesc d = make_desc(H, W, C, levels);
     if (P > 0)
         hipLaunchKernelGGL(tex_fetch_kernel<true>, dim3(grid1d(P, 256)), dim3(256), 0, st, d_tex, grad_rest, d, uv, uvda, trilinear, P, const_cast<float*>(d_out));
-    if (trilinear && levels > 1) {
-        int lt = tail_begin(d);
-        if (lt < 2) lt = 2;
-        // small levels: levels-1 .. lt folded down to level lt-1 inside one block
-        if (lt < levels) hipLaunchKernelGGL(mip_fold_tail_kernel, dim3(1), dim3(1024), 0, st, grad_rest, d, lt - 1);
-        // fold_to_level = 1: leave level 1 un-folded (texir_adam_step_tex adds 0.25 * level 1 while it reads the gradient)
-        for (int l = (lt < levels ? lt : levels) - 1; l >= 1 + fold_to_level; l--) {
-            int Hf = H >> (l - 1), Wf = W >> (l - 1);
-            float* fine = l == 1 ? d_tex : grad_rest + d.off[l - 1];
-            launch_fold(fine, grad_rest + d.off[l], Hf, Wf, C, st);
-        }
-    }
+    if (trilinear && levels > 1) launch_folds(d_tex, grad_rest, d, H, W, C, levels, fold_to_level, st);
     return hipGetLastError();
+}
+
+static void launch_folds(float* d_tex, float* grad_rest, const MipDesc& d, int H, int W, int C, int levels, int fold_to_level, hipStream_t st)
+{
+    int lt = tail_begin(d);
+    if (lt < 2) lt = 2;
+    // small levels: levels-1 .. lt folded down to level lt-1 inside one block
+    if (lt < levels) hipLaunchKernelGGL(mip_fold_tail_kernel, dim3(1), dim3(1024), 0, st, grad_rest, d, lt - 1);
+    // fold_to_level = 1: leave level 1 un-folded (texir_adam_step_tex adds 0.25 * level 1 while it reads the gradient)
+    for (int l = (lt < levels ? lt : levels) - 1; l >= 1 + fold_to_level; l--) {
+        int Hf = H >> (l - 1), Wf = W >> (l - 1);
+        float* fine = l == 1 ? d_tex : grad_rest + d.off[l - 1];
+        launch_fold(fine, grad_rest + d.off[l], Hf, Wf, C, st);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -216,9 +216,10 @@ class MaterialModel(nn.Module):
     def _fetch_materials(self, gb):
         """the four dr.texture fetches of mat_nvdiffrast.py:131-139"""
         texc, texd = gb["uv"], gb["uv_da"]
-        albedo = tex_fetch(self.materials_a, texc, texd, "linear-mipmap-linear", self.max_mip_level)
-        roughness_womipmap = tex_fetch(self.materials_r, texc, texd, "linear")
-        roughness = tex_fetch(self.materials_r, texc, texd, "linear-mipmap-linear", self.max_mip_level)
+        # (cache=gb: the view's fetch coordinates never change, so the backward is a gather over tap lists sorted once per view)
+        albedo = tex_fetch(self.materials_a, texc, texd, "linear-mipmap-linear", self.max_mip_level, cache=gb)
+        roughness_womipmap = tex_fetch(self.materials_r, texc, texd, "linear", cache=gb)
+        roughness = tex_fetch(self.materials_r, texc, texd, "linear-mipmap-linear", self.max_mip_level, cache=gb)
         # the irradiance texture is frozen and the view's uvs are constant: fetch once per view
         irr = gb.get("_irr")
         if irr is None or gb.get("_irr_version") != self.irrt._version or self.irrt.requires_grad:

@@ -39,9 +39,35 @@ def _mips_for(owner, t0, levels):
     return rest
 
 
+def _tap_lists(cache, H, W, C, levels, mode, uv, uv_da):
+    """sorted tap lists of a fixed set of fetch coordinates (one view): built once, kept in the caller's per-view cache dict"""
+    key = ("_taps", H, W, levels, mode, uv.data_ptr(), uv.shape[0])
+    hit = cache.get(key)
+    if hit is not None:
+        return hit
+    if torch.cuda.is_current_stream_capturing():
+        raise _lib.TexirError("tap lists must be built before hipGraph capture (run one eager step first)")
+    L = _lib.lib()
+    P = uv.shape[0]
+    keys = torch.empty(P * 8, device=uv.device, dtype=torch.int64)
+    wts = torch.empty(P * 8, device=uv.device, dtype=torch.float32)
+    _lib.check(L.texir_tex_taps(H, W, C, levels, _lib.ptr(uv), _lib.ptr(uv_da), mode, P, _lib.ptr(keys), _lib.ptr(wts), _lib.stream_ptr()))
+    if mode == 0:
+        keys.view(P, 8)[:, 4:] = -1
+    ks, order = torch.sort(keys, stable=True)
+    first = int((ks < 0).sum().item())
+    ks, order = ks[first:], order[first:]
+    seg_key, counts = torch.unique_consecutive(ks, return_counts=True)
+    starts = (torch.cumsum(counts, 0) - counts).to(torch.int32)
+    hit = (seg_key.contiguous(), starts.contiguous(), counts.to(torch.int32).contiguous(), (order // 8).to(torch.int32).contiguous(),
+           wts[order].contiguous())
+    cache[key] = hit
+    return hit
+
+
 class _TexFetch(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, tex, rest, uv, uv_da, mode, levels, owner=None):
+    def forward(ctx, tex, rest, uv, uv_da, mode, levels, owner=None, taps=None):
         L = _lib.lib()
         H, W, C = tex.shape
         P = uv.shape[0]
@@ -52,6 +78,7 @@ class _TexFetch(torch.autograd.Function):
         ctx.save_for_backward(uv, uv_da)
         ctx.meta = (H, W, C, levels, mode)
         ctx.owner = owner
+        ctx.taps = taps
         return out
 
     @staticmethod
@@ -59,7 +86,7 @@ class _TexFetch(torch.autograd.Function):
         uv, uv_da = ctx.saved_tensors
         H, W, C, levels, mode = ctx.meta
         if not ctx.needs_input_grad[0]:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         L = _lib.lib()
         d_tex = torch.zeros((H, W, C), device=d_out.device, dtype=torch.float32)
         g_rest = torch.zeros(int(L.texir_mip_elems(H, W, C, levels)), device=d_out.device, dtype=torch.float32) if levels > 1 else None
@@ -68,19 +95,29 @@ class _TexFetch(torch.autograd.Function):
         # FusedAdam(fuse_mip_fold=True) asks for the last fold (level 1 -> level 0, a read-modify-write of the whole texture) to be
         # left to its own read of the gradient: the level-1 gradient is parked on the parameter.  Only the first trilinear fetch of a
         # parameter per backward pass defers; a further one folds completely and autograd adds its d_tex as usual.
-        if (mode == 1 and levels > 1 and owner is not None and getattr(owner, "_texir_defer_fold", False)
-                and getattr(owner, "_texir_grad_l1", None) is None):
+        defer = (mode == 1 and levels > 1 and owner is not None and getattr(owner, "_texir_defer_fold", False)
+                 and getattr(owner, "_texir_grad_l1", None) is None)
+        if ctx.taps is not None:
+            # fixed fetch coordinates (a cached view): deterministic gather over the pre-sorted tap lists instead of float atomics
+            seg_key, starts, counts, pix, wts = ctx.taps
+            _lib.check(L.texir_tex_gather_backward(_lib.ptr(d_tex), _lib.ptr(g_rest), H, W, C, levels, _lib.ptr(seg_key), _lib.ptr(starts),
+                                                   _lib.ptr(counts), seg_key.numel(), _lib.ptr(pix), _lib.ptr(wts), _lib.ptr(d_out), mode,
+                                                   1 if defer else 0, _lib.stream_ptr()))
+        elif defer:
             _lib.check(L.texir_tex_fetch_backward_deferred(_lib.ptr(d_tex), _lib.ptr(g_rest), H, W, C, levels, _lib.ptr(uv), _lib.ptr(uv_da),
                                                            uv.shape[0], _lib.ptr(d_out), _lib.stream_ptr()))
-            owner._texir_grad_l1 = g_rest[:(H // 2) * (W // 2) * C]
         else:
             _lib.check(L.texir_tex_fetch_backward(_lib.ptr(d_tex), _lib.ptr(g_rest), H, W, C, levels, _lib.ptr(uv), _lib.ptr(uv_da), mode, uv.shape[0],
                                                   _lib.ptr(d_out), _lib.stream_ptr()))
-        return d_tex, None, None, None, None, None, None
+        if defer:
+            owner._texir_grad_l1 = g_rest[:(H // 2) * (W // 2) * C]
+        return d_tex, None, None, None, None, None, None, None
 
 
-def texture(tex, uv, uv_da=None, filter_mode="linear", max_mip_level=13):
-    """tex [H,W,C] (or [1,H,W,C]); uv [...,2]; uv_da [...,4] (du/dX,du/dY,dv/dX,dv/dY) -> [...,C]"""
+def texture(tex, uv, uv_da=None, filter_mode="linear", max_mip_level=13, cache=None):
+    """tex [H,W,C] (or [1,H,W,C]); uv [...,2]; uv_da [...,4] (du/dX,du/dY,dv/dX,dv/dY) -> [...,C].
+    cache: a dict that lives as long as (uv, uv_da) stay the same tensors (the per-view G-buffer cache): the backward then runs as a
+    deterministic gather over tap lists sorted once, instead of a float-atomic scatter."""
     if tex.dim() == 4:
         tex = tex[0]
     lead = uv.shape[:-1]
@@ -95,5 +132,8 @@ def texture(tex, uv, uv_da=None, filter_mode="linear", max_mip_level=13):
     H, W, C = tex.shape
     levels = int(_lib.lib().texir_mip_levels(H, W, int(max_mip_level))) if mode == 1 else 1
     rest = _mips_for(owner, tex.detach(), levels) if levels > 1 else None
-    out = _TexFetch.apply(tex, rest, uvf, daf, mode, levels, owner if isinstance(owner, torch.nn.Parameter) else None)
+    taps = None
+    if cache is not None and tex.requires_grad and torch.is_grad_enabled():
+        taps = _tap_lists(cache, H, W, C, levels, mode, uvf, daf)
+    out = _TexFetch.apply(tex, rest, uvf, daf, mode, levels, owner if isinstance(owner, torch.nn.Parameter) else None, taps)
     return out.reshape(*lead, C)
