@@ -341,6 +341,16 @@ def test_gather_backward_matches_atomic_scatter_and_is_deterministic(tx):
                 assert torch.equal(t.grad, grads[-1])
         assert rel_l2(grads[1].cpu().numpy(), grads[0].cpu().numpy()) < 1e-5
         assert torch.equal(grads[1], grads[2])
+    # over the cache budget a view silently keeps the atomic scatter
+    import texir_code_amd.texture as TX
+    budget, TX._TAP_BUDGET = TX._TAP_BUDGET, 0
+    try:
+        c = {}
+        t = torch.rand(128, 64, 3, device="cuda", requires_grad=True)
+        texture(t, uv, da, "linear-mipmap-linear", 7, cache=c).backward(g)
+        assert list(c.values()) == [None] and rel_l2(t.grad.cpu().numpy() * 0 + 1, np.ones((128, 64, 3))) == 0
+    finally:
+        TX._TAP_BUDGET = budget
 
 
 def test_fused_mip_fold_adam_is_bit_identical(tx):

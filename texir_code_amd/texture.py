@@ -39,12 +39,22 @@ def _mips_for(owner, t0, levels):
     return rest
 
 
+# Tap lists cost ~28 bytes per tap (8 taps per pixel and texture configuration); beyond this many bytes in total, further views fall
+# back to the float-atomic scatter (hundreds of 1.5 M-pixel views would otherwise pin hundreds of GB).  TEXIR_TAP_CACHE_GB overrides.
+_TAP_BUDGET = int(float(__import__("os").environ.get("TEXIR_TAP_CACHE_GB", "16")) * (1 << 30))
+_tap_bytes = 0
+
+
 def _tap_lists(cache, H, W, C, levels, mode, uv, uv_da):
     """sorted tap lists of a fixed set of fetch coordinates (one view): built once, kept in the caller's per-view cache dict"""
+    global _tap_bytes
     key = ("_taps", H, W, levels, mode, uv.data_ptr(), uv.shape[0])
     hit = cache.get(key)
     if hit is not None:
         return hit
+    if key in cache or _tap_bytes + 28 * 8 * uv.shape[0] > _TAP_BUDGET:
+        cache[key] = None                  # over budget: this view keeps using the atomic scatter
+        return None
     if torch.cuda.is_current_stream_capturing():
         raise _lib.TexirError("tap lists must be built before hipGraph capture (run one eager step first)")
     L = _lib.lib()
@@ -62,6 +72,7 @@ def _tap_lists(cache, H, W, C, levels, mode, uv, uv_da):
     hit = (seg_key.contiguous(), starts.contiguous(), counts.to(torch.int32).contiguous(), (order // 8).to(torch.int32).contiguous(),
            wts[order].contiguous())
     cache[key] = hit
+    _tap_bytes += sum(t.numel() * t.element_size() for t in hit)
     return hit
 
 
