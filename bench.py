@@ -77,7 +77,7 @@ def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5):
     """material-estimation step latency (BASELINE.json: "material-step ms at 4k tex"): stage-2 (joint) optimiser step =
     4 texture fetches (4k albedo x3 / 4k roughness x1 / irradiance, mip stacks rebuilt) + GGX-importance specular trace
     (P = 6*128^2 pixels x 16 spp) + fused RenderLoss/SegLoss + backward + (gradient all-reduce) + fused Adam over 67.1 M texels."""
-    from texir_code_amd import cameras, conf as C, synth
+    from texir_code_amd import cameras, conf as C, dist_util, synth
     from texir_code_amd.loss import RenderLoss
     from texir_code_amd.models import MaterialModel
     from texir_code_amd.optim import FusedAdam
@@ -106,7 +106,7 @@ def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5):
         model.materials_a.copy_(a0)
         model.materials_r.copy_(r0)
     loss_fn = RenderLoss("L1", 1, lazy_item=True)
-    opt = FusedAdam([model.materials_a, model.materials_r], lr=3e-2, fuse_mip_fold=world == 1)
+    opt = FusedAdam([model.materials_a, model.materials_r], lr=3e-2, fuse_mip_fold=True)
     opt.set_clamp(model.materials_r, 1e-2, 0.8)
     opt.set_clamp(model.materials_a, 0.0, float("inf"))
     if world > 1:
@@ -123,8 +123,7 @@ def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5):
     def eager_step(v):
         fwd_bwd(v)
         if world > 1:
-            dist.all_reduce(model.materials_a.grad)
-            dist.all_reduce(model.materials_r.grad)
+            dist_util.reduce_texture_grads([model.materials_a, model.materials_r])
         opt.step()
 
     # hipGraph capture of the launch-bound part of the step (texir_code_amd/graph_step.py); TEXIR_MAT_GRAPH=0 runs eagerly
@@ -153,7 +152,7 @@ def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if gs is not None:
-            gs.step(v, 2, all_reduce=dist.all_reduce if world > 1 else None, shift=nxt)
+            gs.step(v, 2, reduce_grads=dist_util.reduce_texture_grads if world > 1 else None, shift=nxt)
             nxt = gs.draw_shift()           # next step's CPU-generator draw overlaps this step's GPU work (same stream order)
         else:
             eager_step(v)

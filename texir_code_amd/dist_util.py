@@ -26,6 +26,27 @@ def assemble_sum(t):
     return t
 
 
+def reduce_texture_grads(params):
+    """sum the texture gradients over the ranks before the (replicated) optimiser step.  With FusedAdam(fuse_mip_fold=True) a
+    parameter's gradient is the pair (p.grad = level-0 scatter, p._texir_grad_l1 = level-1 stack with everything coarser folded in):
+    the level-1 stack (1/4 of the texture) is always reduced, the full-resolution part only if some rank's pixels sampled level 0 at
+    all (one tiny MAX all-reduce decides, identically on every rank) -- at 4k textures seen through 128^2 cube faces nothing does,
+    and the reduction shrinks from 335 MB to 84 MB."""
+    import torch.distributed as dist
+    params = [p for p in params if p.grad is not None]
+    if not params or not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    need = torch.tensor([0.0 if (getattr(p, "_texir_grad_l1", None) is not None and not getattr(p, "_texir_l0_touched", True)) else 1.0
+                         for p in params], device=params[0].grad.device)
+    dist.all_reduce(need, op=dist.ReduceOp.MAX)
+    for p, n in zip(params, need.tolist()):
+        g1 = getattr(p, "_texir_grad_l1", None)
+        if g1 is not None:
+            dist.all_reduce(g1)
+        if n > 0:
+            dist.all_reduce(p.grad)
+
+
 def morton_order(ids, width):
     """reorder a texel-id list (row-major ids of a [H,width] texture) along the Z-order curve, so that texels processed
     concurrently by neighbouring wavefronts are neighbours on the surface (their rays then share BVH leaves and texture

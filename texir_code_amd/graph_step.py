@@ -66,7 +66,7 @@ class GraphedMatStep:
         # Each graph writes its gradients into its OWN pool buffers (the first capture of an empty pool lays them out differently from
         # the later ones), so the tensors autograd assigned during this capture are remembered per graph and re-attached to the
         # parameters before every optimiser step.
-        self.grads[(key, stage)] = [(p.grad, getattr(p, "_texir_grad_l1", None)) for p in self.params]
+        self.grads[(key, stage)] = [(p.grad, getattr(p, "_texir_grad_l1", None), getattr(p, "_texir_l0_touched", True)) for p in self.params]
         self.graphs[(key, stage)] = g
         self.losses[(key, stage)] = loss.detach()      # keep no autograd graph of the captured region alive
         self.outs[(key, stage)] = self._last_out
@@ -77,7 +77,7 @@ class GraphedMatStep:
         P = self.static_shift.shape[0]
         return torch.rand(P, 1, 2).reshape(P, 2)
 
-    def step(self, key, stage, all_reduce=None, shift=None):
+    def step(self, key, stage, reduce_grads=None, shift=None):
         """one optimiser step on a captured view; returns the (static) loss tensor of that graph"""
         if stage != 0:                                  # stage 0 is Lambertian only: the reference draws no shifts there
             if shift is None:
@@ -87,12 +87,11 @@ class GraphedMatStep:
             self._pinned.copy_(shift)
             self.static_shift.copy_(self._pinned, non_blocking=True)
         self.graphs[(key, stage)].replay()
-        for p, (g, g1) in zip(self.params, self.grads[(key, stage)]):
+        for p, (g, g1, l0) in zip(self.params, self.grads[(key, stage)]):
             p.grad = g
             p._texir_grad_l1 = g1
-        if all_reduce is not None:
-            for p in self.params:
-                if p.grad is not None:
-                    all_reduce(p.grad)
+            p._texir_l0_touched = l0
+        if reduce_grads is not None:
+            reduce_grads(self.params)              # multi-GPU: dist_util.reduce_texture_grads
         self.opt.step()
         return self.losses[(key, stage)]

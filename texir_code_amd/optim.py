@@ -10,8 +10,8 @@ from . import _lib
 class FusedAdam(torch.optim.Optimizer):
     """fuse_mip_fold=True: the [H,W,C] texture parameters ask texture.py's backward to leave the last mip fold (level 1 -> level 0) out
     and this optimiser adds 0.25 * level-1 gradient while it reads the gradient (bit-identical to fold + step; saves one
-    read-modify-write of every texture per step).  Until step() has run, `p.grad` then lacks that term -- do not combine with code
-    that reads or reduces `p.grad` in between (the multi-GPU paths leave it off)."""
+    read-modify-write of every texture per step).  Until step() has run, `p.grad` then lacks that term: code that reduces gradients
+    across ranks in between must treat the pair (p.grad, p._texir_grad_l1), as dist_util.reduce_texture_grads does."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, fuse_mip_fold=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
@@ -21,11 +21,13 @@ class FusedAdam(torch.optim.Optimizer):
             for p in group["params"]:
                 p._texir_defer_fold = self.fuse_mip_fold and p.dim() == 3 and p.shape[0] % 2 == 0 and p.shape[1] % 2 == 0
                 p._texir_grad_l1 = None
+                p._texir_l0_touched = False
 
     def zero_grad(self, set_to_none=True):
         for group in self.param_groups:
             for p in group["params"]:
                 p._texir_grad_l1 = None
+                p._texir_l0_touched = False
         super().zero_grad(set_to_none=set_to_none)
 
     def release(self):

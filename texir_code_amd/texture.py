@@ -69,10 +69,11 @@ def _tap_lists(cache, H, W, C, levels, mode, uv, uv_da):
     ks, order = ks[first:], order[first:]
     seg_key, counts = torch.unique_consecutive(ks, return_counts=True)
     starts = (torch.cumsum(counts, 0) - counts).to(torch.int32)
+    has_l0 = bool(seg_key.numel() > 0 and int(seg_key[0].item()) < H * W)        # keys are sorted: level-0 texels come first
     hit = (seg_key.contiguous(), starts.contiguous(), counts.to(torch.int32).contiguous(), (order // 8).to(torch.int32).contiguous(),
-           wts[order].contiguous())
+           wts[order].contiguous(), has_l0)
     cache[key] = hit
-    _tap_bytes += sum(t.numel() * t.element_size() for t in hit)
+    _tap_bytes += sum(t.numel() * t.element_size() for t in hit[:5])
     return hit
 
 
@@ -110,7 +111,7 @@ class _TexFetch(torch.autograd.Function):
                  and getattr(owner, "_texir_grad_l1", None) is None)
         if ctx.taps is not None:
             # fixed fetch coordinates (a cached view): deterministic gather over the pre-sorted tap lists instead of float atomics
-            seg_key, starts, counts, pix, wts = ctx.taps
+            seg_key, starts, counts, pix, wts, _ = ctx.taps
             _lib.check(L.texir_tex_gather_backward(_lib.ptr(d_tex), _lib.ptr(g_rest), H, W, C, levels, _lib.ptr(seg_key), _lib.ptr(starts),
                                                    _lib.ptr(counts), seg_key.numel(), _lib.ptr(pix), _lib.ptr(wts), _lib.ptr(d_out), mode,
                                                    1 if defer else 0, _lib.stream_ptr()))
@@ -122,6 +123,12 @@ class _TexFetch(torch.autograd.Function):
                                                   _lib.ptr(d_out), _lib.stream_ptr()))
         if defer:
             owner._texir_grad_l1 = g_rest[:(H // 2) * (W // 2) * C]
+        if owner is not None:
+            # does the level-0 gradient of this parameter hold anything at all after this backward pass?  A deferred fetch none of whose
+            # pixels samples level 0 leaves d_tex all zero (the multi-GPU reduction can then skip it); any other fetch of the parameter
+            # writes it.  Sticky over the fetches of one backward pass; FusedAdam.zero_grad resets it.
+            wrote_l0 = (ctx.taps[5] if ctx.taps is not None else True) if defer else True
+            owner._texir_l0_touched = bool(getattr(owner, "_texir_l0_touched", False)) or wrote_l0
         return d_tex, None, None, None, None, None, None, None
 
 

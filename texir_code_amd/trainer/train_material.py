@@ -119,17 +119,16 @@ class MatTrainRunner:
             self._gs.capture(vid0, mvp, cam, gt, gmask, self.seg_mask[str(vid0)], self.floor_max_mask[str(vid0)],
                              self.room_seg_mask[str(vid0)] if stage == 2 else None, stage)
         world = dist_util.world_info()[1]
-        self._gs.step(vid0, stage, all_reduce=dist_util.assemble_sum if world > 1 else None)
+        self._gs.step(vid0, stage, reduce_grads=dist_util.reduce_texture_grads if world > 1 else None)
         out = self._gs.outs[(vid0, stage)]
         return out[0], out[1]
 
     def _new_optimizer(self):
         """fresh Adam + StepLR over ALL model parameters (train_material.py:122-128, 472-476, 539-543); the post-step
         clamps of :458/:592-593 are fused into the optimiser kernel"""
-        # single process: the last mip fold of the texture backward is fused into the optimiser's read of the gradient (bit-identical);
-        # with several ranks the gradients are all-reduced in between, so they must be complete
-        self.mat_optimizer = FusedAdam(self.model.parameters(), lr=self.conf.get_float("train.mat_learning_rate"),
-                                       fuse_mip_fold=dist_util.world_info()[1] == 1)
+        # the last mip fold of the texture backward is fused into the optimiser's read of the gradient (bit-identical); with several
+        # ranks dist_util.reduce_texture_grads sums the (level 0, level 1) pair instead of the folded gradient
+        self.mat_optimizer = FusedAdam(self.model.parameters(), lr=self.conf.get_float("train.mat_learning_rate"), fuse_mip_fold=True)
         self.mat_optimizer.set_clamp(self.model.materials_r, 1e-2, 0.8)
         self.mat_scheduler = torch.optim.lr_scheduler.StepLR(self.mat_optimizer, self.conf.get_int("train.mat_sched_step", default=100),
                                                             gamma=self.conf.get_float("train.mat_sched_factor", default=0.0))
@@ -193,9 +192,7 @@ class MatTrainRunner:
         self.mat_optimizer.zero_grad()
         loss.backward()
         if dist_util.world_info()[1] > 1:
-            for p in (self.model.materials_a, self.model.materials_r):
-                if p.grad is not None:
-                    dist_util.assemble_sum(p.grad)
+            dist_util.reduce_texture_grads([self.model.materials_a, self.model.materials_r])
         self.mat_optimizer.step()
         return loss, out[1]
 
