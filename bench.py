@@ -45,8 +45,9 @@ def algorithmic_bytes_per_ray(counters, spp):
     return 32.0 * nodes / rays + 36.0 * tris / rays + (hits / rays) * 72.0 + 45.0 / spp, nodes / rays, tris / rays, hits / rays
 
 
-def cpu_leg(sc0, pos, nrm, valid, shift, spp, budget_s=15.0):
-    """oracle timed on host cores on a bounded sample; also yields the algorithmic bytes/ray."""
+def cpu_leg(sc0, pos, nrm, valid, shift, spp, budget_s=15.0, timed=True):
+    """oracle timed on host cores on a bounded sample; also yields the algorithmic bytes/ray.  timed=False (N > 1: the CPU baseline is
+    reported at N = 1 only): just the small counting sample."""
     from oracle import oracle as O
     osc = O.Scene(sc0["verts"], sc0["tris"], sc0["tri_uvs"], sc0["hdr"])
     vid = np.argwhere(valid.reshape(-1) > 0)[:, 0]
@@ -66,6 +67,8 @@ def cpu_leg(sc0, pos, nrm, valid, shift, spp, budget_s=15.0):
     cores = O.num_threads()
     run(cores)                                   # warm the thread pool / page in the BVH
     dt, c, n = run(max(cores * 8, 64))           # calibration sample (dynamic schedule needs >> cores texels)
+    if not timed:
+        return None, c
     rate = n * spp / dt
     n_big = int(max(n, min(vid.size, 0.6 * budget_s * rate / spp)))
     dt, c, n = run(n_big)
@@ -274,7 +277,7 @@ def main():
             out["material_step"] = mat
         rays_this_rank = int(ids.numel()) * spp
         if not args.no_cpu:
-            cpu, counters = cpu_leg(sc0, pos, nrm, valid, shift, spp)
+            cpu, counters = cpu_leg(sc0, pos, nrm, valid, shift, spp, timed=world == 1)
             bpr, nbar, tbar, phit = algorithmic_bytes_per_ray(counters, spp)
             from texir_code_amd import _lib
             launches = int(_lib.lib().texir_irt_launch_count(spp))
