@@ -170,12 +170,13 @@ TEXIR_API int texir_tex_fetch_backward(float* d_tex /*dev*/, float* grad_rest /*
                        int32_t C, int32_t levels, const float* uv, const float* uv_da, int32_t filter_mode, int64_t P,
                        const float* d_out /*dev [P,C]*/, void* stream);
 
-/* As texir_tex_fetch_backward (trilinear), but the last fold is left out: on return d_tex holds the level-0 scatter only and the first
+/* As texir_tex_fetch_backward (trilinear; the autograd backward of dr.texture, models/mat_nvdiffrast.py:131,134), but the last fold is left out: on return d_tex holds the level-0 scatter only and the first
  * (H/2)*(W/2)*C floats of grad_rest hold the level-1 gradient with all coarser levels folded in.  texir_adam_step_tex consumes the pair. */
 TEXIR_API int texir_tex_fetch_backward_deferred(float* d_tex /*dev*/, float* grad_rest /*dev*/, int32_t H, int32_t W, int32_t C,
                        int32_t levels, const float* uv, const float* uv_da, int64_t P, const float* d_out /*dev [P,C]*/, void* stream);
 
-/* Atomics-free backward for fetches whose (uv, uv_da) never change (a cached view: geometry and cameras are constant).
+/* Atomics-free backward of the dr.texture fetches (models/mat_nvdiffrast.py:131-139) whose (uv, uv_da) never change (a cached view:
+ * geometry and cameras are constant).
  * texir_tex_taps lists the taps of every pixel: keys/weights [P*8] (4 bilinear taps x 2 mip levels; bilinear mode uses the first 4),
  * key = texel index in the unified order [level 0 | levels 1.. as in mips_rest], -1 for unused slots, weight = bilinear x level blend.
  * The caller sorts them by key once (stable), forms segments (key, start, count) + the sorted (pixel, weight) lists, and then every
@@ -193,7 +194,7 @@ TEXIR_API int texir_tex_gather_backward(float* d_tex, float* grad_rest, int32_t 
 TEXIR_API int texir_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                        float beta1, float beta2, float eps, int32_t step, float clamp_lo, float clamp_hi, void* stream);
 
-/* The same step for a texture [H,W,C] whose gradient is grad + 0.25 * grad_level1[y/2][x/2] (texir_tex_fetch_backward_deferred): the
+/* The same step (trainer/train_material.py:448-458) for a texture [H,W,C] whose gradient is grad + 0.25 * grad_level1[y/2][x/2] (texir_tex_fetch_backward_deferred): the
  * last mip fold is fused into the optimiser's read of the gradient; results equal fold + texir_adam_step bit for bit. */
 TEXIR_API int texir_adam_step_tex(float* param, const float* grad, const float* grad_level1, float* exp_avg, float* exp_avg_sq, int32_t H,
                        int32_t W, int32_t C, float lr, float beta1, float beta2, float eps, int32_t step, float clamp_lo, float clamp_hi,
