@@ -399,13 +399,13 @@ static int resident_grid(K kernel, int block)
     return cus * per_cu;
 }
 
-// TEXIR_IRT_TEXELS_PER_WAVE = 1 | 16 | 64 forces the kernel form (A/B measurements, parity tests of each form); unset or 0 = automatic.
+// TEXIR_IRT_TEXELS_PER_WAVE = 1 | 64 forces the kernel form (A/B measurements, parity tests of each form); unset or 0 = automatic.
 // Read on every call, so a test can switch it between launches.
 static int irt_forced_texels_per_wave()
 {
     const char* e = getenv("TEXIR_IRT_TEXELS_PER_WAVE");
     const int v = e ? atoi(e) : 0;
-    return (v == 1 || v == 16 || v == 64) ? v : 0;
+    return (v == 1 || v == 64) ? v : 0;
 }
 
 int irt_launch_count(int) { return 1; }
@@ -433,11 +433,10 @@ hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, co
     const int l2 = ilog2_exact(N);
 #define TEXIR_IRT(WAVES, L2, NAME, ...) { if (stats) irt_launch(NAME<true, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, work, partial, log2parts, st); \
                                         else irt_launch(NAME<false, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, work, partial, log2parts, st); }
-    // texels per wave: 64 when the list is long enough to fill the chip that way (5 waves x 4 SIMDs x 256 CUs), else 16, else 1 --
-    // a 1024-point NIrF batch would otherwise occupy 16 wavefronts
-    const int64_t fill = 4096;
-    int per_wave = forced ? forced : (n_ids >= 64 * fill ? 64 : (n_ids >= 16 * fill ? 16 : 1));
-    if (per_wave == 16 && !(pow2 && l2 >= 7)) per_wave = forced ? 64 : 1;
+    // texels per wave: 64 from 65 536 listed texels up, else 1 (measured on the c2 scene, Mrays/s for 1 / 64 per wave: 16 k texels
+    // 10 016 / 5 162, 65 k 11 256 / 11 342, 131 k 11 124 / 12 221, 524 k 11 116 / 15 322 -- a short list does not fill the chip with
+    // 64-texel groups; a 16-texel form was slower than both at every length and is gone)
+    int per_wave = forced ? forced : (n_ids >= 65536 ? 64 : 1);
     // 64 texels per wave: the passes of a texel are cut into 2^log2parts ranges of >= 256 passes (N = 2048: 8 parts), each range its own
     // chunk -- at 8 GPUs a rank's share is only ~3 whole-texel chunks per wave, and the idle tail is half a chunk on average.  The
     // number of parts depends on N alone, so results do not depend on the sharding.
@@ -462,7 +461,6 @@ hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, co
     }
     if (!sc.nodes4) TEXIR_IRT(n_ids, l2, irt_kernel, 2)                                        // deep binary tree (capi.hip fallback)
     else if (per_wave == 1) TEXIR_IRT(n_ids, l2, irt_kernel, 4)
-    else if (per_wave == 16) TEXIR_IRT((n_ids + 15) / 16, l2, irt_group_kernel, 4, 4)
     else TEXIR_IRT(((n_ids + 63) / 64) << log2parts, pow2 ? l2 : -1, irt_group_kernel, 4, 6)   // any N (natural sample order if not 2^k)
 #undef TEXIR_IRT
     if (log2parts) {

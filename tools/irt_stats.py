@@ -1,5 +1,5 @@
 """Per-ray traversal statistics of the IrT kernel on a sample of a bench workload (counting build of the product kernel).
-usage: python tools/irt_stats.py [workload] [texels]      (env TEXIR_IRT_TEXELS_PER_WAVE=1|16|64 forces a kernel form)"""
+usage: python tools/irt_stats.py [workload] [texels]      (env TEXIR_IRT_TEXELS_PER_WAVE=1|64 forces a kernel form)"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
