@@ -38,10 +38,15 @@ __device__ __forceinline__ void irt_stats_flush(unsigned long long* stats, int l
     }
 }
 
+// Occupancy: 7 waves/SIMD (<= 72 VGPRs; the compiler parks the per-texel frame in scratch across the traversal loop) with a
+// 16-entry LDS stack (16 KiB per block) measured best: 5 waves / 24 entries 13.85, 6 / 24 14.79, 7 / 16 15.11, 8 / 16 15.06 Grays/s (c4).
+constexpr int kGroupLstk = 16;
+constexpr int kGroupWaves = 7;
+
 // One texel per wave: the 64 lanes trace 64 samples of the texel per pass (any N, binary or 4-wide tree).  Kept as the
 // form for short texel lists (a 1024-point NIrF batch), for binary-tree scenes, and TEXIR_IRT_TEXELS_PER_WAVE=1.
 template <bool STATS, int WIDTH>
-__global__ __launch_bounds__(kBlock) void irt_kernel(SceneDev sc, const float* __restrict__ pos, const float* __restrict__ nrm,
+__global__ __launch_bounds__(kBlock, kGroupWaves) void irt_kernel(SceneDev sc, const float* __restrict__ pos, const float* __restrict__ nrm,
                                                      const float* __restrict__ shift, const int32_t* __restrict__ ids, int64_t n_ids,
                                                      int N, int log2N, int mode, float* __restrict__ irr,
                                                      unsigned long long* __restrict__ stats, unsigned long long* /*work*/, float* /*partial*/, int /*log2parts*/)
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void irt_kernel(SceneDev sc, const float* _
                 float s1 = shift_wrap_clamp(ham1(i), sh1);
                 float d[3];
                 sample_dir(mode, s0, s1, 0.f, f, d);
-                Hit h = trace_closest<STATS, kLdsStack, WIDTH>(sc, px, py, pz, d[0], d[1], d[2], c_nodes, c_tris, STATS ? wi : nullptr);
+                Hit h = trace_closest<STATS, kGroupLstk, WIDTH>(sc, px, py, pz, d[0], d[1], d[2], c_nodes, c_tris, STATS ? wi : nullptr);
                 if (STATS) c_rays++;
                 if (h.slot >= 0 && h.t > 1e-4f) {          // tracer_o3d_irt.py:248
                     float L[3];
@@ -114,11 +119,6 @@ __device__ __forceinline__ uint32_t cell_to_pass_m(uint32_t J, float sh0, float 
     uint32_t low = bphi ? (__brev(phibin) >> (32 - bphi)) : 0u;
     return (th << bphi) | low;
 }
-
-// Occupancy: 7 waves/SIMD (<= 72 VGPRs; the compiler parks the per-texel frame in scratch across the traversal loop) with a
-// 16-entry LDS stack (16 KiB per block) measured best: 5 waves / 24 entries 13.85, 6 / 24 14.79, 7 / 16 15.11, 8 / 16 15.06 Grays/s (c4).
-constexpr int kGroupLstk = 16;
-constexpr int kGroupWaves = 7;
 
 template <bool STATS, int WIDTH, int LOG2GRP>
 __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev sc, const float* __restrict__ pos, const float* __restrict__ nrm,
@@ -433,10 +433,10 @@ hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, co
     const int l2 = ilog2_exact(N);
 #define TEXIR_IRT(WAVES, L2, NAME, ...) { if (stats) irt_launch(NAME<true, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, work, partial, log2parts, st); \
                                         else irt_launch(NAME<false, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, work, partial, log2parts, st); }
-    // texels per wave: 64 from 65 536 listed texels up, else 1 (measured on the c2 scene, Mrays/s for 1 / 64 per wave: 16 k texels
-    // 10 016 / 5 162, 65 k 11 256 / 11 342, 131 k 11 124 / 12 221, 524 k 11 116 / 15 322 -- a short list does not fill the chip with
+    // texels per wave: 64 from 98 304 listed texels up, else 1 (measured on the c2 scene, Mrays/s for 1 / 64 per wave: 16 k texels
+    // 10 688 / 5 296, 65 k 11 352 / 10 813, 131 k 11 674 / 12 463, 524 k 11 438 / 15 222 -- a short list does not fill the chip with
     // 64-texel groups; a 16-texel form was slower than both at every length and is gone)
-    int per_wave = forced ? forced : (n_ids >= 65536 ? 64 : 1);
+    int per_wave = forced ? forced : (n_ids >= 98304 ? 64 : 1);
     // 64 texels per wave: the passes of a texel are cut into 2^log2parts ranges of >= 256 passes (N = 2048: 8 parts), each range its own
     // chunk -- at 8 GPUs a rank's share is only ~3 whole-texel chunks per wave, and the idle tail is half a chunk on average.  The
     // number of parts depends on N alone, so results do not depend on the sharding.
