@@ -86,10 +86,10 @@ TEXIR_API int texir_generate_dir(const float* normals /*dev*/, const float* roug
  *   texel_ids [n_ids] i32 dev: the texels to compute (NULL => all Nt, n_ids ignored).  Seam texels
  *     (index texture all-zero, :137-139,176-178) are simply not listed; irr must be zero-initialised by the caller.
  *   irr [Nt,3] dev: only listed texels are written.  A texel's value has a fixed summation order per kernel form, so for lists of
- *     >= 98304 texels (the 64-texels-per-wave form; shorter lists use the one-texel-per-wave form, which differs in the last bits) the texture does
+ *     >= 32768 texels (the 64-texels-per-wave form; shorter lists use the one-texel-per-wave form, which differs in the last bits) the texture does
  *     not depend on the order or sharding of texel_ids nor on the launch configuration.
- *   Long lists (>= 98304 texels) use a stream-ordered scratch allocation (hipMallocAsync/hipFreeAsync on `stream`,
- *     96 bytes per listed texel at N >= 2048) for the per-pass-range partial sums.
+ *   Long lists (>= 32768 texels) use a stream-ordered scratch allocation (hipMallocAsync/hipFreeAsync on `stream`,
+ *     384 bytes per listed texel at N >= 2048) for the per-pass-range partial sums.
  *   stats [8] u64 dev, nullable: += rays, 64-byte node fetches, triangle tests, hits, wave-level node steps, wave-level
  *   triangle steps (how often a wavefront executed each loop body: lane utilisation = lane count / (64 * wave count)), 2 reserved. */
 TEXIR_API int texir_irt_generate(const texir_scene* scene, const float* pos /*dev*/, const float* nrm /*dev*/,

@@ -433,20 +433,20 @@ hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, co
     const int l2 = ilog2_exact(N);
 #define TEXIR_IRT(WAVES, L2, NAME, ...) { if (stats) irt_launch(NAME<true, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, work, partial, log2parts, st); \
                                         else irt_launch(NAME<false, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, work, partial, log2parts, st); }
-    // texels per wave: 64 from 98 304 listed texels up, else 1 (measured on the c2 scene, Mrays/s for 1 / 64 per wave: 16 k texels
-    // 10 688 / 5 296, 65 k 11 352 / 10 813, 131 k 11 674 / 12 463, 524 k 11 438 / 15 222 -- a short list does not fill the chip with
-    // 64-texel groups; a 16-texel form was slower than both at every length and is gone)
-    int per_wave = forced ? forced : (n_ids >= 98304 ? 64 : 1);
-    // 64 texels per wave: the passes of a texel are cut into 2^log2parts ranges of >= 256 passes (N = 2048: 8 parts), each range its own
-    // chunk -- at 8 GPUs a rank's share is only ~3 whole-texel chunks per wave, and the idle tail is half a chunk on average.  The
-    // number of parts depends on N alone, so results do not depend on the sharding.
+    // texels per wave: 64 from 32 768 listed texels up, else 1 (a short list does not fill the chip with 64-texel groups; measured on the
+    // c2 scene, Grays/s for 1 / 64 per wave: 16 k texels 10.7 / 10.1, 65 k 11.3 / 14.3, 131 k 11.5 / 14.8, 524 k 11.3 / 16.0; a 16-texel
+    // form was slower than both at every length and is gone)
+    int per_wave = forced ? forced : (n_ids >= 32768 ? 64 : 1);
+    // 64 texels per wave: the passes of a texel are cut into 2^log2parts ranges of >= 64 passes (N = 2048: 32 ranges), each range its
+    // own chunk.  Fine chunks matter for lists up to ~1 M texels (262 k texels: 8 ranges 14.1, 32 ranges 15.7 Grays/s), i.e. for every
+    // rank's share of a multi-GPU run; the number of ranges depends on N alone, so results do not depend on the sharding.
     float* partial = nullptr;
     int log2parts = 0;
-    if (sc.nodes4 && per_wave == 64 && pow2) { while (log2parts < 3 && (N >> (log2parts + 1)) >= 256) log2parts++; }
+    if (sc.nodes4 && per_wave == 64 && pow2) { while (log2parts < 5 && (N >> (log2parts + 1)) >= 64) log2parts++; }
     if (const char* cap = getenv("TEXIR_IRT_LOG2PARTS")) { if (log2parts > atoi(cap)) log2parts = atoi(cap) < 0 ? 0 : atoi(cap); }   // A/B switch
     if (log2parts) {
         const size_t bytes = sizeof(float) * 3 * (size_t)n_ids << log2parts;
-        // stream-ordered scratch (1.2 GB at 4k^2 texels); keep it cached in the device's pool between calls instead of
+        // stream-ordered scratch (384 B per listed texel at N >= 2048: 4.8 GB at 4k^2 texels); keep it cached in the device's pool between calls instead of
         // returning it to the OS at every synchronisation
         static bool pool_set = false;
         if (!pool_set) {
