@@ -108,6 +108,10 @@ class MatTrainRunner:
             self._gs = GraphedMatStep(self.model, self.mat_loss, self.mat_optimizer, [self.model.materials_a, self.model.materials_r])
             self._gs_inputs = getattr(self, "_gs_inputs", {})
         if (vid0, stage) not in self._gs.graphs:
+            # every captured (view, stage) graph pins its own gradient buffers (~1.3 x the texture bytes); beyond the budget further views
+            # run the eager step (TEXIR_MAX_GRAPHS, default 96 ~ 43 GB at 4k textures; a new stage starts a fresh set)
+            if len(self._gs.graphs) >= int(os.environ.get("TEXIR_MAX_GRAPHS", "96")):
+                return None
             if vid0 not in self._gs_inputs:
                 gt = gt_item["color"].float().cuda()
                 h, w, c = gt.shape[-3:]
@@ -165,7 +169,9 @@ class MatTrainRunner:
     def train_step(self, gt_item, stage):
         """one optimiser step (train_material.py:424-458 / 486-525 / 552-593)"""
         if getattr(self, "use_graph", False) and not (dist_util.world_info()[1] > 1 and getattr(self, "mat_shard", "pixel") == "pixel"):
-            return self._graph_step(gt_item, stage)
+            res = self._graph_step(gt_item, stage)
+            if res is not None:
+                return res
         gt_color = gt_item["color"].float().cuda()
         h, w, c = gt_color.shape[-3:]
         gt_color = gt_color.reshape(-1, h, w, c)
