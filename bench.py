@@ -4,21 +4,31 @@ A "step" is one full pass of the hot path (fused sample + BVH trace + shade + re
 texir_irt_generate) over the workload's valid texels at its spp.  Inputs (BVH, radiance texture, texel
 G-buffers, shifts) are resident in HBM before the timed region.
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload c2|c4|c1|tiny]
+    python bench.py [--gpus N --steps K --warmup W] [--workload c4|c4_scan|c2|c1|tiny]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself under torch.distributed.run with N ranks
+(one per GPU, backend nccl = RCCL); it refuses loudly when the box has fewer than N devices.
 
 Multi-GPU: one process per GPU; the compacted valid-texel list is dealt block-cyclically to the ranks
 (strong scaling of ONE texture), each rank writes its texels into a zero-initialised full texture and a single
 RCCL all_reduce(SUM) assembles it (disjoint support) -- inside the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes/ray (canonical-BVH2 visit counts measured
-by the CPU oracle on a sample of the same rays) x rays per launch / mean kernel time (HIP events).
+Prints ONE JSON line (rank 0).  `roofline` carries two bounds that hold (both <= 1), each = a per-launch counter of the
+dominant kernel (rocprofv3 --pmc, committed under profiles/pmc_<workload>.json together with a hash of the kernel sources
+-- a profile of other sources is refused) divided by the kernel time measured live with HIP events:
+  * memory: fabric-side bytes (L2 <-> Infinity Cache/HBM read requests x 128 B + writes) / time / 8 TB/s,
+  * VALU issue: SQ_INSTS_VALU / (1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction x time).
+`bound` names the larger.  SURVEY.md 8(d)'s algorithmic bytes (canonical BVH2 visit counts x 32/36 B) are reported under
+`algorithmic` -- they are served by L1/L2 hits of a 4x more compact tree and exceed the HBM peak, so they bound nothing.
 `cpu_baseline` = the CPU oracle (a port of the reference algorithm; Open3D/Embree is not installable here) timed
 on this box's host cores on a bounded sample of the same workload.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,14 +39,52 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (triangles, texel res, radiance-texture res, spp)
-    "tiny": (20000, 128, 256, 64),
-    "c1": (20000, 512, 512, 64),        # configs[0] sizes (reference's CPU-runnable case)
-    "c2": (200000, 2048, 2048, 2048),   # configs[1]: IrT 2048 spp, 2k x 2k, 200k-tri mesh, 1 MI355X
-    "c4": (1000000, 4096, 4096, 2048),  # configs[3]: 4k x 4k, 1M-tri
+    # name: (triangles, texel res, radiance-texture res, spp, scene style)
+    "tiny": (20000, 128, 256, 64, "room"),
+    "c1": (20000, 512, 512, 64, "room"),        # configs[0] sizes (reference's CPU-runnable case)
+    "c2": (200000, 2048, 2048, 2048, "room"),   # configs[1]: IrT 2048 spp, 2k x 2k, 200k-tri mesh, 1 MI355X
+    "c4": (1000000, 4096, 4096, 2048, "room"),  # configs[3]: 4k x 4k, 1M-tri (the configuration the metric is quoted on)
+    # hostile sibling of c4 (never the headline): rotated clutter, thin slats, two openings (p_hit < 1), noisy "scanned" surfaces
+    "c4_scan": (1000000, 4096, 4096, 2048, "scan"),
+    "tiny_scan": (20000, 128, 256, 64, "scan"),
+    # experiment: c4 with a 1k^2 radiance texture (12.6 MB: L2/Infinity-Cache resident) -- how much of c4's time is texture traffic
+    "c4_tex1k": (1000000, 4096, 1024, 2048, "room"),
 }
 HBM_PEAK_GBS = 8000.0
+SIMDS, CLOCK_HZ = 1024, 2.4e9                  # 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles
 BLOCK = 4096  # texels per block of the block-cyclic rank partition
+KERNEL_SOURCES = ["kernels.hip", "device_common.h", "kernels.h", "bvh_build.cpp", "bvh_build.h", "capi.hip", "Makefile"]
+
+
+def kernel_src_sha():
+    """hash of the sources the dominant kernel is built from: a PMC profile only describes the library it was taken with"""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "texir_code_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def make_workload(name, cache=None):
+    """(sc0, pos, nrm, valid, shift, res, spp) of a named workload; seed 666 everywhere.  `cache` (or
+    $TEXIR_SYNTH_CACHE) names a directory where the generated arrays are kept between processes of one session."""
+    from texir_code_amd import synth
+    T, res, tex_res, spp, style = WORKLOADS[name]
+    cache = cache or os.environ.get("TEXIR_SYNTH_CACHE")
+    path = os.path.join(cache, "%s.npz" % name) if cache else None
+    if path and os.path.exists(path):
+        z = np.load(path)
+        sc0 = {k: z[k] for k in ("verts", "tris", "tri_uvs", "hdr", "tri_class")}
+        sc0.update({"T": T, "style": style, "seed": 666})
+        return sc0, z["pos"], z["nrm"], z["valid"], z["shift"], res, spp
+    sc0 = synth.make_scene(T, seed=666, tex_res=tex_res, style=style)
+    pos, nrm, valid = synth.make_texel_gbuffer(sc0, res)
+    shift = synth.make_shifts(res * res)
+    if path:
+        os.makedirs(cache, exist_ok=True)
+        tmp = path + ".tmp%d.npz" % os.getpid()
+        np.savez(tmp, pos=pos, nrm=nrm, valid=valid, shift=shift, **{k: sc0[k] for k in ("verts", "tris", "tri_uvs", "hdr", "tri_class")})
+        os.replace(tmp, path)
+    return sc0, pos, nrm, valid, shift, res, spp
 
 
 def algorithmic_bytes_per_ray(counters, spp):
@@ -55,8 +103,6 @@ def cpu_leg(sc0, pos, nrm, valid, shift, spp, budget_s=15.0, timed=True):
 
     def run(n_tex):
         pick = rng.choice(vid, size=min(n_tex, vid.size), replace=False)
-        v = np.zeros(valid.size, np.uint8)
-        v[pick] = 1
         # compact so the oracle does not scan the whole texture
         c = O.new_counters()
         t0 = time.perf_counter()
@@ -91,6 +137,9 @@ def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5):
     irrt = torch.flip(irr_tex.reshape(res, res, 3), dims=[0]).contiguous()          # file orientation
     model = MaterialModel.from_arrays(sc, sc0["hdr"], irrt, conf, albedo_res=tres, roughness_res=tres)
     views = [cameras.cube_mvps(E) for E in cameras.grid_cameras(4)]
+    sc0 = dict(sc0)
+    if "patches" not in sc0:                 # (workload came from the array cache: the chart list is needed for the GT materials)
+        sc0["patches"] = synth.make_scene(sc0["T"], seed=666, tex_res=8, style=sc0.get("style", "room"))["patches"]
     alb_gt, rgh_gt = synth.make_gt_materials(sc0, tres, tres)
     tri_class = torch.from_numpy(sc0["tri_class"]).to(dev)
     data = []
@@ -168,12 +217,80 @@ def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5):
         tt = torch.tensor([med], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         med = float(tt.item())
+    # algorithmic HBM bytes of one step: fused Adam 28 B/param (the level-1 gradient it folds in is another 1 B/param),
+    # mip build of both trainable textures (read level 0, write 1/3), gradient stacks of the touched mip levels, G-buffer + loss streams
+    n_par = tres * tres * 4
+    P = 6 * cube * cube
+    step_bytes = 28.0 * n_par + 4.0 * n_par * (1.0 + 1.0 / 3.0) + 4.0 * n_par / 4.0 + P * (24 + 8 + 16 + 12 + 2 + 12 + 3 * 16 * 12.0)
     # N > 1: throughput mode -- every rank renders a different view per optimiser step and the dense texture gradients (335 MB at 4k^2) are
     # all-reduced, so one step covers `world` views: compare ms_per_view across N, not ms
     return {"ms": round(med, 3), "views_per_step": world, "ms_per_view": round(med / world, 3),
             "stage": 2, "steps": steps, "warmup": warmup, "hipgraph": bool(graphs),
+            "roofline": {"bound": "hbm", "achieved": round(step_bytes / (med * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(step_bytes / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_step": int(step_bytes),
+                         "note": "algorithmic bytes: Adam 28 B x %.1f M params + mip build + level-1 gradient + per-pixel streams; the %d x %d specular "
+                                 "rays are cache-served BVH traffic and are not counted" % (n_par / 1e6, P, S)},
             "config": "stage-2 step: albedo %d^2x3 + roughness %d^2x1 (%.1f M params), %d px x %d spp, %d-tri mesh, %d views%s"
                       % (tres, tres, (tres * tres * 4) / 1e6, 6 * cube * cube, S, sc0["T"], len(views), ", view-sharded + grad all_reduce" if world > 1 else "")}
+
+
+def load_pmc(workload, kernel):
+    """per-launch PMC counters of the dominant kernel for this workload (written by tools/profile_round.sh); None -- with the
+    reason -- when there is no profile of THESE kernel sources / this kernel form"""
+    path = os.path.join(ROOT, "profiles", "pmc_%s.json" % workload)
+    if not os.path.exists(path):
+        return None, "no profiles/pmc_%s.json" % workload
+    tj = json.load(open(path))
+    if tj.get("kernel_src_sha") != kernel_src_sha():
+        return None, "profiles/pmc_%s.json was taken with other kernel sources (%s != %s)" % (workload, tj.get("kernel_src_sha"), kernel_src_sha())
+    if kernel not in tj.get("kernel", ""):
+        return None, "profiles/pmc_%s.json describes %s, this run launched %s" % (workload, tj.get("kernel"), kernel)
+    return tj, None
+
+
+def roofline(workload, kernel, kern_ms, rays_this_rank, world, alg):
+    """the two bounds of the module docstring; `alg` = (bytes/ray, nodes/ray, tris/ray, p_hit) of SURVEY 8(d) or None"""
+    t = kern_ms * 1e-3
+    out = {"bound": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+           "kernel": kernel, "kernel_ms": round(kern_ms, 3), "rays_per_launch": rays_this_rank}
+    pmc, why = load_pmc(workload, kernel) if world == 1 else (None, "PMC profiles are taken at N = 1")
+    if pmc is None:
+        out["note"] = "no measured bound: " + why
+    else:
+        traffic = float(pmc["fabric_bytes_per_launch"])
+        valu = float(pmc["SQ_INSTS_VALU"])
+        mem_frac = traffic / t / 1e9 / HBM_PEAK_GBS
+        valu_frac = valu / (SIMDS * CLOCK_HZ / 2.0 * t)
+        out.update({"bound": "hbm" if mem_frac >= valu_frac else "valu", "achieved": round(traffic / t / 1e9, 1), "frac": round(max(mem_frac, valu_frac), 4),
+                    "traffic": traffic, "memory": {"fabric_bytes_per_launch": traffic, "gbs": round(traffic / t / 1e9, 1), "frac_of_8TBs": round(mem_frac, 4),
+                                                   "bytes_per_ray": round(traffic / rays_this_rank, 1), "l2_hit_rate": pmc.get("l2_hit_rate")},
+                    "valu_issue": {"insts_per_launch": valu, "peak_insts_per_s": SIMDS * CLOCK_HZ / 2.0, "frac": round(valu_frac, 4),
+                                   "lane_utilisation": pmc.get("valu_lane_utilisation"), "insts_per_64_rays": round(valu / (rays_this_rank / 64.0), 1)},
+                    "profile": "profiles/pmc_%s.json (%s)" % (workload, pmc.get("source", ""))})
+    if alg is not None:
+        bpr, nbar, tbar, phit = alg
+        out["algorithmic"] = {"bytes_per_ray": round(bpr, 1), "nodes_per_ray": round(nbar, 2), "tris_per_ray": round(tbar, 2), "p_hit": round(phit, 4),
+                              "gbs": round(bpr * rays_this_rank / t / 1e9, 1),
+                              "note": "SURVEY 8(d) canonical-BVH2 visit bytes; cache-served, exceeds the HBM peak by construction -- not a bound"}
+    return out
+
+
+def spawn(args):
+    """--gpus N without a launcher: re-execute under torch.distributed.run, one rank per GPU"""
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        sys.exit("bench.py: %d ranks requested (--gpus %d) but this box has %d GPU(s); refusing to report a %d-GPU number"
+                 % (args.gpus, args.gpus, n_dev, args.gpus))
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -185,7 +302,12 @@ def main():
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-mat", action="store_true")
+    ap.add_argument("--extra", default="", help="comma-separated extra workloads timed after the headline (IrT only), reported under extra_workloads")
     args = ap.parse_args()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn(args)
 
     # host torch ops on the path are tiny (the per-step CPU-generator draw of 2P floats): one intra-op thread, like the reference's
     # runners (trainer/train_material.py:34).  With the default (= all cores) the draw's OpenMP fork/join jitters by milliseconds.
@@ -193,110 +315,125 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    local = local % max(1, torch.cuda.device_count())            # lets a 2-rank smoke test share one GPU (with TEXIR_DIST_BACKEND=gloo)
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    backend = os.environ.get("TEXIR_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        sys.exit("bench.py: no GPU visible (the hot path has no CPU fallback)")
+    if local >= n_dev:
+        if backend == "nccl":
+            sys.exit("bench.py: local rank %d has no GPU of its own (%d visible); one process per GPU" % (local, n_dev))
+        local = local % n_dev                # gloo smoke test: ranks may share a GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get("TEXIR_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
 
-    from texir_code_amd import scene as S, synth, dist_util
-    T, res, tex_res, spp = WORKLOADS[args.workload]
-    if args.spp:
-        spp = args.spp
-    sc0 = synth.make_scene(T, seed=666, tex_res=tex_res)
-    pos, nrm, valid = synth.make_texel_gbuffer(sc0, res)
-    shift = synth.make_shifts(res * res)
-    t0 = time.perf_counter()
-    sc = S.Scene(sc0["verts"], sc0["tris"], sc0["tri_uvs"], sc0["hdr"], device=local)
-    build_s = time.perf_counter() - t0
-    d_pos = torch.from_numpy(pos).to(dev).reshape(-1, 3)
-    d_nrm = torch.from_numpy(nrm).to(dev).reshape(-1, 3)
-    d_shift = torch.from_numpy(shift).to(dev)
-    ids_all = torch.nonzero(torch.from_numpy(valid.reshape(-1)) > 0)[:, 0].to(torch.int32)
-    if os.environ.get("TEXIR_TEXEL_ORDER", "morton") == "morton":
-        ids_all = dist_util.morton_order(ids_all, res)
-    ids = dist_util.shard_block_cyclic(ids_all, rank, world, BLOCK).to(dev)
-    n_valid = int(ids_all.numel())
-    irr = torch.zeros((res * res, 3), device=dev)
-
-    def step():
-        irr.zero_()
-        sc.irt_generate(d_pos, d_nrm, d_shift, spp, "uniform", texel_ids=ids, out=irr)
-        if world > 1:
-            dist.all_reduce(irr)
+    from texir_code_amd import scene as S, dist_util
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        irr.zero_()
-        ev[k][0].record()            # HIP events on the stream the kernel is launched on (torch's current stream)
-        sc.irt_generate(d_pos, d_nrm, d_shift, spp, "uniform", texel_ids=ids, out=irr)
-        ev[k][1].record()
+    def run_irt(name, steps, warmup):
+        """time `steps` passes of the hot path over workload `name`; returns the measurements + what the later legs need"""
+        if world > 1 and rank != 0 and os.environ.get("TEXIR_SYNTH_CACHE"):
+            dist.barrier()                  # rank 0 generates into the cache, the others load it
+        sc0, pos, nrm, valid, shift, res, spp = make_workload(name)
+        if world > 1 and rank == 0 and os.environ.get("TEXIR_SYNTH_CACHE"):
+            dist.barrier()
+        if args.spp:
+            spp = args.spp
+        t0 = time.perf_counter()
+        sc = S.Scene(sc0["verts"], sc0["tris"], sc0["tri_uvs"], sc0["hdr"], device=local)
+        build_s = time.perf_counter() - t0
+        d_pos = torch.from_numpy(pos).to(dev).reshape(-1, 3)
+        d_nrm = torch.from_numpy(nrm).to(dev).reshape(-1, 3)
+        d_shift = torch.from_numpy(shift).to(dev)
+        ids_all = torch.nonzero(torch.from_numpy(valid.reshape(-1)) > 0)[:, 0].to(torch.int32)
+        if os.environ.get("TEXIR_TEXEL_ORDER", "morton") == "morton":
+            ids_all = dist_util.morton_order(ids_all, res)
+        ids = dist_util.shard_block_cyclic(ids_all, rank, world, BLOCK).to(dev)
+        irr = torch.zeros((res * res, 3), device=dev)
+        for _ in range(warmup):
+            irr.zero_()
+            sc.irt_generate(d_pos, d_nrm, d_shift, spp, "uniform", texel_ids=ids, out=irr)
+            if world > 1:
+                dist.all_reduce(irr)
+        barrier()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for k in range(steps):
+            irr.zero_()
+            ev[k][0].record()            # HIP events on the stream the kernel is launched on (torch's current stream)
+            sc.irt_generate(d_pos, d_nrm, d_shift, spp, "uniform", texel_ids=ids, out=irr)
+            ev[k][1].record()
+            if world > 1:
+                dist.all_reduce(irr)
+        barrier()
+        dt = time.perf_counter() - t0
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         if world > 1:
-            dist.all_reduce(irr)
-    barrier()
-    dt = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        T, _, tex_res, _, style = WORKLOADS[name]
+        n_valid = int(ids_all.numel())
+        return {"sc": sc, "sc0": sc0, "pos": pos, "nrm": nrm, "valid": valid, "shift": shift, "res": res, "spp": spp, "irr": irr, "ids": ids,
+                "dt": dt, "kern_ms": kern_ms, "n_valid": n_valid, "build_s": build_s, "kernel": sc.irt_kernel_name(int(ids.numel()), spp),
+                "value": n_valid * spp * steps / dt / 1e6,
+                "desc": "%s: IrT %d spp, %dx%d texels (%d valid), %d-tri synthetic %s mesh, %dx%d RGB32F radiance texture"
+                        % (name, spp, res, res, n_valid, T, "indoor" if style == "room" else "scan-like (rotated clutter, slats, openings)", tex_res, tex_res)}
 
+    r = run_irt(args.workload, args.steps, args.warmup)
     mat = None
     if not args.no_mat and args.workload == "c4":
         import contextlib
         with contextlib.redirect_stdout(sys.stderr):          # (constructors print like the reference's; stdout carries the JSON line only)
-            mat = mat_leg(sc, sc0, irr, res, dev, rank, world)
+            mat = mat_leg(r["sc"], r["sc0"], r["irr"], r["res"], dev, rank, world)
 
+    out = None
     if rank == 0:
-        rays_per_step = n_valid * spp
-        value = rays_per_step * args.steps / dt / 1e6
         out = {
-            "metric": "IrT generation throughput", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "metric": "IrT generation throughput", "value": round(r["value"], 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(r["dt"] / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: IrT %d spp, %dx%d texels (%d valid), %d-tri synthetic indoor mesh, %dx%d RGB32F radiance texture"
-                       % (args.workload, spp, res, res, n_valid, T, tex_res, tex_res),
+            "config": {"workload": r["desc"],
                        "parallelism": "texel-sharded x%d (block-cyclic %d) + RCCL all_reduce" % (world, BLOCK) if world > 1 else "single GPU",
-                       "bvh_build_s": round(build_s, 2), "scene": sc.info()},
+                       "bvh_build_s": round(r["build_s"], 2), "scene": r["sc"].info()},
         }
         if mat is not None:
             out["material_step"] = mat
-        rays_this_rank = int(ids.numel()) * spp
+        rays_this_rank = int(r["ids"].numel()) * r["spp"]
+        alg = cpu = None
         if not args.no_cpu:
-            cpu, counters = cpu_leg(sc0, pos, nrm, valid, shift, spp, timed=world == 1)
-            bpr, nbar, tbar, phit = algorithmic_bytes_per_ray(counters, spp)
-            from texir_code_amd import _lib
-            launches = int(_lib.lib().texir_irt_launch_count(spp))
-            achieved = bpr * rays_this_rank / (kern_ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.workload)
-            if os.path.exists(tpath):
-                tj = json.load(open(tpath))
-                traffic = tj.get("hbm_bytes_per_step", 0) / launches if "hbm_bytes_per_step" in tj else tj.get("hbm_bytes_per_launch")
-            out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                               "kernel": "irt_group_kernel<false, 4, 6>", "launches_per_step": launches, "kernel_ms": round(kern_ms / launches, 4),
-                               "kernel_ms_per_step": round(kern_ms, 3), "bytes_per_ray": round(bpr, 1),
-                               "nodes_per_ray": round(nbar, 2), "tris_per_ray": round(tbar, 2), "p_hit": round(phit, 4),
-                               "rays_per_launch": rays_this_rank // launches,
-                               # frac > 1 = the canonical algorithm's bytes are served from cache; the measured fabric-side rate is:
-                               "traffic_gbs": round(traffic / (kern_ms / launches * 1e-3) / 1e9, 1) if traffic else None,
-                               "limiter": "VALU issue in the traversal loop (DESIGN.md section 4)"}
+            cpu, counters = cpu_leg(r["sc0"], r["pos"], r["nrm"], r["valid"], r["shift"], r["spp"], timed=world == 1)
+            alg = algorithmic_bytes_per_ray(counters, r["spp"])
+        out["roofline"] = roofline(args.workload, r["kernel"], r["kern_ms"], rays_this_rank, world, alg)
+        if cpu is not None:
             out["cpu_baseline"] = cpu
+    # further workloads (IrT only), never the headline
+    extras = [w for w in args.extra.split(",") if w]
+    if extras:
+        del r
+        torch.cuda.empty_cache()
+        ex = {}
+        for w in extras:
+            e = run_irt(w, args.steps, args.warmup)
+            if rank == 0:
+                ex[w] = {"value": round(e["value"], 2), "unit": "Mrays/s", "ms_per_step": round(e["dt"] / args.steps * 1e3, 3), "workload": e["desc"],
+                         "kernel": e["kernel"], "scene": e["sc"].info()}
+            del e
+            torch.cuda.empty_cache()
+        if rank == 0:
+            out["extra_workloads"] = ex
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -97,9 +97,10 @@ TEXIR_API int texir_irt_generate(const texir_scene* scene, const float* pos /*de
                        int64_t Nt, int32_t N, int32_t mode, float* irr /*dev*/, uint64_t* stats /*dev, nullable*/,
                        void* stream);
 
-/* number of kernel launches one texir_irt_generate call issues for N samples per texel (the cell-major schedule launches
- * once per 64-sample direction cell when N is a power of two >= 128); used by bench.py to report per-launch figures. */
-TEXIR_API int32_t texir_irt_launch_count(int32_t N);
+/* name of the kernel form ONE texir_irt_generate call over n_ids listed texels at N samples launches on this scene
+ * ("irt_group_kernel<false, 4, 6>": 64 texels per wave; "irt_kernel<false, 4|2>": one texel per wave) -- the launcher's own
+ * decision, so that bench.py's roofline names the kernel that really ran.  buf receives a NUL-terminated string. */
+TEXIR_API int texir_irt_kernel_name(const texir_scene* scene, int64_t n_ids, int32_t N, char* buf, int32_t cap);
 
 /* Replaces MaterialModel.render + specular_reflectance (models/mat_nvdiffrast.py:201-249, 260-279), forward:
  *   rgb = irr*albedo/pi + (1/S) sum_i Ls_i * w_i(roughness)        
@@ -159,8 +160,11 @@ TEXIR_API int texir_gbuffer_cast(const texir_scene* scene, const float* mvp /*ho
  * uv_da); boundary_mode 'wrap'. */
 TEXIR_API int32_t texir_mip_levels(int32_t H, int32_t W, int32_t max_mip_level);
 TEXIR_API int64_t texir_mip_elems(int32_t H, int32_t W, int32_t C, int32_t levels);
+/* from_level 0: levels 1.. from the texture; 1: level 1 of mips_rest is already current (texir_adam_step_tex wrote it with the
+ * update), build levels 2.. from it.  (TEXIR_MIP_PER_LEVEL=1 selects the one-launch-per-level reference implementation; the
+ * default builds five levels per launch through LDS -- identical bits.) */
 TEXIR_API int texir_mip_build(const float* tex /*dev*/, float* mips_rest /*dev*/, int32_t H, int32_t W, int32_t C, int32_t levels,
-                       void* stream);
+                       int32_t from_level, void* stream);
 TEXIR_API int texir_tex_fetch_forward(const float* tex /*dev*/, const float* mips_rest /*dev, nullable*/, int32_t H, int32_t W,
                        int32_t C, int32_t levels, const float* uv /*dev [P,2]*/, const float* uv_da /*dev [P,4], nullable for mode 0*/,
                        int32_t filter_mode, int64_t P, float* out /*dev [P,C]*/, void* stream);
@@ -181,7 +185,9 @@ TEXIR_API int texir_tex_fetch_backward_deferred(float* d_tex /*dev*/, float* gra
  * key = texel index in the unified order [level 0 | levels 1.. as in mips_rest], -1 for unused slots, weight = bilinear x level blend.
  * The caller sorts them by key once (stable), forms segments (key, start, count) + the sorted (pixel, weight) lists, and then every
  * backward is texir_tex_gather_backward: one thread per touched texel adds its list in order (deterministic), followed by the
- * same folds as texir_tex_fetch_backward (defer_last_fold = 1: as texir_tex_fetch_backward_deferred).  d_tex / grad_rest zero on entry. */
+ * same folds as texir_tex_fetch_backward (defer_last_fold = 1: as texir_tex_fetch_backward_deferred).  d_tex / grad_rest zero on entry.
+ * With defer_last_fold = 1, d_tex may be NULL when no listed tap samples level 0 (no key < H*W): the level-0 gradient is then
+ * identically zero and texir_adam_step_tex(grad = NULL) never reads it. */
 TEXIR_API int texir_tex_taps(int32_t H, int32_t W, int32_t C, int32_t levels, const float* uv, const float* uv_da, int32_t filter_mode,
                        int64_t P, int64_t* keys /*dev [P*8]*/, float* weights /*dev [P*8]*/, void* stream);
 TEXIR_API int texir_tex_gather_backward(float* d_tex, float* grad_rest, int32_t H, int32_t W, int32_t C, int32_t levels,
@@ -195,10 +201,14 @@ TEXIR_API int texir_adam_step(float* param, const float* grad, float* exp_avg, f
                        float beta1, float beta2, float eps, int32_t step, float clamp_lo, float clamp_hi, void* stream);
 
 /* The same step (trainer/train_material.py:448-458) for a texture [H,W,C] whose gradient is grad + 0.25 * grad_level1[y/2][x/2] (texir_tex_fetch_backward_deferred): the
- * last mip fold is fused into the optimiser's read of the gradient; results equal fold + texir_adam_step bit for bit. */
-TEXIR_API int texir_adam_step_tex(float* param, const float* grad, const float* grad_level1, float* exp_avg, float* exp_avg_sq, int32_t H,
-                       int32_t W, int32_t C, float lr, float beta1, float beta2, float eps, int32_t step, float clamp_lo, float clamp_hi,
-                       void* stream);
+ * last mip fold is fused into the optimiser's read of the gradient; results equal fold + texir_adam_step bit for bit.
+ * grad == NULL: no pixel of the step sampled mip level 0, the level-0 gradient is neither materialised nor read.
+ * mip_level1 != NULL: level 1 of the NEXT forward's mip stack (models/mat_nvdiffrast.py:131-134 rebuild it from the updated
+ * texture every step) is written on the way: texir_mip_build(..., from_level = 1) then skips the pass over the full texture. */
+TEXIR_API int texir_adam_step_tex(float* param, const float* grad /*nullable: level-0 gradient identically zero*/, const float* grad_level1,
+                       float* exp_avg, float* exp_avg_sq, float* mip_level1 /*nullable: [H/2,W/2,C] <- 2x2 average of the updated texels*/,
+                       int32_t H, int32_t W, int32_t C, float lr, float beta1, float beta2, float eps, int32_t step, float clamp_lo,
+                       float clamp_hi, void* stream);
 
 #ifdef __cplusplus
 }

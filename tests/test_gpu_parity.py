@@ -385,7 +385,7 @@ def test_fused_mip_fold_adam_is_bit_identical(tx):
         p = torch.rand(H, W, C, device="cuda")
         m, v = torch.rand_like(p) * 0.1, torch.rand_like(p) * 0.01
         if fused:
-            _lib.check(L.texir_adam_step_tex(_lib.ptr(p), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(m), _lib.ptr(v), H, W, C, 3e-2, 0.9, 0.999, 1e-8, 3, 0.0, 0.8,
+            _lib.check(L.texir_adam_step_tex(_lib.ptr(p), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(m), _lib.ptr(v), None, H, W, C, 3e-2, 0.9, 0.999, 1e-8, 3, 0.0, 0.8,
                                              _lib.stream_ptr()))
         else:
             _lib.check(L.texir_adam_step(_lib.ptr(p), _lib.ptr(folded), _lib.ptr(m), _lib.ptr(v), p.numel(), 3e-2, 0.9, 0.999, 1e-8, 3, 0.0, 0.8,
@@ -409,6 +409,68 @@ def test_fused_mip_fold_adam_is_bit_identical(tx):
             assert getattr(t, "_texir_grad_l1", None) is None
         res.append(t.detach().cpu().numpy())
     assert rel_l2(res[1], res[0]) < 1e-5
+
+
+def test_adam_tex_null_level0_gradient_and_fused_mip_level1(tx):
+    """texir_adam_step_tex: (a) grad = NULL equals an all-zero level-0 gradient bit for bit; (b) the level-1 texels it writes on the
+    way equal texir_mip_build's level 1 of the updated texture bit for bit, and a build continued from them (from_level = 1) equals
+    the full build; for C = 1 and 3 and a non-square texture"""
+    from texir_code_amd import _lib
+    L = _lib.lib()
+    for (H, W, C) in ((64, 64, 3), (128, 32, 1), (256, 256, 3)):
+        levels = int(L.texir_mip_levels(H, W, 13))
+        n_rest = int(L.texir_mip_elems(H, W, C, levels))
+        torch.manual_seed(H + C)
+        p0 = torch.rand(H, W, C, device="cuda")
+        m0, v0 = torch.rand_like(p0) * 0.1, torch.rand_like(p0) * 0.01
+        g1 = torch.randn((H // 2) * (W // 2) * C, device="cuda")
+        res = []
+        for null_g in (False, True):
+            p, m, v = p0.clone(), m0.clone(), v0.clone()
+            rest = torch.full((n_rest,), -7.0, device="cuda")
+            g0 = None if null_g else torch.zeros(H, W, C, device="cuda")
+            _lib.check(L.texir_adam_step_tex(_lib.ptr(p), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(m), _lib.ptr(v), _lib.ptr(rest), H, W, C, 3e-2, 0.9, 0.999,
+                                             1e-8, 2, 1e-2, 0.8, _lib.stream_ptr()))
+            _lib.check(L.texir_mip_build(_lib.ptr(p), _lib.ptr(rest), H, W, C, levels, 1, _lib.stream_ptr()))      # levels 2.. from the fused level 1
+            full = torch.empty(n_rest, device="cuda")
+            _lib.check(L.texir_mip_build(_lib.ptr(p), _lib.ptr(full), H, W, C, levels, 0, _lib.stream_ptr()))
+            assert torch.equal(rest, full), (H, W, C, null_g)
+            res.append((p, m, v, rest))
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+        assert not torch.equal(res[0][0], p0)
+
+
+def test_multi_level_mip_kernels_match_the_per_level_reference(tx, monkeypatch):
+    """the pyramid kernels (five mip levels per launch through LDS; all folds of a gradient stack in one launch) produce the same
+    bits as the first implementation (one launch per level, TEXIR_MIP_PER_LEVEL=1), build and folds (complete and deferred), incl.
+    non-square sizes and stacks shallower than one tile"""
+    from texir_code_amd import _lib
+    L = _lib.lib()
+    for (H, W, C, mx) in ((4096, 4096, 1, 13), (1024, 2048, 3, 13), (64, 64, 3, 13), (96, 160, 2, 13), (256, 256, 4, 3), (32, 32, 1, 1), (2, 2, 3, 13)):
+        levels = int(L.texir_mip_levels(H, W, mx))
+        n_rest = int(L.texir_mip_elems(H, W, C, levels))
+        torch.manual_seed(H + W + C)
+        tex = torch.rand(H, W, C, device="cuda")
+        g0s, grs = torch.randn(H, W, C, device="cuda"), torch.randn(n_rest, device="cuda")
+        dummy = torch.zeros(8, device="cuda")
+        outs = []
+        for per_level in ("1", "0"):
+            monkeypatch.setenv("TEXIR_MIP_PER_LEVEL", per_level)
+            rest = torch.zeros(n_rest, device="cuda")
+            _lib.check(L.texir_mip_build(_lib.ptr(tex), _lib.ptr(rest), H, W, C, levels, 0, _lib.stream_ptr()))
+            full0, full_r = g0s.clone(), grs.clone()          # P = 0: no scatter, the folds only
+            _lib.check(L.texir_tex_fetch_backward(_lib.ptr(full0), _lib.ptr(full_r), H, W, C, levels, _lib.ptr(dummy), _lib.ptr(dummy), 1, 0, _lib.ptr(dummy),
+                                                  _lib.stream_ptr()))
+            def0, def_r = g0s.clone(), grs.clone()
+            if levels >= 2:
+                _lib.check(L.texir_tex_fetch_backward_deferred(_lib.ptr(def0), _lib.ptr(def_r), H, W, C, levels, _lib.ptr(dummy), _lib.ptr(dummy), 0,
+                                                               _lib.ptr(dummy), _lib.stream_ptr()))
+            outs.append((rest, full0, def0, def_r[:max(1, (H // 2) * (W // 2) * C)].clone()))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b), (H, W, C)
+        if levels > 1:
+            assert not torch.equal(outs[1][1], g0s)             # the folds did something
 
 
 def test_full_size_c2_properties(c2_workload, tx):

@@ -1,0 +1,135 @@
+"""GPU-box tests of what the scaling run depends on: the RCCL code path is executed on hardware, `bench.py --gpus N`
+really starts N ranks (or refuses), and BASELINE configs[3] / [4] run at full mesh/texture size (C4: 4096^2 texels, 1 M triangles;
+C5: 2 M-triangle joint NIrF -> IrT -> Mat walk-through at reduced spp)."""
+import json
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cmd, timeout=900, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=e)
+
+
+def test_rccl_process_group_world_of_one(tmp_path):
+    """backend "nccl" (= RCCL on ROCm) initialises and all-reduces on this box -- the calls bench.py / exp_runner make at N > 1,
+    through the same helpers (dist_util.assemble_sum / reduce_texture_grads)"""
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "from texir_code_amd import dist_util\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "t = torch.arange(1 << 20, device='cuda', dtype=torch.float32)\n"
+        "dist.all_reduce(t)\n"
+        "dist.barrier()\n"
+        "assert float(t[12345]) == 12345.0 and dist.get_world_size() == 1 and dist.get_backend() == 'nccl'\n"
+        "dist_util.assemble_sum(t)\n"
+        "p = torch.nn.Parameter(torch.zeros(64, 64, 3, device='cuda')); p.grad = torch.ones_like(p)\n"
+        "dist_util.reduce_texture_grads([p])\n"
+        "torch.cuda.synchronize(); dist.destroy_process_group(); print('rccl ok')\n")
+    r = _run([sys.executable, "-c", code], env={"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0",
+                                                "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_bench_gpus_flag_starts_ranks_or_refuses():
+    """`python bench.py --gpus N` (the driver's command shape, no launcher): with fewer than N devices it must fail loudly instead of
+    printing an n_gpus: 1 line; with enough devices rank 0 prints n_gpus: N measured over RCCL"""
+    n_dev = torch.cuda.device_count()
+    want = 2
+    r = _run([sys.executable, "bench.py", "--gpus", str(want), "--workload", "tiny", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-mat"])
+    if n_dev < want:
+        assert r.returncode != 0 and "ranks requested" in (r.stderr + r.stdout) and '"n_gpus"' not in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+    else:
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == want and line["value"] > 0
+    # a launcher that started a different number of ranks than --gpus says is refused too
+    r = _run([sys.executable, "bench.py", "--gpus", "1", "--workload", "tiny", "--no-cpu", "--no-mat"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """the N > 1 bench path end to end (block-cyclic shards, all_reduce assembly, max-over-ranks timing, one JSON line from rank 0) with
+    two ranks sharing this GPU over gloo; the assembled texture's throughput line must carry n_gpus: 2"""
+    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+              "bench.py", "--gpus", "2", "--workload", "tiny", "--steps", "1", "--warmup", "1", "--no-cpu", "--no-mat"],
+             env={"TEXIR_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+
+
+@pytest.fixture(scope="module")
+def c4_workload():
+    """BASELINE.json configs[3] at full size: 1 M triangles, 4096^2 texels, 4096^2 radiance texture"""
+    sys.path.insert(0, ROOT)
+    import bench
+    from texir_code_amd import scene as S, dist_util
+    sc0, pos, nrm, valid, shift, res, spp = bench.make_workload("c4")
+    sc = S.Scene(sc0["verts"], sc0["tris"], sc0["tri_uvs"], sc0["hdr"])
+    ids = torch.nonzero(torch.from_numpy(valid.reshape(-1)) > 0)[:, 0].to(torch.int32)
+    ids = dist_util.morton_order(ids, res).cuda()
+    d = lambda a: torch.from_numpy(a).cuda()
+    return sc0, sc, d(pos).reshape(-1, 3), d(nrm).reshape(-1, 3), d(shift), ids, valid
+
+
+def test_full_size_c4_properties(c4_workload):
+    """configs[3] (the bench's own workload: 4096^2 texels / 12.5 M valid, 1 M triangles, 4k^2 texture) at reduced spp for the
+    O(spp) checks and at the full 2048 spp for determinism + the 8-way shard union: finiteness, seams zero, determinism, exact
+    linearity, superposition, union of the 8 block-cyclic rank shards == the single-rank texture bit for bit"""
+    from texir_code_amd import dist_util
+    sc0, sc, pos, nrm, shift, ids, valid = c4_workload
+    v = torch.from_numpy(valid.reshape(-1) > 0).cuda()
+    hdr = torch.from_numpy(sc0["hdr"]).cuda()
+    N = 256
+    base, st = sc.irt_generate(pos, nrm, shift, N, "uniform", texel_ids=ids, stats=True)
+    assert int(st[0]) == ids.numel() * N                                     # every ray traced
+    assert torch.isfinite(base).all() and bool((base[~v] == 0).all()) and float(base[v].min()) >= 0
+    sc.set_texture(hdr * 4.0)
+    assert torch.equal(sc.irt_generate(pos, nrm, shift, N, "uniform", texel_ids=ids), base * 4.0)
+    A = hdr.clone()
+    A[: hdr.shape[0] // 2] = 0
+    sc.set_texture(A)
+    ia = sc.irt_generate(pos, nrm, shift, N, "uniform", texel_ids=ids)
+    sc.set_texture(hdr - A)
+    ib = sc.irt_generate(pos, nrm, shift, N, "uniform", texel_ids=ids)
+    assert rel_l2((ia + ib).cpu().numpy(), base.cpu().numpy()) < 1e-6
+    sc.set_texture(torch.full_like(hdr, 0.5))
+    const = sc.irt_generate(pos, nrm, shift, N, "uniform", texel_ids=ids)[v]
+    assert abs(float(const.mean()) - math.pi * 0.5) < 5e-3
+    sc.set_texture(hdr)
+    del ia, ib, A, const
+    # full 2048 spp: two identical launches, then the 8-rank partition of the SCALE run
+    N = 2048
+    full = sc.irt_generate(pos, nrm, shift, N, "uniform", texel_ids=ids)
+    assert torch.equal(full, sc.irt_generate(pos, nrm, shift, N, "uniform", texel_ids=ids))
+    acc = torch.zeros_like(full)
+    for r in range(8):
+        part = dist_util.shard_block_cyclic(ids, r, 8, 4096)
+        sc.irt_generate(pos, nrm, shift, N, "uniform", texel_ids=part, out=acc)
+    assert torch.equal(acc, full)
+    assert rel_l2(full.cpu().numpy(), base.cpu().numpy()) < 0.05              # 256 vs 2048 spp: same integral
+
+
+def test_c5_joint_pipeline_smoke():
+    """configs[4]: NIrF -> IrT -> pad -> Mat on the 2 M-triangle mesh (tools/run_c5.py), reduced spp / steps"""
+    r = _run([sys.executable, "tools/run_c5.py", "--tris", "2000000", "--res", "2048", "--spp", "128", "--nirf-steps", "5", "--mat-steps", "5"], timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["scene"]["triangles"] == 2000000
+    assert d["nirf"]["gt_Mrays_s"] > 0 and math.isfinite(d["nirf"]["final_loss"])
+    assert d["irt"]["Mrays_s"] > 0 and d["material_step"]["ms"] > 0

@@ -1,0 +1,107 @@
+"""Watertightness of the HIP tracer (VERDICT r1 weak #1 / Embree semantics cited at SURVEY 8c, models/tracer_o3d_irt.py:244-248):
+rays fired from inside CLOSED meshes straight at shared edges and vertices (+- ulp-scale jitter) must never escape, and their hit
+distance must agree with the float64 brute-force oracle.  Embree (Open3D's RaycastingScene) does not leak there; a
+Moeller-Trumbore test with independent per-triangle edge tests does."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def icosphere(subdiv, seed=0, bump=0.08):
+    """closed, indexed (shared vertices) triangle mesh: subdivided icosahedron, radius 1 +- smooth radial bumps"""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    v = [np.array(p, np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(subdiv):
+        mid, nf = {}, []
+
+        def m(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in mid:
+                p = v[a] + v[b]
+                v.append(p / np.linalg.norm(p))
+                mid[k] = len(v) - 1
+            return mid[k]
+        for a, b, c in f:
+            ab, bc, ca = m(a, b), m(b, c), m(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    v = np.array(v)
+    rng = np.random.default_rng(seed)
+    k = rng.normal(size=(4, 3))
+    r = 1.0 + bump * sum(np.sin(3.0 * v @ k[i] + i) for i in range(4)) / 4.0
+    return (v * r[:, None]).astype(np.float32), np.array(f, np.int32)
+
+
+def box_grid(n):
+    """closed axis-aligned cube [-1,1]^3, every face an n x n grid of quads with SHARED vertices along the cube's edges"""
+    idx, verts, tris = {}, [], []
+
+    def vid(p):
+        k = tuple(np.round(p, 9))
+        if k not in idx:
+            idx[k] = len(verts)
+            verts.append(p)
+        return idx[k]
+    g = np.linspace(-1.0, 1.0, n + 1)
+    for ax in range(3):
+        for s in (-1.0, 1.0):
+            for i in range(n):
+                for j in range(n):
+                    q = []
+                    for (a, b) in ((i, j), (i + 1, j), (i + 1, j + 1), (i, j + 1)):
+                        p = np.zeros(3)
+                        p[ax] = s
+                        p[(ax + 1) % 3] = g[a]
+                        p[(ax + 2) % 3] = g[b]
+                        q.append(vid(p))
+                    tris += [(q[0], q[1], q[2]), (q[0], q[2], q[3])]
+    return np.array(verts, np.float32), np.array(tris, np.int32)
+
+
+def stress_rays(verts, tris, n_org, rng):
+    """origins inside, targets = every vertex, every edge midpoint and a random point on every edge, each with jitters of 0 and
+    +-{1e-7, 1e-6, 1e-5} (relative to the mesh size) in a random direction; directions are NOT normalised (query_irf's aren't)"""
+    e = np.concatenate([tris[:, [0, 1]], tris[:, [1, 2]], tris[:, [2, 0]]])
+    e = np.unique(np.sort(e, axis=1), axis=0)
+    a, b = verts[e[:, 0]].astype(np.float64), verts[e[:, 1]].astype(np.float64)
+    lam = rng.uniform(0.02, 0.98, (e.shape[0], 1))
+    targets = np.concatenate([verts.astype(np.float64), 0.5 * (a + b), a + lam * (b - a)])
+    orgs, dirs = [], []
+    for _ in range(n_org):
+        o = rng.uniform(-0.25, 0.25, 3)
+        for jit in (0.0, 1e-7, -1e-7, 1e-6, -1e-6, 1e-5):
+            t = targets + jit * rng.normal(size=targets.shape)
+            d = (t.astype(np.float32) - o.astype(np.float32)) * np.float32(rng.uniform(0.3, 3.0))
+            orgs.append(np.broadcast_to(o.astype(np.float32), d.shape))
+            dirs.append(d.astype(np.float32))
+    return np.ascontiguousarray(np.concatenate(orgs)), np.ascontiguousarray(np.concatenate(dirs))
+
+
+@pytest.mark.parametrize("mesh", ["icosphere", "box"])
+def test_no_ray_escapes_through_shared_edges_or_vertices(mesh):
+    from texir_code_amd import scene as S
+    from oracle import oracle as O
+    verts, tris = icosphere(4) if mesh == "icosphere" else box_grid(24)
+    T = tris.shape[0]
+    uvs = np.tile(np.array([[0.1, 0.1], [0.9, 0.1], [0.1, 0.9]], np.float32), (T, 1))
+    hdr = np.ones((4, 4, 3), np.float32)
+    rng = np.random.default_rng(11)
+    org, d = stress_rays(verts, tris, 14 if mesh == "icosphere" else 10, rng)
+    assert org.shape[0] >= 1_000_000, org.shape
+    sc = S.Scene(verts, tris, uvs, hdr)
+    rad, t, pid, uv = sc.trace_shade(torch.from_numpy(org), torch.from_numpy(d), return_hits=True)
+    t = t.cpu().numpy()
+    miss = ~np.isfinite(t)
+    assert miss.sum() == 0, "%d of %d rays escaped a closed mesh (first: org %s dir %s)" % (miss.sum(), t.size, org[miss][:1], d[miss][:1])
+    assert (rad.cpu().numpy() == 1.0).all()                      # constant texture: every hit shades to exactly 1
+    # distance against the float64 brute force on a sample (the oracle costs rays x triangles)
+    pick = rng.choice(t.size, 60000, replace=False)
+    t_ref, _, _ = O.Scene(verts, tris, uvs, hdr).cast_rays(org[pick], d[pick], tracer="brute")
+    ok = np.isfinite(t_ref)
+    assert ok.mean() > 0.999                                       # (the f64 oracle itself may lose a ray exactly on an edge)
+    assert np.abs(t[pick][ok] - t_ref[ok]).max() < 2e-5 * max(1.0, float(t_ref[ok].max()))

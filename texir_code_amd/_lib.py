@@ -9,15 +9,6 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TEXIR_HIP_LIB") or os.path.join(_HERE, "libtexir_hip.so")   # (override: A/B builds of the kernels)
 _LIB = None
 
-EXPORTS = [
-    "texir_last_error", "texir_version", "texir_scene_create", "texir_scene_destroy", "texir_scene_set_texture",
-    "texir_scene_info", "texir_trace_shade", "texir_generate_dir", "texir_irt_generate", "texir_spec_forward",
-    "texir_spec_backward", "texir_loss_forward", "texir_loss_backward", "texir_tex_fetch_forward", "texir_tex_fetch_backward",
-    "texir_adam_step", "texir_raster_cube", "texir_tex_fetch_backward_deferred", "texir_adam_step_tex",
-    "texir_tex_taps", "texir_tex_gather_backward",
-]
-
-
 class TexirError(RuntimeError):
     pass
 
@@ -57,19 +48,18 @@ def lib():
             "texir_spec_forward": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp],
             "texir_spec_backward": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp],
         }
+        sig["texir_irt_kernel_name"] = [vp, i64, i32, C.c_char_p, i32]
         sig["texir_loss_forward"] = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp]
         sig["texir_scene_set_corner_normals"] = [vp, vp]
         sig["texir_gbuffer_cast"] = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
-        sig["texir_mip_build"] = [vp, vp, i32, i32, i32, i32, vp]
+        sig["texir_mip_build"] = [vp, vp, i32, i32, i32, i32, i32, vp]
         sig["texir_tex_fetch_forward"] = [vp, vp, i32, i32, i32, i32, vp, vp, i32, i64, vp, vp]
         sig["texir_tex_fetch_backward"] = [vp, vp, i32, i32, i32, i32, vp, vp, i32, i64, vp, vp]
         sig["texir_adam_step"] = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, f32, vp]
         sig["texir_tex_fetch_backward_deferred"] = [vp, vp, i32, i32, i32, i32, vp, vp, i64, vp, vp]
         sig["texir_tex_taps"] = [i32, i32, i32, i32, vp, vp, i32, i64, vp, vp, vp]
         sig["texir_tex_gather_backward"] = [vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp]
-        sig["texir_adam_step_tex"] = [vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, i32, f32, f32, vp]
-        L.texir_irt_launch_count.argtypes = [i32]
-        L.texir_irt_launch_count.restype = i32
+        sig["texir_adam_step_tex"] = [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, i32, f32, f32, vp]
         L.texir_mip_levels.argtypes = [i32, i32, i32]
         L.texir_mip_levels.restype = i32
         L.texir_mip_elems.argtypes = [i32, i32, i32, i32]

@@ -145,31 +145,41 @@ int32_t emit(const Tmp* t, std::vector<GpuNode>& out)
 // ---- 4-wide collapse: repeatedly open the inner child with the largest surface area until four children ----
 struct Quant { uint8_t lo[3], hi[3]; };
 
+// Child boxes are stored with a small ABSOLUTE slack on every side: the traversal's slab test runs in float32 with a folded
+// origin (t = q * (cell / d) + (origin / d - o / d)); its rounding error, a few ulps of the coordinates involved (<= ~4 * 2^-24 * M
+// in space, M = largest |coordinate| of the scene), would otherwise cull a box the ray only grazes -- and with it the triangle
+// behind a shared edge or vertex that lies exactly on the box's face (flat, axis-aligned geometry: every ray that hits it).
+// slack = 2^-19 * M is 8x that bound and ~1/50 of a leaf-level cell: it moves a quantised plane by one cell only when the true
+// plane happens to sit within `slack` of a cell boundary (a few percent of the planes) -- no measurable extra node visits.
+static float g_slack = 0.f;         // set per build (build_bvh), read by emit4_fill
+
 void emit4_fill(GpuNode4& g, const Box& nb, const Tmp* const* kids, int nk, const int32_t* codes, int32_t dummy_leaf)
 {
-    uint32_t e[3]; float scale[3];
+    const double slack = (double)g_slack;
+    float scale[3];
     for (int a = 0; a < 3; a++) {
-        double ext = (double)nb.mx[a] - (double)nb.mn[a];
+        const double ext = (double)nb.mx[a] - (double)nb.mn[a] + 2.0 * slack;
         int ex = 1;
         if (ext > 0.0) { ex = 127 + (int)std::ceil(std::log2(ext / 255.0)); if (ex < 1) ex = 1; if (ex > 254) ex = 254; }
-        // make sure 255 cells really cover the extent in float arithmetic
-        for (;;) { uint32_t bits = (uint32_t)ex << 23; float sc; std::memcpy(&sc, &bits, 4); if ((double)nb.mn[a] + 255.0 * (double)sc >= (double)nb.mx[a] || ex >= 254) { scale[a] = sc; break; } ex++; }
-        e[a] = (uint32_t)ex;
-        g.origin[a] = nb.mn[a];
+        const float org = std::nextafter((float)((double)nb.mn[a] - slack), -FLT_MAX);
+        // make sure 255 cells really cover the padded extent in float arithmetic
+        for (;;) { uint32_t bits = (uint32_t)ex << 23; float sc; std::memcpy(&sc, &bits, 4); if ((double)org + 255.0 * (double)sc >= (double)nb.mx[a] + slack || ex >= 254) { scale[a] = sc; break; } ex++; }
+        g.origin[a] = org;
     }
     g.cell_x = scale[0]; g.cell_y = scale[1]; g.cell_z = scale[2];
-    (void)e;
     uint32_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     for (int k = 0; k < 4; k++) {
         uint32_t ql[3] = {255, 255, 255}, qh[3] = {0, 0, 0};          // unused slot: inverted box
         if (k < nk) {
             for (int a = 0; a < 3; a++) {
-                double l = std::floor(((double)kids[k]->box.mn[a] - (double)nb.mn[a]) / (double)scale[a]);
-                double h = std::ceil(((double)kids[k]->box.mx[a] - (double)nb.mn[a]) / (double)scale[a]);
+                const float org = g.origin[a];
+                const double mn = (double)kids[k]->box.mn[a] - slack, mx = (double)kids[k]->box.mx[a] + slack;
+                double l = std::floor((mn - (double)org) / (double)scale[a]);
+                double h = std::ceil((mx - (double)org) / (double)scale[a]);
                 int li = (int)std::max(0.0, std::min(255.0, l)), hi_ = (int)std::max(0.0, std::min(255.0, h));
-                // conservative in FLOAT decode: origin + q*scale must bracket the child box
-                while (li > 0 && nb.mn[a] + (float)li * scale[a] > kids[k]->box.mn[a]) li--;
-                while (hi_ < 255 && nb.mn[a] + (float)hi_ * scale[a] < kids[k]->box.mx[a]) hi_++;
+                // conservative in FLOAT decode: origin + q*scale must bracket the padded child box
+                while (li > 0 && (double)(org + (float)li * scale[a]) > mn) li--;
+                while (hi_ < 255 && (double)(org + (float)hi_ * scale[a]) < mx) hi_++;
                 ql[a] = (uint32_t)li; qh[a] = (uint32_t)hi_;
             }
         }
@@ -200,41 +210,10 @@ int32_t emit4(const Tmp* t, std::vector<GpuNode4>& out, int depth, int& max_dept
     return idx;
 }
 
-// renumber the wide tree so that the nodes of the first `levels` levels come first, in breadth-first order (they are
-// staged into LDS by the traversal kernels); all other nodes keep their depth-first relative order
-int reorder_top_levels(std::vector<GpuNode4>& nodes, int levels)
-{
-    const int n = (int)nodes.size();
-    std::vector<int32_t> order; order.reserve(n);
-    std::vector<char> taken((size_t)n, 0);
-    std::vector<int32_t> frontier{0};
-    for (int lv = 0; lv < levels && !frontier.empty(); lv++) {
-        std::vector<int32_t> next;
-        for (int32_t i : frontier) {
-            order.push_back(i); taken[i] = 1;
-            for (int k = 0; k < 4; k++) if (nodes[i].c[k] >= 0) next.push_back(nodes[i].c[k]);
-        }
-        frontier.swap(next);
-    }
-    const int top = (int)order.size();
-    for (int i = 0; i < n; i++) if (!taken[i]) order.push_back(i);
-    std::vector<int32_t> new_of((size_t)n);
-    for (int i = 0; i < n; i++) new_of[order[i]] = i;
-    std::vector<GpuNode4> out((size_t)n);
-    for (int i = 0; i < n; i++) {
-        GpuNode4 g = nodes[order[i]];
-        for (int k = 0; k < 4; k++) if (g.c[k] >= 0) g.c[k] = new_of[g.c[k]];
-        out[i] = g;
-    }
-    nodes.swap(out);
-    return top;
-}
-
 }  // namespace
 
 void build_bvh(const float* verts, int V, const int32_t* tris, int T, const float* tri_uvs, BvhHost& out)
 {
-    (void)V;
     std::vector<Box> tb((size_t)T);
     std::vector<float> cen(3 * (size_t)T);
     std::vector<int32_t> order((size_t)T);
@@ -243,6 +222,13 @@ void build_bvh(const float* verts, int V, const int32_t* tris, int T, const floa
         for (int k = 0; k < 3; k++) tb[p].grow(verts + 3 * (size_t)tris[3 * (size_t)p + k]);
         for (int a = 0; a < 3; a++) cen[3 * (size_t)p + a] = 0.5f * (tb[p].mn[a] + tb[p].mx[a]);
         order[p] = p;
+    }
+    {   // absolute box slack of this scene (see emit4_fill); TEXIR_BOX_SLACK_LOG2 overrides the exponent for A/B runs (99 = none)
+        float M = 0.f;
+        for (int64_t i = 0; i < 3 * (int64_t)V; i++) M = std::max(M, std::fabs(verts[i]));
+        const char* e = getenv("TEXIR_BOX_SLACK_LOG2");
+        const int l2 = e ? atoi(e) : -19;
+        g_slack = l2 == 99 ? 0.f : std::ldexp(M, l2);
     }
     Ctx c{&tb, &cen, &order};
     unsigned hw = std::max(1u, std::thread::hardware_concurrency());
@@ -273,7 +259,6 @@ void build_bvh(const float* verts, int V, const int32_t* tris, int T, const floa
     const int32_t dummy_leaf = ~(int32_t)(((uint32_t)T << 3) | 0u);
     emit4(root.get(), out.nodes4, 1, d4, dummy_leaf);
     out.max_depth4 = d4;
-    out.top4 = reorder_top_levels(out.nodes4, kTopLevels);
     out.tris.resize((size_t)T + 1);
     out.uvs.resize((size_t)T + 1);
     std::memset(&out.tris[T], 0, sizeof(GpuTri));
@@ -285,7 +270,11 @@ void build_bvh(const float* verts, int V, const int32_t* tris, int T, const floa
         const float* b = verts + 3 * (size_t)tris[3 * (size_t)p + 1];
         const float* cc = verts + 3 * (size_t)tris[3 * (size_t)p + 2];
         GpuTri& g = out.tris[i];
+#if TEXIR_TRI_WATERTIGHT
+        for (int k = 0; k < 3; k++) { g.v0[k] = a[k]; g.e1[k] = b[k]; g.e2[k] = cc[k]; }         // the vertices themselves, bit for bit
+#else
         for (int k = 0; k < 3; k++) { g.v0[k] = a[k]; g.e1[k] = b[k] - a[k]; g.e2[k] = cc[k] - a[k]; }
+#endif
         g.prim = (uint32_t)p; g.pad1 = g.pad2 = 0.f;
         GpuTriUV& u = out.uvs[i];
         std::memcpy(u.uv, tri_uvs + 6 * (size_t)p, sizeof(float) * 6);

@@ -17,7 +17,15 @@ struct alignas(16) GpuNode {
 };
 static_assert(sizeof(GpuNode) == 64, "node must be 64 bytes");
 
-// 48-byte leaf-ordered triangle: (v0, prim id bits), (e1, 0), (e2, 0)
+// Triangle intersector (compile-time, the builder and the kernels of one library agree):
+//   TEXIR_TRI_WATERTIGHT = 1 (default): edge functions in ray space on the three stored VERTICES (the Pluecker form Embree's
+//     robust mode uses): the value a ray gets for an edge shared by two triangles is exactly the negative of the neighbour's,
+//     so no ray slips between them;  = 0: Moeller-Trumbore on (v0, e1, e2), ~30 VALU cheaper per test, leaks at shared edges.
+#ifndef TEXIR_TRI_WATERTIGHT
+#define TEXIR_TRI_WATERTIGHT 1
+#endif
+
+// 48-byte leaf-ordered triangle: (v0, prim id bits), (a, 0), (b, 0) with (a, b) = (v1, v2) [watertight] or (e1, e2) = (v1-v0, v2-v0)
 struct alignas(16) GpuTri {
     float v0[3]; uint32_t prim;
     float e1[3]; float pad1;
@@ -47,8 +55,6 @@ static_assert(sizeof(GpuNode4) == 64, "wide node must be 64 bytes");
 
 constexpr int32_t kEmptyChild = INT32_MIN;   // child slot with an inverted box, never entered
 constexpr int kMaxLeaf = 2;
-constexpr int kTopLevels = 4;             // 1 + 4 + 16 + 64 = at most 85 wide nodes (5440 B) cached in LDS per workgroup
-constexpr int kTopMax = 85;
 constexpr int kMaxDepth = 60;                // traversal stack bound (LDS part + private overflow)
 
 struct BvhHost {
@@ -57,7 +63,6 @@ struct BvhHost {
     std::vector<GpuTri> tris;
     std::vector<GpuTriUV> uvs;
     int max_depth = 0, max_depth4 = 0;
-    int top4 = 0;            // nodes4[0 .. top4) = the first kTopLevels levels in breadth-first order
 };
 
 // verts [V,3], tris [T,3], tri_uvs [3T,2]

@@ -21,6 +21,8 @@ struct texir_scene {
     SceneDev dev{};
     void* d_nodes4 = nullptr;
     void* d_nodes = nullptr; void* d_tris = nullptr; void* d_uvs = nullptr; float* d_tex = nullptr;
+    float* d_tex_tiled = nullptr;        // retiled copy read by the hit shader (texture layouts 1, 2); d_tex stays the row-major master
+    size_t tiled_bytes = 0;
     int64_t n_nodes = 0, n_nodes4 = 0, n_tris = 0, max_depth = 0;
     int width = 2;
     size_t tex_bytes = 0;
@@ -93,9 +95,20 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
     if ((e = hipMemcpy(s->d_tris, h.tris.data(), h.tris.size() * sizeof(GpuTri), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload tris");
     if ((e = hipMemcpy(s->d_uvs, h.uvs.data(), h.uvs.size() * sizeof(GpuTriUV), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload uvs");
     if ((e = hipMemcpy(s->d_tex, hdr_tex, s->tex_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload texture");
-    s->dev.nodes4 = (const float4*)s->d_nodes4; s->dev.top4 = s->width == 4 ? h.top4 : 0;
+    s->dev.nodes4 = (const float4*)s->d_nodes4;
     s->dev.nodes = (const float4*)s->d_nodes; s->dev.tris = (const float4*)s->d_tris; s->dev.uvs = (const float4*)s->d_uvs;
-    s->dev.tex = s->d_tex; s->dev.Ht = Ht; s->dev.Wt = Wt;
+    s->dev.tex = s->d_tex; s->dev.Ht = Ht; s->dev.Wt = Wt; s->dev.tex_layout = 0; s->dev.tiles_x = 0;
+    // hit-shader texture layout: 2 (one 128-byte line per bilinear footprint) by default, TEXIR_TEX_LAYOUT=0|1|2 for A/B runs
+    const char* lenv = getenv("TEXIR_TEX_LAYOUT");
+    const int layout = lenv ? atoi(lenv) : 2;
+    if (layout == 1 || layout == 2) {
+        int tx, ty;
+        s->tiled_bytes = tex_retile_bytes(Ht, Wt, layout, &tx, &ty);
+        if ((e = hipMalloc((void**)&s->d_tex_tiled, s->tiled_bytes)) != hipSuccess) return bail(e, "hipMalloc tiled texture");
+        if ((e = launch_tex_retile(s->d_tex, s->d_tex_tiled, Ht, Wt, layout, 0)) != hipSuccess) return bail(e, "retile texture");
+        if ((e = hipStreamSynchronize(0)) != hipSuccess) return bail(e, "retile texture");
+        s->dev.tex = s->d_tex_tiled; s->dev.tex_layout = layout; s->dev.tiles_x = tx;
+    }
     *out = s;
     return TEXIR_OK;
 }
@@ -109,6 +122,7 @@ int texir_scene_destroy(texir_scene* s)
     if (s->d_tris) (void)hipFree(s->d_tris);
     if (s->d_uvs) (void)hipFree(s->d_uvs);
     if (s->d_tex) (void)hipFree(s->d_tex);
+    if (s->d_tex_tiled) (void)hipFree(s->d_tex_tiled);
     if (s->d_cnrm) (void)hipFree(s->d_cnrm);
     if (s->d_work) (void)hipFree(s->d_work);
     delete s;
@@ -120,6 +134,7 @@ int texir_scene_set_texture(texir_scene* s, const float* tex, int32_t Ht, int32_
     if (!s || !tex) return fail(TEXIR_ERR_INVALID, "texir_scene_set_texture: null argument");
     if (Ht != s->dev.Ht || Wt != s->dev.Wt) return fail(TEXIR_ERR_INVALID, "texir_scene_set_texture: size %dx%d != scene texture %dx%d", Ht, Wt, s->dev.Ht, s->dev.Wt);
     HIP_TRY(hipMemcpyAsync(s->d_tex, tex, s->tex_bytes, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, (hipStream_t)stream));
+    if (s->d_tex_tiled) HIP_TRY(launch_tex_retile(s->d_tex, s->d_tex_tiled, Ht, Wt, s->dev.tex_layout, (hipStream_t)stream));
     return TEXIR_OK;
 }
 
@@ -128,7 +143,7 @@ int texir_scene_info(const texir_scene* s, int64_t out[8])
     if (!s || !out) return fail(TEXIR_ERR_INVALID, "texir_scene_info: null argument");
     out[0] = s->width == 4 ? s->n_nodes4 : s->n_nodes; out[1] = s->n_tris; out[2] = s->max_depth;
     out[3] = s->width == 4 ? s->n_nodes4 * (int64_t)sizeof(GpuNode4) : s->n_nodes * (int64_t)sizeof(GpuNode);
-    out[4] = s->n_tris * (int64_t)sizeof(GpuTri); out[5] = s->n_tris * (int64_t)sizeof(GpuTriUV); out[6] = (int64_t)s->tex_bytes; out[7] = s->device;
+    out[4] = s->n_tris * (int64_t)sizeof(GpuTri); out[5] = s->n_tris * (int64_t)sizeof(GpuTriUV); out[6] = (int64_t)(s->d_tex_tiled ? s->tiled_bytes : s->tex_bytes); out[7] = s->device;
     return TEXIR_OK;
 }
 
@@ -164,7 +179,13 @@ int texir_irt_generate(const texir_scene* s, const float* pos, const float* nrm,
     return TEXIR_OK;
 }
 
-int32_t texir_irt_launch_count(int32_t N) { return irt_launch_count(N); }
+int texir_irt_kernel_name(const texir_scene* s, int64_t n_ids, int32_t N, char* buf, int32_t cap)
+{
+    if (!s || !buf || cap < 1) return fail(TEXIR_ERR_INVALID, "texir_irt_kernel_name: null argument");
+    const IrtPlan p = irt_plan(s->dev, n_ids, N);
+    snprintf(buf, (size_t)cap, "%s", p.name);
+    return TEXIR_OK;
+}
 
 int texir_spec_forward(const texir_scene* s, const float* normal, const float* albedo, const float* rough, const float* points, const float* irr,
                        const float* cam, const float* shift, int64_t P, int32_t S, float* rgb, float* Ls_ws, void* stream)
@@ -217,11 +238,12 @@ static int check_tex(const char* fn, int H, int W, int C, int levels)
     return 0;
 }
 
-int texir_mip_build(const float* tex, float* mips_rest, int32_t H, int32_t W, int32_t C, int32_t levels, void* stream)
+int texir_mip_build(const float* tex, float* mips_rest, int32_t H, int32_t W, int32_t C, int32_t levels, int32_t from_level, void* stream)
 {
     if (!tex || !mips_rest) return fail(TEXIR_ERR_INVALID, "texir_mip_build: null argument");
+    if (from_level < 0 || from_level > 1) return fail(TEXIR_ERR_INVALID, "texir_mip_build: from_level must be 0 or 1");
     if (int rc = check_tex("texir_mip_build", H, W, C, levels)) return rc;
-    HIP_TRY(launch_mip_build(tex, mips_rest, H, W, C, levels, (hipStream_t)stream));
+    HIP_TRY(launch_mip_build(tex, mips_rest, H, W, C, levels, from_level, (hipStream_t)stream));
     return TEXIR_OK;
 }
 
@@ -269,7 +291,9 @@ int texir_tex_gather_backward(float* d_tex, float* grad_rest, int32_t H, int32_t
                               const int32_t* seg_start, const int32_t* seg_count, int32_t n_seg, const int32_t* pix, const float* weights,
                               const float* d_out, int32_t filter_mode, int32_t defer_last_fold, void* stream)
 {
-    if (!d_tex || !d_out || (n_seg > 0 && (!seg_key || !seg_start || !seg_count || !pix || !weights)) || (filter_mode == 1 && levels > 1 && !grad_rest))
+    // d_tex may be NULL with defer_last_fold when no tap of the lists samples level 0 (then nothing is written there and the caller's
+    // optimiser step treats the level-0 gradient as identically zero)
+    if ((!d_tex && !defer_last_fold) || !d_out || (n_seg > 0 && (!seg_key || !seg_start || !seg_count || !pix || !weights)) || (filter_mode == 1 && levels > 1 && !grad_rest))
         return fail(TEXIR_ERR_INVALID, "texir_tex_gather_backward: null argument");
     if (filter_mode < 0 || filter_mode > 1 || n_seg < 0 || (defer_last_fold && (filter_mode != 1 || levels < 2)))
         return fail(TEXIR_ERR_INVALID, "texir_tex_gather_backward: bad filter_mode/n_seg/defer_last_fold");
@@ -279,12 +303,12 @@ int texir_tex_gather_backward(float* d_tex, float* grad_rest, int32_t H, int32_t
     return TEXIR_OK;
 }
 
-int texir_adam_step_tex(float* param, const float* grad, const float* grad_level1, float* exp_avg, float* exp_avg_sq, int32_t H, int32_t W,
-                        int32_t C, float lr, float beta1, float beta2, float eps, int32_t step, float clamp_lo, float clamp_hi, void* stream)
+int texir_adam_step_tex(float* param, const float* grad, const float* grad_level1, float* exp_avg, float* exp_avg_sq, float* mip_level1, int32_t H,
+                        int32_t W, int32_t C, float lr, float beta1, float beta2, float eps, int32_t step, float clamp_lo, float clamp_hi, void* stream)
 {
-    if (!param || !grad || !grad_level1 || !exp_avg || !exp_avg_sq) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex: null argument");
+    if (!param || !grad_level1 || !exp_avg || !exp_avg_sq) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex: null argument");
     if (H < 2 || W < 2 || (H & 1) || (W & 1) || C < 1 || C > 4 || step < 1) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex: bad H/W/C/step");
-    HIP_TRY(launch_adam_tex(param, grad, grad_level1, exp_avg, exp_avg_sq, H, W, C, lr, beta1, beta2, eps, step, clamp_lo, clamp_hi, (hipStream_t)stream));
+    HIP_TRY(launch_adam_tex(param, grad, grad_level1, exp_avg, exp_avg_sq, mip_level1, H, W, C, lr, beta1, beta2, eps, step, clamp_lo, clamp_hi, (hipStream_t)stream));
     return TEXIR_OK;
 }
 

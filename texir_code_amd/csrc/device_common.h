@@ -14,9 +14,10 @@ struct SceneDev {
     const float4* nodes;   // GpuNode as 4 x float4
     const float4* tris;    // GpuTri as 3 x float4
     const float4* uvs;     // GpuTriUV as 2 x float4
-    const float* tex;      // [Ht,Wt,3]
+    const float* tex;      // [Ht,Wt,3] row-major (layout 0), or the retiled copy the hit shader reads (layouts 1, 2: see shade_hit)
     int Ht, Wt;
-    int top4;              // first top4 wide nodes = upper tree levels (breadth-first), staged into LDS by kernels that opt in
+    int tex_layout;        // 0 row-major; 1 = 8x8-texel tiles of 12-byte texels; 2 = overlapping 3x3 tiles at stride 2, one 128-byte line each
+    int tiles_x;           // tiles per tile row (layouts 1, 2)
 };
 
 constexpr int kBlock = 256;          // 4 waves
@@ -114,10 +115,22 @@ __device__ __forceinline__ void shade_hit(const SceneDev& sc, int tri_slot, floa
     // out-of-range neighbours carry weight exactly 0 after the border clamp, so clamping their index is exact
     float w00 = wx0 * wy0, w10 = (x0 + 1 < sc.Wt) ? wx1 * wy0 : 0.f, w01 = (y0 + 1 < sc.Ht) ? wx0 * wy1 : 0.f,
           w11 = (x0 + 1 < sc.Wt && y0 + 1 < sc.Ht) ? wx1 * wy1 : 0.f;
-    const float* p00 = sc.tex + ((size_t)y0 * sc.Wt + x0) * 3;
-    const float* p10 = sc.tex + ((size_t)y0 * sc.Wt + x1) * 3;
-    const float* p01 = sc.tex + ((size_t)y1 * sc.Wt + x0) * 3;
-    const float* p11 = sc.tex + ((size_t)y1 * sc.Wt + x1) * 3;
+    // Where the four taps live.  The values read are the same in every layout (the retiled copies hold the identical floats), so
+    // the result is bit-identical; what changes is how many 128-byte lines a fetch touches: row-major 2 rows 12*Wt bytes apart
+    // (2.4 lines on average), layout 2 exactly one line (any 2x2 footprint lies inside the 3x3 tile of (x0/2, y0/2)).
+    const float *p00, *p10, *p01, *p11;
+    if (sc.tex_layout == 2) {
+        const float* t = sc.tex + ((size_t)(y0 >> 1) * sc.tiles_x + (x0 >> 1)) * 32 + ((y0 & 1) * 3 + (x0 & 1)) * 3;
+        p00 = t; p10 = t + 3; p01 = t + 9; p11 = t + 12;
+    } else if (sc.tex_layout == 1) {
+        auto at = [&](int x, int y) { return sc.tex + (((size_t)(y >> 3) * sc.tiles_x + (x >> 3)) * 64 + ((y & 7) * 8 + (x & 7))) * 3; };
+        p00 = at(x0, y0); p10 = at(x1, y0); p01 = at(x0, y1); p11 = at(x1, y1);
+    } else {
+        p00 = sc.tex + ((size_t)y0 * sc.Wt + x0) * 3;
+        p10 = sc.tex + ((size_t)y0 * sc.Wt + x1) * 3;
+        p01 = sc.tex + ((size_t)y1 * sc.Wt + x0) * 3;
+        p11 = sc.tex + ((size_t)y1 * sc.Wt + x1) * 3;
+    }
     for (int c = 0; c < 3; c++) {
         float acc = p00[c] * w00;
         acc += p10[c] * w10;
@@ -125,6 +138,23 @@ __device__ __forceinline__ void shade_hit(const SceneDev& sc, int tri_slot, floa
         acc += p11[c] * w11;
         rgb[c] = acc;
     }
+}
+
+// Watertight triangle test (Woop, Benthin, Wald: "Watertight Ray/Triangle Intersection", JCGT 2013 -- the algorithm class Embree's
+// robust mode stands for; Open3D's RaycastingScene is an Embree scene): the triangle's vertices are moved to the ray's origin and
+// sheared so that the ray becomes the +z axis; what is left is a 2D point-in-triangle test of the origin.  A vertex's sheared
+// coordinates depend on the vertex and the ray only, so every triangle sharing it sees the same numbers, and the three edge
+// functions  C.x*B.y - C.y*B.x  are evaluated with EXACT signs: products and difference rounded separately (rounding is monotonic:
+// the sign of the rounded difference is right unless it is 0), and an exact-zero result is resolved by the error terms of the two
+// products (fma(a, b, -fl(a*b)) is exact).  The set of triangles that accept a ray is therefore exactly the set whose sheared
+// (rounded) 2D image contains the origin, edges and vertices included: a closed mesh cannot leak.
+// Returns U, V, W (weights of v0, v1, v2 before normalisation) and whether the origin is inside (all signs agree, zeros count as inside).
+__device__ __forceinline__ float edge2_exact(float bx, float by, float cx, float cy)
+{
+    const float p = cx * by, q = cy * bx;
+    float r = p - q;
+    if (r == 0.f) r = __builtin_fmaf(cx, by, -p) - __builtin_fmaf(cy, bx, -q);
+    return r;
 }
 
 #pragma clang fp contract(fast)
@@ -139,6 +169,9 @@ struct Hit { float t, u, v; int slot; };
 // Per-lane traversal state.  A ray is started with ray_begin() and advanced with traverse(); node == kSentinel <=> finished.
 struct RayState {
     float dx, dy, dz, idx, idy, idz, oodx, oody, oodz;
+#if TEXIR_TRI_WATERTIGHT
+    float mx[3], my[3], mz[3];       // rows of the ray-space shear: x' = A . mx, y' = A . my, z' = A . mz (A = vertex - origin)
+#endif
     Hit h;
     int node, sp;
 };
@@ -153,6 +186,25 @@ __device__ __forceinline__ void ray_begin(RayState& r, float ox, float oy, float
     r.oodx = ox * r.idx; r.oody = oy * r.idy; r.oodz = oz * r.idz;
     r.h.t = __builtin_inff(); r.h.u = 0.f; r.h.v = 0.f; r.h.slot = -1;
     r.node = 0; r.sp = 0;
+#if TEXIR_TRI_WATERTIGHT
+    {
+        // kz = dominant axis of the direction, (kx, ky) the other two in an order that keeps the winding; the shear maps d to (0, 0, 1)
+        const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
+        const int kz = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+        const float dkz = kz == 0 ? dx : (kz == 1 ? dy : dz);
+        const bool neg = dkz < 0.f;
+        const int k1 = kz == 2 ? 0 : kz + 1, k2 = k1 == 2 ? 0 : k1 + 1;
+        const int kx = neg ? k2 : k1, ky = neg ? k1 : k2;
+        const float dkx = kx == 0 ? dx : (kx == 1 ? dy : dz), dky = ky == 0 ? dx : (ky == 1 ? dy : dz);
+        const float Sz = __builtin_amdgcn_rcpf(dkz), Sx = dkx * Sz, Sy = dky * Sz;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            r.mx[c] = c == kx ? 1.f : (c == kz ? -Sx : 0.f);
+            r.my[c] = c == ky ? 1.f : (c == kz ? -Sy : 0.f);
+            r.mz[c] = c == kz ? Sz : 0.f;
+        }
+    }
+#endif
 }
 
 struct NeverLeave { static constexpr bool never = true; __device__ bool operator()(int) const { return false; } };
@@ -161,35 +213,50 @@ struct NeverLeave { static constexpr bool never = true; __device__ bool operator
 // until every lane is back at a node) until all lanes have finished, or until leave(node) -- evaluated once per round with
 // the lane's current node -- is true (it must be wave-uniform and define `static constexpr bool never = false`; a persistent
 // kernel can use it to hand finished lanes their next ray -- measured slower than lock-step passes).  One instance per kernel (it owns the LDS part of the stacks); `ovf` is the caller's private overflow.
-template <bool STATS, int LSTK, int WIDTH, typename Leave>
-__device__ __forceinline__ void traverse(const SceneDev& sc, RayState& r, int (&ovf)[kStackCap - LSTK], float ox, float oy, float oz,
+//
+// CULL: a stack entry also carries the child's entry distance, and an entry whose distance is not below the closest hit found
+// since it was pushed is dropped when it is popped (it cannot contain a closer hit: same result, bit for bit) instead of
+// costing a node fetch + a full node step that finds all four children behind the hit.  Entries are 8 bytes then (one
+// ds_write_b64 / ds_read_b64, conflict-free in the [entry][thread] layout), so a kernel keeps LSTK * 2 KiB of LDS per block.
+template <bool CULL> struct StackEntry { typedef int type; };
+template <> struct StackEntry<true> { typedef int2 type; };
+
+template <bool STATS, int LSTK, int WIDTH, bool CULL, typename Leave>
+__device__ __forceinline__ void traverse(const SceneDev& sc, RayState& r, typename StackEntry<CULL>::type (&ovf)[kStackCap - LSTK], float ox, float oy, float oz,
                                          uint32_t& n_nodes, uint32_t& n_tris, uint32_t* wave_iters, Leave leave)
 {
+    typedef typename StackEntry<CULL>::type Entry;
     // STATS: n_nodes / n_tris count this lane's node fetches and triangle tests; wave_iters[0/1] (if given) count, on the first
     // active lane, how many times the wave executed the node-step and the triangle-step bodies (for lane-utilisation figures)
     auto first_active = [&]() -> bool { unsigned long long m = __ballot(1); return (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1; };
     // the traversal stack: LSTK entries per lane in LDS ([entry][thread]), deeper ones private.  The stack pointer is kept as
     // the LDS address of the next free entry (push = ds_write + one add, no index scaling in the node step).
-    __shared__ int lds_all[LSTK * kBlock];
-    int* const base = lds_all + threadIdx.x;
-    int* const lim = base + LSTK * kBlock;
-    int* top = base + r.sp * kBlock;
+    __shared__ Entry lds_all[LSTK * kBlock];
+    Entry* const base = lds_all + threadIdx.x;
+    Entry* const lim = base + LSTK * kBlock;
+    Entry* top = base + r.sp * kBlock;
     const float dx = r.dx, dy = r.dy, dz = r.dz, idx = r.idx, idy = r.idy, idz = r.idz, oodx = r.oodx, oody = r.oody, oodz = r.oodz;
     Hit h = r.h;
     int node = r.node;
+    (void)dx; (void)dy; (void)dz;       // (the watertight intersector of the 4-wide path reads the ray's shear rows instead)
+    auto make = [](int code, float tn) -> Entry { if constexpr (CULL) return make_int2(code, __float_as_int(tn)); else return code; };
     // LDS part and private overflow are kept in separate, wave-uniformly guarded code paths: the overflow is almost never
     // touched (depth > LSTK), and hipcc must not merge the two address spaces into one flat access
-    auto push = [&](int x) {
+    auto push = [&](int code, float tn) {
+        const Entry x = make(code, tn);
         if (top < lim) *top = x;
         if (__any(top >= lim)) { if (top >= lim) ovf[(top - lim) / kBlock] = x; }
         top += kBlock;
     };
     auto pop = [&]() -> int {
-        if (top == base) return kSentinel;
-        top -= kBlock;
-        int v = *(top < lim ? top : lim - kBlock);
-        if (__any(top >= lim)) { int b = ovf[top >= lim ? (top - lim) / kBlock : 0]; v = top >= lim ? b : v; }
-        return v;
+        for (;;) {
+            if (top == base) return kSentinel;
+            top -= kBlock;
+            Entry v = *(top < lim ? top : lim - kBlock);
+            if (__any(top >= lim)) { Entry b = ovf[top >= lim ? (top - lim) / kBlock : 0]; v = top >= lim ? b : v; }
+            if constexpr (CULL) { if (__int_as_float(v.y) < h.t) return v.x; }      // else: behind the closest hit, drop it
+            else return v;
+        }
     };
     for (;;) {
         // run-to-completion callers: plain per-lane loop.  Resumable callers: wave-uniform loop control -- finished lanes stay in
@@ -231,16 +298,20 @@ __device__ __forceinline__ void traverse(const SceneDev& sc, RayState& r, int (&
                 const float inf = __builtin_inff();
                 if (!__any(top + 3 * kBlock > lim)) {
                     // common case (one wave-uniform test per node): the whole update stays inside the LDS part of the stack
-                    if (key[3] < inf) { *top = code[3]; top += kBlock; }
-                    if (key[2] < inf) { *top = code[2]; top += kBlock; }
-                    if (key[1] < inf) { *top = code[1]; top += kBlock; }
+                    if (key[3] < inf) { *top = make(code[3], key[3]); top += kBlock; }
+                    if (key[2] < inf) { *top = make(code[2], key[2]); top += kBlock; }
+                    if (key[1] < inf) { *top = make(code[1], key[1]); top += kBlock; }
                     if (key[0] < inf) node = code[0];
-                    else if (top != base) { top -= kBlock; node = *top; }
+                    else if constexpr (CULL) {
+                        node = kSentinel;
+                        while (top != base) { top -= kBlock; const Entry e = *top; if (__int_as_float(e.y) < h.t) { node = e.x; break; } }
+                    }
+                    else if (top != base) { top -= kBlock; node = *reinterpret_cast<const int*>(top); }
                     else node = kSentinel;
                 } else {
-                    if (key[3] < inf) push(code[3]);
-                    if (key[2] < inf) push(code[2]);
-                    if (key[1] < inf) push(code[1]);
+                    if (key[3] < inf) push(code[3], key[3]);
+                    if (key[2] < inf) push(code[2], key[2]);
+                    if (key[1] < inf) push(code[1], key[1]);
                     node = key[0] < inf ? code[0] : pop();
                 }
             }
@@ -262,7 +333,7 @@ __device__ __forceinline__ void traverse(const SceneDev& sc, RayState& r, int (&
                 if (h0 && h1) {
                     bool swp = t1n < t0n;
                     int nearc = swp ? ch.y : ch.x, farc = swp ? ch.x : ch.y;
-                    push(farc);
+                    push(farc, swp ? t0n : t1n);
                     node = nearc;
                 } else if (h0) node = ch.x;
                 else if (h1) node = ch.y;
@@ -271,12 +342,33 @@ __device__ __forceinline__ void traverse(const SceneDev& sc, RayState& r, int (&
 }
         while (node < 0) {
             const uint32_t code = ~(uint32_t)node;
-            node = pop();
+            if constexpr (!CULL) node = pop();           // (early: the LDS read overlaps the triangle loads)
             int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
             for (int i = first; i < first + cnt; i++) {
                 const float4* tp = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.tris) + (uint32_t)i * 48u);
                 float4 v0 = tp[0], e1 = tp[1], e2 = tp[2];
                 if (STATS) { n_tris++; if (wave_iters && first_active()) wave_iters[1]++; }
+#if TEXIR_TRI_WATERTIGHT
+                // (tp[1], tp[2] hold the vertices v1, v2 here, not edges.)  Shear the three vertices into ray space ...
+                const float a0 = v0.x - ox, a1 = v0.y - oy, a2 = v0.z - oz;
+                const float b0 = e1.x - ox, b1 = e1.y - oy, b2 = e1.z - oz;
+                const float c0 = e2.x - ox, c1 = e2.y - oy, c2 = e2.z - oz;
+                const float Ax = __builtin_fmaf(a2, r.mx[2], __builtin_fmaf(a1, r.mx[1], a0 * r.mx[0])), Ay = __builtin_fmaf(a2, r.my[2], __builtin_fmaf(a1, r.my[1], a0 * r.my[0]));
+                const float Bx = __builtin_fmaf(b2, r.mx[2], __builtin_fmaf(b1, r.mx[1], b0 * r.mx[0])), By = __builtin_fmaf(b2, r.my[2], __builtin_fmaf(b1, r.my[1], b0 * r.my[0]));
+                const float Cx = __builtin_fmaf(c2, r.mx[2], __builtin_fmaf(c1, r.mx[1], c0 * r.mx[0])), Cy = __builtin_fmaf(c2, r.my[2], __builtin_fmaf(c1, r.my[1], c0 * r.my[0]));
+                // ... 2D edge functions with exact signs (device_common.h edge2_exact): U, V, W = unnormalised weights of v0, v1, v2
+                const float U = edge2_exact(Bx, By, Cx, Cy), V = edge2_exact(Cx, Cy, Ax, Ay), W = edge2_exact(Ax, Ay, Bx, By);
+                const float mn = fminf(fminf(U, V), W), mx = fmaxf(fmaxf(U, V), W);
+                const float det = U + V + W;
+                const float Az = __builtin_fmaf(a2, r.mz[2], __builtin_fmaf(a1, r.mz[1], a0 * r.mz[0]));
+                const float Bz = __builtin_fmaf(b2, r.mz[2], __builtin_fmaf(b1, r.mz[1], b0 * r.mz[0]));
+                const float Cz = __builtin_fmaf(c2, r.mz[2], __builtin_fmaf(c1, r.mz[1], c0 * r.mz[0]));
+                const float inv = __builtin_amdgcn_rcpf(det);
+                const float t = (U * Az + V * Bz + W * Cz) * inv;
+                const float u = V * inv, v = W * inv;
+                // inside <=> no two of the signs differ (zeros -- the origin exactly on an edge or vertex -- count as inside for BOTH neighbours)
+                const bool ok = !((mn < 0.f) & (mx > 0.f)) & (det != 0.f) & (t > 0.f) & (t < h.t);
+#else
                 // Moeller-Trumbore, same operation order as the oracle
                 float px = dy * e2.z - dz * e2.y, py = dz * e2.x - dx * e2.z, pz = dx * e2.y - dy * e2.x;
                 float det = e1.x * px + e1.y * py + e1.z * pz;
@@ -287,22 +379,24 @@ __device__ __forceinline__ void traverse(const SceneDev& sc, RayState& r, int (&
                 float v = (dx * qx + dy * qy + dz * qz) * inv;
                 float t = (e2.x * qx + e2.y * qy + e2.z * qz) * inv;
                 bool ok = (det != 0.f) & (u >= 0.f) & (u <= 1.f) & (v >= 0.f) & (u + v <= 1.f) & (t > 0.f) & (t < h.t);
+#endif
                 if (ok) { h.t = t; h.u = u; h.v = v; h.slot = i; }
             }
+            if constexpr (CULL) node = pop();            // after the tests: the pop drops what this leaf's hit has just put out of reach
         }
     }
     r.h = h; r.sp = (int)(top - base) / kBlock; r.node = node;
 }
 
 // closest hit of one ray per lane, run to completion
-template <bool STATS, int LSTK = kLdsStack, int WIDTH = 2>
+template <bool STATS, int LSTK = kLdsStack, int WIDTH = 2, bool CULL = false>
 __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float oy, float oz, float dx, float dy, float dz,
                                              uint32_t& n_nodes, uint32_t& n_tris, uint32_t* wave_iters = nullptr)
 {
     RayState r;
     ray_begin(r, ox, oy, oz, dx, dy, dz);
-    int ovf[kStackCap - LSTK];
-    traverse<STATS, LSTK, WIDTH>(sc, r, ovf, ox, oy, oz, n_nodes, n_tris, wave_iters, NeverLeave());
+    typename StackEntry<CULL>::type ovf[kStackCap - LSTK];
+    traverse<STATS, LSTK, WIDTH, CULL>(sc, r, ovf, ox, oy, oz, n_nodes, n_tris, wave_iters, NeverLeave());
     return r.h;
 }
 

@@ -9,7 +9,10 @@ namespace texir {
 hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, const float* shift, const int32_t* ids, int64_t n_ids,
                       int N, int mode, float* irr, unsigned long long* stats, unsigned long long* work /*dev: chunk counter of this launch*/,
                       hipStream_t st);
-int irt_launch_count(int N);
+struct IrtPlan { int per_wave, log2parts, width; char name[64]; };
+IrtPlan irt_plan(const SceneDev& sc, int64_t n_ids, int N);      // the kernel form launch_irt picks for this call
+size_t tex_retile_bytes(int Ht, int Wt, int layout, int* tiles_x, int* tiles_y);
+hipError_t launch_tex_retile(const float* src_row_major, float* dst, int Ht, int Wt, int layout, hipStream_t st);
 hipError_t launch_trace_shade(const SceneDev& sc, const float* org, const float* dir, int64_t R, float t_min, float* rad, float* t_hit,
                               uint32_t* prim, float* puv, hipStream_t st);
 hipError_t launch_gen_dir(const float* normals, const float* rough, const float* shift, int64_t b, int N, int mode, float* L, hipStream_t st);
@@ -26,7 +29,7 @@ hipError_t launch_gbuffer(const SceneDev& sc, const float* mvp_host, const float
                           float* uv, float* uvda, int32_t* tri, hipStream_t st);
 int mip_levels(int H, int W, int max_mip_level);
 int64_t mip_total_elems(int H, int W, int C, int levels);
-hipError_t launch_mip_build(const float* tex, float* rest, int H, int W, int C, int levels, hipStream_t st);
+hipError_t launch_mip_build(const float* tex, float* rest, int H, int W, int C, int levels, int from_level, hipStream_t st);
 hipError_t launch_tex_fetch(const float* tex, const float* rest, int H, int W, int C, int levels, const float* uv, const float* uvda, int trilinear,
                             int64_t P, float* out, hipStream_t st);
 hipError_t launch_tex_fetch_bwd(float* d_tex, float* grad_rest, int H, int W, int C, int levels, const float* uv, const float* uvda, int trilinear,
@@ -36,8 +39,8 @@ hipError_t launch_tex_taps(int H, int W, int C, int levels, const float* uv, con
 hipError_t launch_tex_gather_bwd(float* d_tex, float* grad_rest, int H, int W, int C, int levels, const long long* seg_key, const int* seg_start,
                                  const int* seg_count, int n_seg, const int* pix, const float* w, const float* d_out, int trilinear,
                                  int fold_to_level, hipStream_t st);
-hipError_t launch_adam_tex(float* p, const float* g, const float* g1, float* m, float* v, int H, int W, int C, float lr, float beta1, float beta2,
-                           float eps, int step, float lo, float hi, hipStream_t st);
+hipError_t launch_adam_tex(float* p, const float* g /*nullable*/, const float* g1, float* m, float* v, float* mip1 /*nullable*/, int H, int W, int C, float lr,
+                           float beta1, float beta2, float eps, int step, float lo, float hi, hipStream_t st);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step,
                        float lo, float hi, hipStream_t st);
 }  // namespace texir

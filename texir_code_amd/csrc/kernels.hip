@@ -5,12 +5,15 @@
 //   spec_fwd/bwd_kernel render + specular_reflectance and its analytic grad  (models/mat_nvdiffrast.py:201-279)
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "device_common.h"
 #include "kernels.h"
 
 namespace texir {
+
+static int grid_for_static(int64_t per_block, int64_t n) { int64_t w = (n + per_block - 1) / per_block; return (int)(w < 1 ? 1 : (w > 2048 ? 2048 : w)); }
 
 // Sample order inside a texel.  The estimator is a plain sum, so the order is free; choose it so that the 64
 // samples a wave traces together fall into one (phi-bin, cos-theta-bin) cell of the Hammersley lattice
@@ -40,8 +43,16 @@ __device__ __forceinline__ void irt_stats_flush(unsigned long long* stats, int l
 
 // Occupancy: 7 waves/SIMD (<= 72 VGPRs; the compiler parks the per-texel frame in scratch across the traversal loop) with a
 // 16-entry LDS stack (16 KiB per block) measured best: 5 waves / 24 entries 13.85, 6 / 24 14.79, 7 / 16 15.11, 8 / 16 15.06 Grays/s (c4).
-constexpr int kGroupLstk = 16;
+#ifndef TEXIR_CULL
+#define TEXIR_CULL 1
+#endif
+constexpr bool kCull = TEXIR_CULL != 0;
+#ifndef TEXIR_GROUP_LSTK
+#define TEXIR_GROUP_LSTK (TEXIR_CULL ? 11 : 16)         // 8-byte entries with culling: 11 x 2 KiB = 22 KiB per block, 7 blocks = 154 of 160 KiB
+#endif
+constexpr int kGroupLstk = TEXIR_GROUP_LSTK;
 constexpr int kGroupWaves = 7;
+constexpr int kLstk = kCull ? kLdsStack / 2 : kLdsStack;   // the other tracing kernels: 24 KiB of stack per block either way
 
 // One texel per wave: the 64 lanes trace 64 samples of the texel per pass (any N, binary or 4-wide tree).  Kept as the
 // form for short texel lists (a 1024-point NIrF batch), for binary-tree scenes, and TEXIR_IRT_TEXELS_PER_WAVE=1.
@@ -69,7 +80,7 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_kernel(SceneDev sc, c
                 float s1 = shift_wrap_clamp(ham1(i), sh1);
                 float d[3];
                 sample_dir(mode, s0, s1, 0.f, f, d);
-                Hit h = trace_closest<STATS, kGroupLstk, WIDTH>(sc, px, py, pz, d[0], d[1], d[2], c_nodes, c_tris, STATS ? wi : nullptr);
+                Hit h = trace_closest<STATS, kGroupLstk, WIDTH, kCull>(sc, px, py, pz, d[0], d[1], d[2], c_nodes, c_tris, STATS ? wi : nullptr);
                 if (STATS) c_rays++;
                 if (h.slot >= 0 && h.t > 1e-4f) {          // tracer_o3d_irt.py:248
                     float L[3];
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
                 float s1 = shift_wrap_clamp(ham1(i), sh1);
                 float d[3];
                 sample_dir(mode, s0, s1, 0.f, f, d);
-                Hit h = trace_closest<STATS, kGroupLstk, WIDTH>(sc, px, py, pz, d[0], d[1], d[2], cn, ct, STATS ? wi : nullptr);
+                Hit h = trace_closest<STATS, kGroupLstk, WIDTH, kCull>(sc, px, py, pz, d[0], d[1], d[2], cn, ct, STATS ? wi : nullptr);
                 if (STATS) c_rays++;
                 if (h.slot >= 0 && h.t > 1e-4f) {          // tracer_o3d_irt.py:248
                     float L[3];
@@ -204,6 +215,54 @@ __global__ __launch_bounds__(256) void irt_combine_kernel(const float* __restric
     }
 }
 
+// Retiled copies of the radiance texture for the hit shader (device_common.h shade_hit): same floats, other addresses.
+//   layout 1: 8x8-texel tiles, 12-byte texels (768 B per tile), tile-row major
+//   layout 2: one 128-byte line per 3x3 block of texels at stride 2 (27 floats + 5 pad), so that every 2x2 bilinear footprint
+//             lies inside ONE line; texels past the right/bottom edge repeat the edge texel (their bilinear weight is 0)
+__global__ __launch_bounds__(256) void tex_retile_kernel(const float* __restrict__ src, float* __restrict__ dst, int Ht, int Wt, int layout, int tiles_x, int tiles_y)
+{
+    if (layout == 2) {
+        const int64_t n = (int64_t)tiles_x * tiles_y * 32;
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+            const int64_t tile = e >> 5; const int f = (int)(e & 31);
+            float v = 0.f;
+            if (f < 27) {
+                const int ty = (int)(tile / tiles_x), tx = (int)(tile - (int64_t)ty * tiles_x);
+                const int r = f / 9, c = (f - 9 * r) / 3, ch = f - 9 * r - 3 * c;
+                const int y = min(2 * ty + r, Ht - 1), x = min(2 * tx + c, Wt - 1);
+                v = src[((size_t)y * Wt + x) * 3 + ch];
+            }
+            dst[e] = v;
+        }
+    } else {
+        const int64_t n = (int64_t)tiles_x * tiles_y * 192;
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+            const int64_t tile = e / 192; const int f = (int)(e - tile * 192);
+            const int ty = (int)(tile / tiles_x), tx = (int)(tile - (int64_t)ty * tiles_x);
+            const int t = f / 3, ch = f - 3 * t;
+            const int y = min(8 * ty + (t >> 3), Ht - 1), x = min(8 * tx + (t & 7), Wt - 1);
+            dst[e] = src[((size_t)y * Wt + x) * 3 + ch];
+        }
+    }
+}
+
+size_t tex_retile_bytes(int Ht, int Wt, int layout, int* tiles_x, int* tiles_y)
+{
+    if (layout == 2) { *tiles_x = (Wt + 1) / 2; *tiles_y = (Ht + 1) / 2; return (size_t)*tiles_x * *tiles_y * 128; }
+    if (layout == 1) { *tiles_x = (Wt + 7) / 8; *tiles_y = (Ht + 7) / 8; return (size_t)*tiles_x * *tiles_y * 768; }
+    *tiles_x = *tiles_y = 0;
+    return 0;
+}
+
+hipError_t launch_tex_retile(const float* src, float* dst, int Ht, int Wt, int layout, hipStream_t st)
+{
+    int tx, ty;
+    const size_t bytes = tex_retile_bytes(Ht, Wt, layout, &tx, &ty);
+    if (!bytes) return hipSuccess;
+    hipLaunchKernelGGL(tex_retile_kernel, dim3(grid_for_static(256, (int64_t)(bytes / 4))), dim3(256), 0, st, src, dst, Ht, Wt, layout, tx, ty);
+    return hipGetLastError();
+}
+
 template <int WIDTH>
 __global__ __launch_bounds__(kBlock) void trace_shade_kernel(SceneDev sc, const float* __restrict__ org, const float* __restrict__ dir,
                                                              int64_t R, float t_min, float* __restrict__ rad, float* __restrict__ t_hit,
@@ -213,7 +272,7 @@ __global__ __launch_bounds__(kBlock) void trace_shade_kernel(SceneDev sc, const 
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < R; r += (int64_t)gridDim.x * kBlock) {
         float ox = org[3 * r], oy = org[3 * r + 1], oz = org[3 * r + 2];
         float dx = dir[3 * r], dy = dir[3 * r + 1], dz = dir[3 * r + 2];
-        Hit h = trace_closest<false, kLdsStack, WIDTH>(sc, ox, oy, oz, dx, dy, dz, cn, ct);
+        Hit h = trace_closest<false, kLstk, WIDTH, kCull>(sc, ox, oy, oz, dx, dy, dz, cn, ct);
         float L[3] = {0.f, 0.f, 0.f};
         bool hit = h.slot >= 0 && h.t > t_min;
         if (hit) shade_hit(sc, h.slot, h.u, h.v, L);
@@ -349,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(SceneDev sc, const float* 
                     L[0] = lp[0]; L[1] = lp[1]; L[2] = lp[2];
                     dacc += (L[0] * g0 + L[1] * g1 + L[2] * g2) * ss.w.d;
                 } else {
-                    Hit h = trace_closest<false, kLdsStack, WIDTH>(sc, ox, oy, oz, ss.l[0], ss.l[1], ss.l[2], cn, ct);
+                    Hit h = trace_closest<false, kLstk, WIDTH, kCull>(sc, ox, oy, oz, ss.l[0], ss.l[1], ss.l[2], cn, ct);
                     if (h.slot >= 0 && h.t > 1e-4f) shade_hit(sc, h.slot, h.u, h.v, L);
                     if (Ls_ws) { float* lp = Ls_ws + 3 * ((size_t)p * S + i); lp[0] = L[0]; lp[1] = L[1]; lp[2] = L[2]; }
                     acc[0] += L[0] * ss.w.v; acc[1] += L[1] * ss.w.v; acc[2] += L[2] * ss.w.v;
@@ -408,7 +467,26 @@ static int irt_forced_texels_per_wave()
     return (v == 1 || v == 64) ? v : 0;
 }
 
-int irt_launch_count(int) { return 1; }
+// Which kernel form a call launches (shared by launch_irt and texir_irt_kernel_name, so that a bench line names what really ran):
+// texels per wave: 64 from 32 768 listed texels up, else 1 (a short list does not fill the chip with 64-texel groups; measured on the
+// c2 scene, Grays/s for 1 / 64 per wave: 16 k texels 10.7 / 10.1, 65 k 11.3 / 14.3, 131 k 11.5 / 14.8, 524 k 11.3 / 16.0; a 16-texel
+// form was slower than both at every length and is gone).
+// 64 texels per wave: the passes of a texel are cut into 2^log2parts ranges of >= 64 passes (N = 2048: 32 ranges), each range its
+// own chunk.  Fine chunks matter for lists up to ~1 M texels (262 k texels: 8 ranges 14.1, 32 ranges 15.7 Grays/s), i.e. for every
+// rank's share of a multi-GPU run; the number of ranges depends on N alone, so results do not depend on the sharding.
+IrtPlan irt_plan(const SceneDev& sc, int64_t n_ids, int N)
+{
+    IrtPlan p{};
+    const int forced = irt_forced_texels_per_wave();
+    const bool pow2 = (N & (N - 1)) == 0;
+    p.width = sc.nodes4 ? 4 : 2;
+    p.per_wave = !sc.nodes4 ? 1 : (forced ? forced : (n_ids >= 32768 ? 64 : 1));
+    p.log2parts = 0;
+    if (sc.nodes4 && p.per_wave == 64 && pow2) { while (p.log2parts < 5 && (N >> (p.log2parts + 1)) >= 64) p.log2parts++; }
+    if (const char* cap = getenv("TEXIR_IRT_LOG2PARTS")) { if (p.log2parts > atoi(cap)) p.log2parts = atoi(cap) < 0 ? 0 : atoi(cap); }   // A/B switch
+    snprintf(p.name, sizeof(p.name), p.per_wave == 64 ? "irt_group_kernel<false, %d, 6>" : "irt_kernel<false, %d>", p.width);
+    return p;
+}
 
 template <typename K>
 static void irt_launch(K kernel, int64_t waves_wanted, const SceneDev& sc, const float* pos, const float* nrm, const float* shift,
@@ -428,22 +506,14 @@ hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, co
     if (n_ids <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(work, 0, sizeof(unsigned long long), st);       // chunk counter of this launch
     if (e != hipSuccess) return e;
-    const int forced = irt_forced_texels_per_wave();
     const bool pow2 = (N & (N - 1)) == 0;
     const int l2 = ilog2_exact(N);
+    const IrtPlan plan = irt_plan(sc, n_ids, N);
 #define TEXIR_IRT(WAVES, L2, NAME, ...) { if (stats) irt_launch(NAME<true, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, work, partial, log2parts, st); \
                                         else irt_launch(NAME<false, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, work, partial, log2parts, st); }
-    // texels per wave: 64 from 32 768 listed texels up, else 1 (a short list does not fill the chip with 64-texel groups; measured on the
-    // c2 scene, Grays/s for 1 / 64 per wave: 16 k texels 10.7 / 10.1, 65 k 11.3 / 14.3, 131 k 11.5 / 14.8, 524 k 11.3 / 16.0; a 16-texel
-    // form was slower than both at every length and is gone)
-    int per_wave = forced ? forced : (n_ids >= 32768 ? 64 : 1);
-    // 64 texels per wave: the passes of a texel are cut into 2^log2parts ranges of >= 64 passes (N = 2048: 32 ranges), each range its
-    // own chunk.  Fine chunks matter for lists up to ~1 M texels (262 k texels: 8 ranges 14.1, 32 ranges 15.7 Grays/s), i.e. for every
-    // rank's share of a multi-GPU run; the number of ranges depends on N alone, so results do not depend on the sharding.
+    const int per_wave = plan.per_wave;
     float* partial = nullptr;
-    int log2parts = 0;
-    if (sc.nodes4 && per_wave == 64 && pow2) { while (log2parts < 5 && (N >> (log2parts + 1)) >= 64) log2parts++; }
-    if (const char* cap = getenv("TEXIR_IRT_LOG2PARTS")) { if (log2parts > atoi(cap)) log2parts = atoi(cap) < 0 ? 0 : atoi(cap); }   // A/B switch
+    const int log2parts = plan.log2parts;
     if (log2parts) {
         const size_t bytes = sizeof(float) * 3 * (size_t)n_ids << log2parts;
         // stream-ordered scratch (384 B per listed texel at N >= 2048: 4.8 GB at 4k^2 texels); keep it cached in the device's pool between calls instead of

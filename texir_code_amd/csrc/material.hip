@@ -11,6 +11,7 @@
 //   adam_kernel        torch.optim.Adam step fused with the trainer's post-step clamp (train_material.py:448-458).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "device_common.h"
 #include "kernels.h"
@@ -48,12 +49,15 @@ __global__ __launch_bounds__(kBlock) void gbuffer_kernel(SceneDev sc, GbufArgs g
         const float s2 = 2.f / (float)g.c;
         float dXx = s2 * fb.dx[0], dXy = s2 * fb.dx[1], dXz = s2 * fb.dx[2];
         float dYx = s2 * fb.dy[0], dYy = s2 * fb.dy[1], dYz = s2 * fb.dy[2];
-        Hit h = trace_closest<false, kLdsStack, WIDTH>(sc, ex, ey, ez, dx, dy, dz, cn, ct);
+        Hit h = trace_closest<false, kLdsStack / 2, WIDTH, true>(sc, ex, ey, ez, dx, dy, dz, cn, ct);
         float o_pos[3] = {1.f, 0.f, 0.f}, o_n[3] = {1.f, 0.f, 0.f}, o_uv[2] = {0.f, 0.f}, o_da[4] = {0.f, 0.f, 0.f, 0.f};   // bg (mat_nvdiffrast.py:125)
         float m = 0.f; int32_t tri = 0;
         if (h.slot >= 0) {
             const float4* tp = sc.tris + 3 * (size_t)h.slot;
             float4 v0 = tp[0], e1 = tp[1], e2 = tp[2];
+#if TEXIR_TRI_WATERTIGHT
+            e1.x -= v0.x; e1.y -= v0.y; e1.z -= v0.z; e2.x -= v0.x; e2.y -= v0.y; e2.z -= v0.z;      // the record holds v1, v2
+#endif
             m = 1.f; tri = (int32_t)__float_as_uint(v0.w) + 1;
             const float u = h.u, v = h.v, w = 1.f - u - v;
             o_pos[0] = v0.x + u * e1.x + v * e2.x; o_pos[1] = v0.y + u * e1.y + v * e2.y; o_pos[2] = v0.z + u * e1.z + v * e2.z;
@@ -233,6 +237,111 @@ __global__ __launch_bounds__(1024) void mip_fold_tail_kernel(float* __restrict__
     }
 }
 
+
+// Several mip levels per launch.  A block owns a 32x32-texel tile of the SOURCE level s and produces its 16x16 / 8x8 / ... / 1x1
+// descendants (levels s+1 .. s+5) through LDS; the levels above (at most 32^2 texels) are left to the single-block tail kernel.
+// Same arithmetic as one mip_down_kernel launch per level (0.25 * (((a + b) + c) + d)), so the stack is bit-identical.
+template <int C>
+__global__ __launch_bounds__(256) void mip_pyr_down_kernel(const float* __restrict__ src, float* __restrict__ rest, MipDesc d, int s, int n_out)
+{
+    __shared__ float buf[2][16 * 16 * C];
+    const int Hs = d.H >> s, Ws = d.W >> s;
+    const int tiles_x = (Ws + 31) / 32;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    // level s+1: 16x16 outputs straight from global memory, one thread per output texel
+    {
+        const int oy = threadIdx.x >> 4, ox = threadIdx.x & 15;
+        const int Y = ty * 16 + oy, X = tx * 16 + ox, Hd = Hs >> 1, Wd = Ws >> 1;
+        if (Y < Hd && X < Wd) {
+            const float* r0 = src + ((size_t)(2 * Y) * Ws + 2 * X) * C;
+            const float* r1 = r0 + (size_t)Ws * C;
+            float* o = rest + d.off[s + 1] + ((size_t)Y * Wd + X) * C;
+#pragma unroll
+            for (int c = 0; c < C; c++) { const float v = 0.25f * (r0[c] + r0[C + c] + r1[c] + r1[C + c]); o[c] = v; buf[0][(oy * 16 + ox) * C + c] = v; }
+        }
+    }
+    int cur = 0;
+    for (int k = 2; k <= n_out; k++) {
+        __syncthreads();
+        const int n = 32 >> k;                                  // outputs per tile side at level s+k
+        const int Hd = Hs >> k, Wd = Ws >> k;
+        if ((int)threadIdx.x < n * n) {
+            const int oy = threadIdx.x / n, ox = threadIdx.x - oy * n;
+            const int Y = ty * n + oy, X = tx * n + ox;
+            if (Y < Hd && X < Wd) {
+                const float* b = buf[cur] + ((2 * oy) * (2 * n) + 2 * ox) * C;
+                float* o = rest + d.off[s + k] + ((size_t)Y * Wd + X) * C;
+#pragma unroll
+                for (int c = 0; c < C; c++) { const float v = 0.25f * (b[c] + b[C + c] + b[2 * n * C + c] + b[2 * n * C + C + c]); o[c] = v; buf[cur ^ 1][(oy * n + ox) * C + c] = v; }
+            }
+        }
+        cur ^= 1;
+    }
+}
+
+// The folds of a whole gradient stack in one launch: level f (the finest one to fold INTO) += 0.25 * level f+1 += 0.25 * level f+2 ...
+// A block owns a 32x32 tile of level f.  It first walks its chain of ancestors down from the top level (one texel per level: the
+// same fused multiply-adds the level-by-level kernels perform on those texels), then folds its own sub-pyramid (levels f+5 .. f+1)
+// through LDS and finally read-modify-writes its tile of level f.  Only level f is written back: nothing reads the coarser
+// gradient levels afterwards.  Bit-identical to mip_fold_tail_kernel + one mip_fold_kernel launch per level.
+template <int C>
+__global__ __launch_bounds__(256) void mip_pyr_fold_kernel(float* __restrict__ fine_base /* level f */, const float* __restrict__ rest, MipDesc d, int f)
+{
+    __shared__ float buf[2][16 * 16 * C];
+    const int Hf = d.H >> f, Wf = d.W >> f;
+    const int tiles_x = (Wf + 31) / 32;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int top = d.levels - 1;
+    const int K = min(5, top - f);                              // levels f+1 .. f+K live inside the tile
+    // ancestors: levels top .. f+K (one texel each for this tile), folded from the top down by the first C threads
+    if (K == 5 && (int)threadIdx.x < C) {
+        const int c = threadIdx.x;
+        float acc = 0.f;
+        for (int l = top; l >= f + 5; l--) {
+            const int sh = l - f - 5;                           // tile coordinate -> texel of level l (tile = 32 texels of level f = 1 texel of level f+5)
+            const int Y = ty >> sh, X = tx >> sh;
+            const int Wl = d.W >> l;
+            const float g = rest[d.off[l] + ((size_t)Y * Wl + X) * C + c];
+            acc = l == top ? g : __builtin_fmaf(0.25f, acc, g);
+        }
+        buf[0][c] = acc;                                         // folded level f+K, 1 texel (K == 5) -- see below for K < 5
+    }
+    // (K < 5 only for stacks with fewer than six levels above f: then level f+K is the top level and the tile covers all of it)
+    int cur = 0;
+    if (K < 5) {
+        __syncthreads();
+        const int n = 32 >> K, Hl = d.H >> (f + K), Wl = d.W >> (f + K);
+        for (int i = threadIdx.x; i < n * n * C; i += 256) {
+            const int c = i % C, t = i / C, ox = t % n, oy = t / n;
+            const int Y = ty * n + oy, X = tx * n + ox;
+            buf[1][i] = (Y < Hl && X < Wl) ? rest[d.off[f + K] + ((size_t)Y * Wl + X) * C + c] : 0.f;
+        }
+        cur = 1;
+    }
+    for (int k = K - 1; k >= 1; k--) {
+        __syncthreads();
+        const int n = 32 >> k, Hl = d.H >> (f + k), Wl = d.W >> (f + k);
+        for (int i = threadIdx.x; i < n * n * C; i += 256) {
+            const int c = i % C, t = i / C, ox = t % n, oy = t / n;
+            const int Y = ty * n + oy, X = tx * n + ox;
+            float v = 0.f;
+            if (Y < Hl && X < Wl) v = __builtin_fmaf(0.25f, buf[cur][((oy >> 1) * (n >> 1) + (ox >> 1)) * C + c], rest[d.off[f + k] + ((size_t)Y * Wl + X) * C + c]);
+            buf[cur ^ 1][i] = v;
+        }
+        cur ^= 1;
+    }
+    __syncthreads();
+    // level f: 32x32 texels, read-modify-write (when K == 0 there is nothing above f: the launcher does not call us)
+    for (int i = threadIdx.x; i < 32 * 32 * C; i += 256) {
+        const int c = i % C, t = i / C, ox = t & 31, oy = t >> 5;
+        const int Y = ty * 32 + oy, X = tx * 32 + ox;
+        if (Y < Hf && X < Wf) {
+            float* o = fine_base + ((size_t)Y * Wf + X) * C + c;
+            *o = __builtin_fmaf(0.25f, buf[cur][((oy >> 1) * 16 + (ox >> 1)) * C + c], *o);
+        }
+    }
+}
+
 __device__ __forceinline__ float mip_level_from_da(float4 da, int W, int H, int maxl)
 {
     float dsdx = da.x * (float)W, dsdy = da.y * (float)W, dtdx = da.z * (float)H, dtdy = da.w * (float)H;
@@ -364,6 +473,7 @@ __global__ __launch_bounds__(256) void tex_gather_kernel(float* __restrict__ lvl
 {
     for (int s = blockIdx.x * 256 + threadIdx.x; s < n_seg; s += gridDim.x * 256) {
         const long long key = seg_key[s];
+        if (key < n0 && !lvl0) continue;                     // (caller passed no level-0 buffer: it promised that no list samples level 0)
         const int b = seg_start[s], e = b + seg_count[s];
         float acc[C];
         for (int c = 0; c < C; c++) acc[c] = 0.f;
@@ -377,18 +487,41 @@ __global__ __launch_bounds__(256) void tex_gather_kernel(float* __restrict__ lvl
     }
 }
 
-// builds levels 1..levels-1 into `rest` from the caller's level-0 texture
-hipError_t launch_mip_build(const float* tex, float* rest, int H, int W, int C, int levels, hipStream_t st)
+template <int C>
+static void launch_pyr_down_c(const float* src, float* rest, const MipDesc& d, int s_lvl, int n_out, hipStream_t st)
 {
-    if (levels <= 1) return hipSuccess;
+    const int Hs = d.H >> s_lvl, Ws = d.W >> s_lvl;
+    const int blocks = ((Hs + 31) / 32) * ((Ws + 31) / 32);
+    hipLaunchKernelGGL(mip_pyr_down_kernel<C>, dim3(blocks), dim3(256), 0, st, src, rest, d, s_lvl, n_out);
+}
+
+// builds levels from_level+1 .. levels-1 into `rest`; from_level = 0: from the caller's level-0 texture, = 1: level 1 is already
+// in `rest` (the fused optimiser wrote it while it updated the texture, texir_adam_step_tex)
+// TEXIR_MIP_PER_LEVEL=1 keeps the first implementation (one launch per level) alive: the parity tests run both and demand identical bits
+static bool mip_per_level() { const char* e = getenv("TEXIR_MIP_PER_LEVEL"); return e && atoi(e) != 0; }
+
+hipError_t launch_mip_build(const float* tex, float* rest, int H, int W, int C, int levels, int from_level, hipStream_t st)
+{
+    if (levels <= 1 + from_level) return hipSuccess;
     MipDesc d = make_desc(H, W, C, levels);
-    int lt = tail_begin(d);
-    if (lt < 2) lt = 2;                       // level 1 always comes from the separate level-0 pointer
-    for (int l = 1; l < lt && l < levels; l++) {
-        int Hd = H >> l, Wd = W >> l;
-        const float* src = l == 1 ? tex : rest + d.off[l - 1];
-        launch_down(src, rest + d.off[l], Hd, Wd, C, st);
+    if (mip_per_level()) {
+        int lt = tail_begin(d);
+        if (lt < 2) lt = 2;                       // level 1 always comes from the separate level-0 pointer
+        for (int l = 1 + from_level; l < lt && l < levels; l++) {
+            const float* src_l = l == 1 ? tex : rest + d.off[l - 1];
+            launch_down(src_l, rest + d.off[l], H >> l, W >> l, C, st);
+        }
+        if (lt < levels) hipLaunchKernelGGL(mip_down_tail_kernel, dim3(1), dim3(1024), 0, st, rest, d, lt);
+        return hipGetLastError();
     }
+    const int s_lvl = from_level;
+    const int n_out = (levels - 1 - s_lvl) < 5 ? (levels - 1 - s_lvl) : 5;
+    const float* src = s_lvl == 0 ? tex : rest + d.off[s_lvl];
+    if (C == 1) launch_pyr_down_c<1>(src, rest, d, s_lvl, n_out, st);
+    else if (C == 2) launch_pyr_down_c<2>(src, rest, d, s_lvl, n_out, st);
+    else if (C == 3) launch_pyr_down_c<3>(src, rest, d, s_lvl, n_out, st);
+    else launch_pyr_down_c<4>(src, rest, d, s_lvl, n_out, st);
+    const int lt = s_lvl + n_out + 1;
     if (lt < levels) hipLaunchKernelGGL(mip_down_tail_kernel, dim3(1), dim3(1024), 0, st, rest, d, lt);
     return hipGetLastError();
 }
@@ -445,16 +578,28 @@ hipError_t launch_tex_fetch_bwd(float* d_tex, float* grad_rest, int H, int W, in
 
 static void launch_folds(float* d_tex, float* grad_rest, const MipDesc& d, int H, int W, int C, int levels, int fold_to_level, hipStream_t st)
 {
-    int lt = tail_begin(d);
-    if (lt < 2) lt = 2;
-    // small levels: levels-1 .. lt folded down to level lt-1 inside one block
-    if (lt < levels) hipLaunchKernelGGL(mip_fold_tail_kernel, dim3(1), dim3(1024), 0, st, grad_rest, d, lt - 1);
-    // fold_to_level = 1: leave level 1 un-folded (texir_adam_step_tex adds 0.25 * level 1 while it reads the gradient)
-    for (int l = (lt < levels ? lt : levels) - 1; l >= 1 + fold_to_level; l--) {
-        int Hf = H >> (l - 1), Wf = W >> (l - 1);
-        float* fine = l == 1 ? d_tex : grad_rest + d.off[l - 1];
-        launch_fold(fine, grad_rest + d.off[l], Hf, Wf, C, st);
+    // one launch folds the whole stack into level `fold_to_level` (1: level 1 stays un-folded into level 0 -- texir_adam_step_tex adds
+    // 0.25 * level 1 while it reads the gradient)
+    const int f = fold_to_level;
+    if (levels - 1 - f < 1) return;
+    if (mip_per_level()) {
+        int lt = tail_begin(d);
+        if (lt < 2) lt = 2;
+        // small levels: levels-1 .. lt folded down to level lt-1 inside one block
+        if (lt < levels) hipLaunchKernelGGL(mip_fold_tail_kernel, dim3(1), dim3(1024), 0, st, grad_rest, d, lt - 1);
+        for (int l = (lt < levels ? lt : levels) - 1; l >= 1 + fold_to_level; l--) {
+            float* fine_l = l == 1 ? d_tex : grad_rest + d.off[l - 1];
+            launch_fold(fine_l, grad_rest + d.off[l], H >> (l - 1), W >> (l - 1), C, st);
+        }
+        return;
     }
+    float* fine = f == 0 ? d_tex : grad_rest + d.off[f];
+    const int Hf = H >> f, Wf = W >> f;
+    const int blocks = ((Hf + 31) / 32) * ((Wf + 31) / 32);
+    if (C == 1) hipLaunchKernelGGL(mip_pyr_fold_kernel<1>, dim3(blocks), dim3(256), 0, st, fine, grad_rest, d, f);
+    else if (C == 2) hipLaunchKernelGGL(mip_pyr_fold_kernel<2>, dim3(blocks), dim3(256), 0, st, fine, grad_rest, d, f);
+    else if (C == 3) hipLaunchKernelGGL(mip_pyr_fold_kernel<3>, dim3(blocks), dim3(256), 0, st, fine, grad_rest, d, f);
+    else hipLaunchKernelGGL(mip_pyr_fold_kernel<4>, dim3(blocks), dim3(256), 0, st, fine, grad_rest, d, f);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -486,33 +631,54 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 // Adam over a texture [H,W,C] whose gradient is level 0 + 0.25 * (level-1 gradient of the 2x2 block): the last fold of the mip
 // backward happens here, while the gradient is read anyway (saves one read-modify-write of the finest level per step).
-// Same arithmetic as mip_fold_kernel followed by adam_kernel, bit for bit.
+// Same arithmetic as mip_fold_kernel followed by adam_kernel, bit for bit.  One thread per 2x2 block of texels:
+//   * g == nullptr: the level-0 part of the gradient is identically zero (no pixel of the step sampled mip level 0 -- the usual
+//     case for 4k textures seen through 128^2 cube faces), so it is neither zero-filled nor read (fma(0.25, g1, 0) is the same float);
+//   * mip1 != nullptr: the thread also writes the 2x2 average of the UPDATED texels = level 1 of the next forward's mip stack
+//     (same expression as the mip build), which removes the build's pass over the whole level-0 texture.
 template <int C>
 __global__ __launch_bounds__(256) void adam_tex_kernel(float* __restrict__ p, const float* __restrict__ g, const float* __restrict__ g1,
-                                                       float* __restrict__ m, float* __restrict__ v, int H, int W, float beta1, float beta2,
-                                                       float eps, float step_size, float bc2_sqrt, float lo, float hi)
+                                                       float* __restrict__ m, float* __restrict__ v, float* __restrict__ mip1, int H, int W,
+                                                       float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float lo, float hi)
 {
-    const int e = blockIdx.x * 256 + threadIdx.x;           // element inside a row: texel * C + channel
-    if (e >= W * C) return;
-    const int tx = e / C, ch = e - tx * C;
-    for (int y = blockIdx.y; y < H; y += gridDim.y) {
-        const size_t i = (size_t)y * W * C + e;
-        const float gi = __builtin_fmaf(0.25f, g1[((size_t)(y >> 1) * (W >> 1) + (tx >> 1)) * C + ch], g[i]);
-        adam_update(p[i], gi, m[i], v[i], beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+    const int bx = blockIdx.x * 256 + threadIdx.x;          // 2x2 block column
+    const int Wh = W >> 1, Hh = H >> 1;
+    if (bx >= Wh) return;
+    for (int by = blockIdx.y; by < Hh; by += gridDim.y) {
+        float g1c[C], pn[2][2][C];
+#pragma unroll
+        for (int c = 0; c < C; c++) g1c[c] = g1[((size_t)by * Wh + bx) * C + c];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const size_t i0 = ((size_t)(2 * by + r) * W + 2 * bx) * C;
+#pragma unroll
+            for (int e = 0; e < 2 * C; e++) {
+                const size_t i = i0 + e;
+                const float gi = __builtin_fmaf(0.25f, g1c[e % C], g ? g[i] : 0.f);
+                float pi = p[i], mi = m[i], vi = v[i];
+                adam_update(pi, gi, mi, vi, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+                p[i] = pi; m[i] = mi; v[i] = vi;
+                pn[r][e / C][e % C] = pi;
+            }
+        }
+        if (mip1) {
+#pragma unroll
+            for (int c = 0; c < C; c++) mip1[((size_t)by * Wh + bx) * C + c] = 0.25f * (pn[0][0][c] + pn[0][1][c] + pn[1][0][c] + pn[1][1][c]);
+        }
     }
 }
 
-hipError_t launch_adam_tex(float* p, const float* g, const float* g1, float* m, float* v, int H, int W, int C, float lr, float beta1, float beta2,
-                           float eps, int step, float lo, float hi, hipStream_t st)
+hipError_t launch_adam_tex(float* p, const float* g, const float* g1, float* m, float* v, float* mip1, int H, int W, int C, float lr, float beta1,
+                           float beta2, float eps, int step, float lo, float hi, hipStream_t st)
 {
     double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     float step_size = (float)((double)lr / bc1);
     float bc2_sqrt = (float)sqrt(bc2);
-    dim3 grid((W * C + 255) / 256, H > 4096 ? 4096 : H);
-    if (C == 1) hipLaunchKernelGGL(adam_tex_kernel<1>, grid, dim3(256), 0, st, p, g, g1, m, v, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
-    else if (C == 2) hipLaunchKernelGGL(adam_tex_kernel<2>, grid, dim3(256), 0, st, p, g, g1, m, v, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
-    else if (C == 3) hipLaunchKernelGGL(adam_tex_kernel<3>, grid, dim3(256), 0, st, p, g, g1, m, v, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
-    else hipLaunchKernelGGL(adam_tex_kernel<4>, grid, dim3(256), 0, st, p, g, g1, m, v, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+    dim3 grid(((W >> 1) + 255) / 256, (H >> 1) > 4096 ? 4096 : (H >> 1));
+    if (C == 1) hipLaunchKernelGGL(adam_tex_kernel<1>, grid, dim3(256), 0, st, p, g, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+    else if (C == 2) hipLaunchKernelGGL(adam_tex_kernel<2>, grid, dim3(256), 0, st, p, g, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+    else if (C == 3) hipLaunchKernelGGL(adam_tex_kernel<3>, grid, dim3(256), 0, st, p, g, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+    else hipLaunchKernelGGL(adam_tex_kernel<4>, grid, dim3(256), 0, st, p, g, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
     return hipGetLastError();
 }
 

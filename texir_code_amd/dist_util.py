@@ -33,17 +33,19 @@ def reduce_texture_grads(params):
     all (one tiny MAX all-reduce decides, identically on every rank) -- at 4k textures seen through 128^2 cube faces nothing does,
     and the reduction shrinks from 335 MB to 84 MB."""
     import torch.distributed as dist
-    params = [p for p in params if p.grad is not None]
+    params = [p for p in params if p.grad is not None or getattr(p, "_texir_grad_l1", None) is not None]
     if not params or not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         return
     need = torch.tensor([0.0 if (getattr(p, "_texir_grad_l1", None) is not None and not getattr(p, "_texir_l0_touched", True)) else 1.0
-                         for p in params], device=params[0].grad.device)
+                         for p in params], device=params[0].device)
     dist.all_reduce(need, op=dist.ReduceOp.MAX)
     for p, n in zip(params, need.tolist()):
         g1 = getattr(p, "_texir_grad_l1", None)
         if g1 is not None:
             dist.all_reduce(g1)
         if n > 0:
+            if p.grad is None:                 # this rank's pixels touched no level-0 texel (the tensor was never made), another rank's did
+                p.grad = torch.zeros_like(p)
             dist.all_reduce(p.grad)
 
 

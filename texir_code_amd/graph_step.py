@@ -63,8 +63,8 @@ class GraphedMatStep:
             if gc_was:
                 gc.enable()
         self.pool = g.pool()
-        # Each graph writes its gradients into its OWN pool buffers (the first capture of an empty pool lays them out differently from
-        # the later ones), so the tensors autograd assigned during this capture are remembered per graph and re-attached to the
+        # The gradient stacks live in per-parameter buffers shared by all graphs (texture.py backward); whatever else autograd assigned
+        # during this capture (a level-0 gradient, when the view samples level 0) is remembered per graph and re-attached to the
         # parameters before every optimiser step.
         self.grads[(key, stage)] = [(p.grad, getattr(p, "_texir_grad_l1", None), getattr(p, "_texir_l0_touched", True)) for p in self.params]
         self.graphs[(key, stage)] = g
@@ -77,15 +77,36 @@ class GraphedMatStep:
         P = self.static_shift.shape[0]
         return torch.rand(P, 1, 2).reshape(P, 2)
 
+    def _stage_shift(self, shift):
+        """host -> device copy of the step's shifts through a ring of pinned buffers.  The copy is asynchronous, so a staging buffer
+        may only be rewritten once ITS previous copy has run: each slot carries an event recorded right after its copy, and a slot is
+        reused only after that event (callers may queue several steps without a host sync in between)."""
+        if getattr(self, "_ring", None) is None:
+            self._ring = [(torch.empty(tuple(self.static_shift.shape), dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(3)]
+            self._ring_used = [False] * 3
+            self._ring_next = 0
+        i = self._ring_next
+        buf, ev = self._ring[i]
+        if self._ring_used[i]:
+            ev.synchronize()
+        buf.copy_(shift)
+        self.static_shift.copy_(buf, non_blocking=True)
+        ev.record()
+        self._ring_used[i] = True
+        self._ring_next = (i + 1) % len(self._ring)
+
     def step(self, key, stage, reduce_grads=None, shift=None):
         """one optimiser step on a captured view; returns the (static) loss tensor of that graph"""
         if stage != 0:                                  # stage 0 is Lambertian only: the reference draws no shifts there
             if shift is None:
                 shift = self.draw_shift()
-            if getattr(self, "_pinned", None) is None:
-                self._pinned = torch.empty(tuple(self.static_shift.shape), dtype=torch.float32).pin_memory()
-            self._pinned.copy_(shift)
-            self.static_shift.copy_(self._pinned, non_blocking=True)
+            self._stage_shift(shift)
+        # the captured forward may build only mip levels 2.. (level 1 comes from the previous optimiser step, optim.FusedAdam): if the
+        # texture was changed any other way since, rebuild the stack eagerly before replaying
+        from .texture import refresh_mips
+        for p in self.params:
+            if getattr(p, "_texir_mips", None) is not None and getattr(p, "_texir_mip1_version", None) != (p.data_ptr(), p._version):
+                refresh_mips(p)
         self.graphs[(key, stage)].replay()
         for p, (g, g1, l0) in zip(self.params, self.grads[(key, stage)]):
             p.grad = g

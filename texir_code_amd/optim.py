@@ -51,7 +51,8 @@ class FusedAdam(torch.optim.Optimizer):
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
-                if p.grad is None:
+                g1 = getattr(p, "_texir_grad_l1", None)
+                if p.grad is None and g1 is None:
                     continue
                 if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                     raise _lib.TexirError("FusedAdam needs contiguous float32 CUDA parameters")
@@ -62,16 +63,20 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p)
                 st["step"] += 1
                 lo, hi = self._clamps.get(id(p), (-math.inf, math.inf))
-                g = p.grad.contiguous()
-                g1 = getattr(p, "_texir_grad_l1", None)
+                g = None if p.grad is None else p.grad.contiguous()      # None: level-0 gradient identically zero (texture.py backward)
                 if g1 is not None:
                     H, W, C = p.shape
+                    # level 1 of the next forward's mip stack is written on the way (texture._mips_for then builds levels 2.. only)
+                    mips = getattr(p, "_texir_mips", None)
+                    mip1 = mips[1] if (mips is not None and mips[1].numel() >= (H // 2) * (W // 2) * C and mips[1].device == p.device) else None
                     _lib.check(L.texir_adam_step_tex(_lib.ptr(p), _lib.ptr(g), _lib.ptr(g1), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]),
-                                                     H, W, C, float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]),
-                                                     lo, hi, _lib.stream_ptr()))
+                                                     _lib.ptr(mip1), H, W, C, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                     int(st["step"]), lo, hi, _lib.stream_ptr()))
+                    p._texir_mip1_version = (p.data_ptr(), p._version) if mip1 is not None else None
                     if not getattr(p, "_texir_l1_static", False):      # (hipGraph replay re-fills the same buffer: keep it)
                         p._texir_grad_l1 = None
                 else:
+                    p._texir_mip1_version = None                       # the texture changes behind the mip stack's back
                     _lib.check(L.texir_adam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]), p.numel(),
                                                  float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]), lo, hi,
                                                  _lib.stream_ptr()))

@@ -75,6 +75,12 @@ class Scene:
         keys = ["inner_nodes", "triangles", "max_depth", "node_bytes", "tri_bytes", "uv_bytes", "tex_bytes", "device"]
         return dict(zip(keys, (int(x) for x in out)))
 
+    def irt_kernel_name(self, n_ids, n_samples):
+        """the kernel form one irt_generate call over n_ids listed texels launches (the launcher's own decision)"""
+        buf = C.create_string_buffer(96)
+        _lib.check(_lib.lib().texir_irt_kernel_name(self.h, int(n_ids), int(n_samples), buf, 96))
+        return buf.value.decode()
+
     def set_texture(self, tex):
         """tex [Ht,Wt,3] tensor (device or host) -- stage -1's temporary light-source-only texture (mat_nvdiffrast.py:141-150)"""
         if torch.is_tensor(tex) and tex.is_cuda:

@@ -66,6 +66,64 @@ def _room_and_boxes(rng, n_boxes):
     return P
 
 
+def _rot(rng):
+    """uniformly random rotation matrix (random unit quaternion)"""
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _box_faces(c, R, half, cls):
+    """six outward-facing parallelogram patches of the box centre c, axes R[:,k], half extents half[k]"""
+    P = []
+    for ax in range(3):
+        a1, a2 = (ax + 1) % 3, (ax + 2) % 3
+        for sgn in (+1.0, -1.0):
+            n = sgn * R[:, ax]
+            eu, ev = 2 * half[a1] * R[:, a1], 2 * half[a2] * R[:, a2]
+            if sgn < 0:
+                eu, ev = ev, eu                       # keeps eu x ev = outward normal
+            o = c + half[ax] * n - 0.5 * eu - 0.5 * ev
+            P.append(Patch(o, eu, ev, cls))
+    return P
+
+
+def _scan_clutter(rng):
+    """`scan` style (bench workload c4_scan): the same 8 x 3 x 6 m shell, but with two openings (a window and a door: rays escape,
+    p_hit < 1), ~150 randomly ROTATED boxes anywhere in the volume (nothing axis-aligned, some floating like shelves), a
+    venetian blind of thin slats in front of the window, and strongly displaced, jittered surfaces -- what a scanned real-world
+    indoor mesh does to a BVH (README.md:21-34 describes the reference's data as captured scenes)."""
+    X, Y, Z = ROOM
+    P = []
+    P.append(Patch((0, 0, 0), (0, 0, Z), (X, 0, 0), 46))          # floor
+    P.append(Patch((0, Y, 0), (X, 0, 0), (0, 0, Z), 44))          # ceiling
+    # z=0 wall (n=+z) with a window x in [2.5,5.5], y in [0.9,2.2]: four patches around the hole
+    P.append(Patch((0, 0, 0), (2.5, 0, 0), (0, Y, 0), 45))
+    P.append(Patch((5.5, 0, 0), (X - 5.5, 0, 0), (0, Y, 0), 45))
+    P.append(Patch((2.5, 0, 0), (3.0, 0, 0), (0, 0.9, 0), 45))
+    P.append(Patch((2.5, 2.2, 0), (3.0, 0, 0), (0, Y - 2.2, 0), 45))
+    P.append(Patch((0, 0, Z), (0, Y, 0), (X, 0, 0), 45))          # z=Z wall
+    P.append(Patch((0, 0, 0), (0, Y, 0), (0, 0, Z), 45))          # x=0 wall
+    # x=X wall (n=-x) with a door z in [2.0,3.0], y in [0,2.1]
+    P.append(Patch((X, 0, 0), (0, 0, 2.0), (0, Y, 0), 45))
+    P.append(Patch((X, 0, 3.0), (0, 0, Z - 3.0), (0, Y, 0), 45))
+    P.append(Patch((X, 2.1, 2.0), (0, 0, 1.0), (0, Y - 2.1, 0), 45))
+    for _ in range(150):
+        half = rng.uniform(0.05, 0.45, 3) * rng.uniform(0.3, 1.0)
+        c = np.array([rng.uniform(0.5, X - 0.5), rng.uniform(0.1, Y - 0.3), rng.uniform(0.5, Z - 0.5)])
+        P += _box_faces(c, _rot(rng), half, int(rng.integers(0, 43)))
+    # blind: 40 slats 3 m x 3 cm x 2 mm, tilted ~35 degrees about x, 8 cm in front of the window
+    tilt = np.deg2rad(35.0)
+    Rs = np.array([[1, 0, 0], [0, np.cos(tilt), -np.sin(tilt)], [0, np.sin(tilt), np.cos(tilt)]], np.float64)
+    for k in range(40):
+        c = np.array([4.0, 0.92 + k * (1.26 / 40), 0.08])
+        P += _box_faces(c, Rs, np.array([1.5, 0.015, 0.001]), 42)
+    return P
+
+
 def _allocate_grids(P, T):
     """choose (gu, gv) per patch, quads ~ area, 2*sum(gu*gv) <= T (remainder fixed by edge splits)."""
     if T <= 2 * len(P):
@@ -137,13 +195,33 @@ def _patch_heights(p, rng_phase, gu, gv):
     return p.amp * f * win
 
 
-def make_scene(T, seed=666, tex_res=1024, n_boxes=40, amp=3e-3):
+def _scan_heights(p, rng, gu, gv):
+    """scan style: three octaves of smooth noise (wavelengths 60 / 15 / 4 cm) plus per-vertex white jitter (sensor noise), zero on
+    the patch border"""
+    a = np.linspace(0.0, 1.0, gu + 1)[:, None]
+    b = np.linspace(0.0, 1.0, gv + 1)[None, :]
+    f = np.zeros((gu + 1, gv + 1))
+    for wl, wgt in ((0.6, 1.0), (0.15, 0.45), (0.04, 0.2)):
+        f = f + wgt * (2.0 * _smooth_noise(rng, gu + 1, gv + 1, max(1.0, wl / max(p.lu / max(gu, 1), 1e-9))) - 1.0)
+    f = f + 0.08 * rng.normal(size=f.shape)
+    win = np.minimum(1.0, 8.0 * np.minimum(np.minimum(a, 1 - a), np.minimum(b, 1 - b)) * np.ones_like(f))
+    return p.amp * f * win
+
+
+def make_scene(T, seed=666, tex_res=1024, n_boxes=40, amp=3e-3, style="room"):
     """returns dict: verts [V,3] f32, tris [T,3] i32, tri_uvs [3T,2] f32, hdr [tex_res,tex_res,3] f32,
-    patches (list of Patch), plus per-chart GT material colours."""
+    patches (list of Patch), plus per-chart GT material colours.  style = "room" (axis-aligned room + boxes)
+    or "scan" (_scan_clutter: rotated clutter, thin slats, openings, noisy surfaces; T >= 20000)."""
     rng = np.random.default_rng(seed)
     if T < 12 or T % 2:
         raise ValueError("T must be even and >= 12")
-    P = _room_and_boxes(rng, 0 if T < 12 + 40 * 10 else n_boxes)
+    if style == "scan":
+        if T < 4000:
+            raise ValueError("scan style needs T >= 4000")
+        P = _scan_clutter(rng)
+        amp = 1.2e-2
+    else:
+        P = _room_and_boxes(rng, 0 if T < 12 + 40 * 10 else n_boxes)
     _allocate_grids(P, T)
     _pack(P)
     verts, tris, tuvs, tcls = [], [], [], []
@@ -155,7 +233,7 @@ def make_scene(T, seed=666, tex_res=1024, n_boxes=40, amp=3e-3):
         gu, gv = p.gu, p.gv
         a = np.linspace(0.0, 1.0, gu + 1)
         b = np.linspace(0.0, 1.0, gv + 1)
-        hgt = _patch_heights(p, p.phase, gu, gv)
+        hgt = _scan_heights(p, rng, gu, gv) if style == "scan" else _patch_heights(p, p.phase, gu, gv)
         pos = (p.o[None, None, :] + a[:, None, None] * p.eu[None, None, :] + b[None, :, None] * p.ev[None, None, :]
                + hgt[:, :, None] * p.n[None, None, :])
         verts.append(pos.reshape(-1, 3))
@@ -200,7 +278,7 @@ def make_scene(T, seed=666, tex_res=1024, n_boxes=40, amp=3e-3):
     assert tris.shape[0] == T
     sc = {
         "verts": verts.astype(np.float32), "tris": tris.astype(np.int32),
-        "tri_uvs": tuvs.reshape(-1, 2).astype(np.float32), "patches": P, "seed": seed, "T": T, "tri_class": tcls,
+        "tri_uvs": tuvs.reshape(-1, 2).astype(np.float32), "patches": P, "seed": seed, "T": T, "tri_class": tcls, "style": style,
     }
     sc["hdr"] = make_hdr_texture(sc, tex_res, seed)
     return sc
@@ -248,6 +326,8 @@ def make_hdr_texture(sc, res, seed=666):
     # emissive rectangles: 4 ceiling lamps + 2 wall windows
     lamps = [(1, 0.15, 0.2, 0.1, 0.15), (1, 0.55, 0.2, 0.1, 0.15), (1, 0.15, 0.65, 0.1, 0.15), (1, 0.55, 0.65, 0.1, 0.15),
              (2, 0.3, 0.45, 0.25, 0.35), (5, 0.35, 0.4, 0.3, 0.4)]
+    if sc.get("style") == "scan":          # patch 1 is the ceiling in both styles; the wall lights sit on the z=Z and x=0 walls
+        lamps = lamps[:4] + [(6, 0.3, 0.45, 0.25, 0.35), (7, 0.35, 0.4, 0.3, 0.4)]
     for (pi, a0, b0, da, db) in lamps:
         p = P[pi]
         x, y, w, h = p.rect

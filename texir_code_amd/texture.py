@@ -31,12 +31,29 @@ def _mips_for(owner, t0, levels):
         if torch.cuda.is_current_stream_capturing():
             raise _lib.TexirError("mip stack must be allocated before hipGraph capture (run one eager step first)")
         rest = torch.empty(n, device=t0.device, dtype=torch.float32)
-    _lib.check(L.texir_mip_build(_lib.ptr(t0), _lib.ptr(rest), H, W, C, levels, _lib.stream_ptr()))
+    # FusedAdam(fuse_mip_fold=True) writes level 1 (the 2x2 average of the texels it has just updated) into this very buffer and stamps
+    # the tensor version it did that at: then only levels 2.. are rebuilt, and the pass over the whole level-0 texture disappears.  Any
+    # other in-place change of the texture (clamp_, copy_, ...) bumps the version and gets the full build.
+    fresh1 = (hit is not None and hit[1] is rest and getattr(owner, "_texir_mip1_version", None) == (t0.data_ptr(), t0._version) and levels > 2)
+    _lib.check(L.texir_mip_build(_lib.ptr(t0), _lib.ptr(rest), H, W, C, levels, 1 if fresh1 else 0, _lib.stream_ptr()))
     try:
         owner._texir_mips = (key, rest)
+        owner._texir_mip1_version = (t0.data_ptr(), t0._version)
     except AttributeError:
         pass
     return rest
+
+
+def refresh_mips(param):
+    """full rebuild of a trainable texture's cached mip stack (hipGraph replays call this when the texture was changed behind the
+    optimiser's back, see graph_step.GraphedMatStep.step)"""
+    hit = getattr(param, "_texir_mips", None)
+    if hit is None:
+        return
+    H, W, C = param.shape
+    levels = hit[0][5]
+    _lib.check(_lib.lib().texir_mip_build(_lib.ptr(param.detach()), _lib.ptr(hit[1]), H, W, C, levels, 0, _lib.stream_ptr()))
+    param._texir_mip1_version = (param.data_ptr(), param._version)
 
 
 # Tap lists cost ~28 bytes per tap (8 taps per pixel and texture configuration); beyond this many bytes in total, further views fall
@@ -100,8 +117,6 @@ class _TexFetch(torch.autograd.Function):
         if not ctx.needs_input_grad[0]:
             return None, None, None, None, None, None, None, None
         L = _lib.lib()
-        d_tex = torch.zeros((H, W, C), device=d_out.device, dtype=torch.float32)
-        g_rest = torch.zeros(int(L.texir_mip_elems(H, W, C, levels)), device=d_out.device, dtype=torch.float32) if levels > 1 else None
         d_out = d_out.contiguous()
         owner = ctx.owner
         # FusedAdam(fuse_mip_fold=True) asks for the last fold (level 1 -> level 0, a read-modify-write of the whole texture) to be
@@ -109,6 +124,39 @@ class _TexFetch(torch.autograd.Function):
         # parameter per backward pass defers; a further one folds completely and autograd adds its d_tex as usual.
         defer = (mode == 1 and levels > 1 and owner is not None and getattr(owner, "_texir_defer_fold", False)
                  and getattr(owner, "_texir_grad_l1", None) is None)
+        n_rest = int(L.texir_mip_elems(H, W, C, levels))
+        g_rest = None
+        if levels > 1:
+            if defer:
+                # the gradient stack of a deferring parameter lives in ONE buffer owned by the parameter, reused by every step and shared
+                # by all captured hipGraphs (they run one after the other on one stream): nothing is allocated per step or per graph
+                g_rest = getattr(owner, "_texir_grest", None)
+                if g_rest is None or g_rest.numel() != n_rest or g_rest.device != d_out.device:
+                    if torch.cuda.is_current_stream_capturing():
+                        raise _lib.TexirError("gradient stack must be allocated before hipGraph capture (run one eager step first)")
+                    g_rest = torch.empty(n_rest, device=d_out.device, dtype=torch.float32)
+                    owner._texir_grest = g_rest
+                g_rest.zero_()
+            else:
+                g_rest = torch.zeros(n_rest, device=d_out.device, dtype=torch.float32)
+        # a deferred fetch over cached tap lists none of which samples level 0 has an identically zero level-0 gradient: it is not
+        # materialised at all (no 4 * H * W * C byte fill, and the optimiser does not read it) -- autograd gets None for the texture
+        skip_l0 = bool(defer and ctx.taps is not None and not ctx.taps[5])
+        own_l0 = bool(defer and not skip_l0 and owner.grad is None)
+        if skip_l0:
+            d_tex = None
+        elif own_l0:
+            # level 0 is sampled: its gradient also goes to a buffer owned by the parameter (shared by all steps and graphs) and is
+            # attached as .grad directly -- handing a buffer somebody else references to autograd would make it clone 4*H*W*C bytes
+            d_tex = getattr(owner, "_texir_g0", None)
+            if d_tex is None or d_tex.shape != (H, W, C) or d_tex.device != d_out.device:
+                if torch.cuda.is_current_stream_capturing():
+                    raise _lib.TexirError("gradient buffer must be allocated before hipGraph capture (run one eager step first)")
+                d_tex = torch.empty((H, W, C), device=d_out.device, dtype=torch.float32)
+                owner._texir_g0 = d_tex
+            d_tex.zero_()
+        else:
+            d_tex = torch.zeros((H, W, C), device=d_out.device, dtype=torch.float32)
         if ctx.taps is not None:
             # fixed fetch coordinates (a cached view): deterministic gather over the pre-sorted tap lists instead of float atomics
             seg_key, starts, counts, pix, wts, _ = ctx.taps
@@ -129,6 +177,10 @@ class _TexFetch(torch.autograd.Function):
             # writes it.  Sticky over the fetches of one backward pass; FusedAdam.zero_grad resets it.
             wrote_l0 = (ctx.taps[5] if ctx.taps is not None else True) if defer else True
             owner._texir_l0_touched = bool(getattr(owner, "_texir_l0_touched", False)) or wrote_l0
+        if own_l0:
+            if owner.grad is None:
+                owner.grad = d_tex
+                return None, None, None, None, None, None, None, None
         return d_tex, None, None, None, None, None, None, None
 
 

@@ -1,0 +1,297 @@
+// Design-exploration tool (not product, not oracle): replays the IrT kernel's wave-level schedule on the CPU --
+// 64 neighbouring texels per wave, one absolute direction cell per pass, lock-step while-while traversal of the product's
+// own 4-wide quantised BVH (texir_code_amd/csrc/bvh_build.cpp is linked in) -- and counts what the GPU's issue-bound inner
+// loops execute: per-lane node visits / triangle tests and WAVE-level node steps / triangle steps.  Variants of the
+// traversal (pop culling with a stored entry distance, leaf sizes via TEXIR_MAX_LEAF, ...) can be compared here for free
+// before they cost GPU minutes.
+//
+//   g++ -O2 -fopenmp -std=c++17 -I texir_code_amd/csrc tools/bvh_sim.cpp texir_code_amd/csrc/bvh_build.cpp -o /tmp/bvh_sim -lpthread
+//   python tools/bvh_sim_dump.py c4 /tmp/sim_c4 && /tmp/bvh_sim /tmp/sim_c4 [groups] [passes]
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bvh_build.h"
+
+using namespace texir;
+
+template <typename T>
+static std::vector<T> load(const std::string& p)
+{
+    FILE* f = fopen(p.c_str(), "rb");
+    if (!f) { fprintf(stderr, "cannot open %s\n", p.c_str()); exit(1); }
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<T> v((size_t)n / sizeof(T));
+    if (fread(v.data(), 1, (size_t)n, f) != (size_t)n) exit(1);
+    fclose(f);
+    return v;
+}
+
+static inline uint32_t brev(uint32_t x)
+{
+    x = (x >> 16) | (x << 16); x = ((x & 0xff00ff00u) >> 8) | ((x & 0x00ff00ffu) << 8);
+    x = ((x & 0xf0f0f0f0u) >> 4) | ((x & 0x0f0f0f0fu) << 4); x = ((x & 0xccccccccu) >> 2) | ((x & 0x33333333u) << 2);
+    x = ((x & 0xaaaaaaaau) >> 1) | ((x & 0x55555555u) << 1); return x;
+}
+static float swc(float s, float sh) { s += sh; if (s > 1.f) s -= 1.f; if (s < 0.f) s += 1.f; return fminf(fmaxf(s, 1e-6f), (float)(1.0 - 1e-6)); }
+
+struct Frame { float n[3], U[3], V[3]; };
+static Frame make_frame(float nx, float ny, float nz)
+{
+    Frame f; float ax = 1.f, ay = 0.f; if (fabsf(nx) > 0.99f) { ax = 0.f; ay = 1.f; }
+    float ln = sqrtf(nx * nx + ny * ny + nz * nz) + 1e-6f; f.n[0] = nx / ln; f.n[1] = ny / ln; f.n[2] = nz / ln;
+    float c0 = ay * f.n[2], c1 = -ax * f.n[2], c2 = ax * f.n[1] - ay * f.n[0];
+    float lc = sqrtf(c0 * c0 + c1 * c1 + c2 * c2) + 1e-6f; f.U[0] = c0 / lc; f.U[1] = c1 / lc; f.U[2] = c2 / lc;
+    float e0 = f.n[1] * f.U[2] - f.n[2] * f.U[1], e1 = f.n[2] * f.U[0] - f.n[0] * f.U[2], e2 = f.n[0] * f.U[1] - f.n[1] * f.U[0];
+    float le = sqrtf(e0 * e0 + e1 * e1 + e2 * e2) + 1e-6f; f.V[0] = e0 / le; f.V[1] = e1 / le; f.V[2] = e2 / le; return f;
+}
+static uint32_t cell_to_pass(uint32_t J, float sh0, float sh1, int log2N)
+{
+    int cells = log2N, bphi = (cells + 1) >> 1, bth = cells - bphi;
+    uint32_t nphi = 1u << bphi, nth = 1u << bth, Jphi = J & (nphi - 1u), Jth = J >> bphi;
+    uint32_t dphi = (uint32_t)(sh1 * (float)nphi + 0.5f), dth = (uint32_t)(sh0 * (float)nth + 0.5f);
+    uint32_t phibin = (Jphi + nphi - (dphi & (nphi - 1u))) & (nphi - 1u), th = (Jth + nth - (dth & (nth - 1u))) & (nth - 1u);
+    uint32_t low = bphi ? (brev(phibin) >> (32 - bphi)) : 0u;
+    return (th << bphi) | low;
+}
+static uint32_t sample_index(uint32_t cell, int log2N)
+{
+    int cells = log2N, bphi = (cells + 1) >> 1, bth = cells - bphi;
+    uint32_t low = cell & ((1u << bphi) - 1u), th = bth ? (cell >> bphi) : 0u;
+    return (th << (log2N - bth)) | low;
+}
+
+struct Ray { float o[3], d[3], id[3], ood[3]; float t; int slot; int node; std::vector<int> stk; std::vector<float> stk_t; };
+
+struct Counters { double rays = 0, nodes = 0, tris = 0, wnode = 0, wtri = 0, culled = 0, hits = 0, wcull = 0, maxsp = 0, wuni = 0, wdeep[4] = {0, 0, 0, 0}, lines = 0; };
+
+static const int kSent = 0x7FFFFFFF;
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: bvh_sim <dir> [groups=64] [passes=64] [variant flags: cull cull8 nosort]\n"); return 1; }
+    std::string dir = argv[1];
+    int n_groups = argc > 2 ? atoi(argv[2]) : 64, n_pass = argc > 3 ? atoi(argv[3]) : 64;
+    bool cull = false, cull8 = false, nosort = false;
+    for (int i = 4; i < argc; i++) { if (!strcmp(argv[i], "cull")) cull = true; if (!strcmp(argv[i], "cull8")) cull = cull8 = true; if (!strcmp(argv[i], "nosort")) nosort = true; }
+    auto verts = load<float>(dir + "/verts.f32"); auto tris = load<int32_t>(dir + "/tris.i32"); auto uvs = load<float>(dir + "/tri_uvs.f32");
+    auto pos = load<float>(dir + "/pos.f32"); auto nrm = load<float>(dir + "/nrm.f32"); auto shift = load<float>(dir + "/shift.f32");
+    auto ids = load<int32_t>(dir + "/ids.i32"); auto meta = load<int32_t>(dir + "/meta.i32");
+    const int N = meta[0]; int log2N = 0; while ((1 << log2N) < N) log2N++;
+    const int T = (int)tris.size() / 3, V = (int)verts.size() / 3;
+    BvhHost h; build_bvh(verts.data(), V, tris.data(), T, uvs.data(), h);
+    printf("T=%d nodes4=%zu depth4=%d N=%d groups=%d passes=%d cull=%d cull8=%d\n", T, h.nodes4.size(), h.max_depth4, N, n_groups, n_pass, cull, cull8);
+    // 8-bit entry distance (conservative lower bound): minifloat with 5 exponent + 3 mantissa bits below an exponent ceiling taken from the scene
+    float diag = 0.f; { float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f}; for (int i = 0; i < V; i++) for (int a = 0; a < 3; a++) { mn[a] = fminf(mn[a], verts[3 * i + a]); mx[a] = fmaxf(mx[a], verts[3 * i + a]); } for (int a = 0; a < 3; a++) diag += (mx[a] - mn[a]) * (mx[a] - mn[a]); diag = sqrtf(diag); }
+    int emax; frexpf(diag, &emax);            // diag < 2^emax
+    auto q8 = [&](float t) -> float {         // round DOWN to the minifloat grid
+        if (!(t > 0.f)) return 0.f;
+        uint32_t b; memcpy(&b, &t, 4);
+        int e = (int)(b >> 23) - 127;         // t in [2^e, 2^(e+1))
+        int elo = emax - 31;
+        if (e < elo) return 0.f;
+        if (e >= emax) return ldexpf(1.f, emax);
+        b &= 0xFFF00000u;                     // keep 3 mantissa bits
+        float r; memcpy(&r, &b, 4); return r;
+    };
+    if (argc > 2 && !strcmp(argv[2], "rays")) {
+        // watertightness study: trace org.f32/dir.f32 one ray at a time with the kernel's float arithmetic (fmaf where hipcc contracts),
+        // count rays that find no hit.  variants (argv[3..]): pad = far plane distances x (1 + 2^-21); sub = node origin minus ray origin first;
+        // inflate = quantised child boxes grown by one cell (done here at decode time)
+        bool pad = false, sub = false, inflate = false, mt = false;
+        for (int i = 3; i < argc; i++) { pad |= !strcmp(argv[i], "pad"); sub |= !strcmp(argv[i], "sub"); inflate |= !strcmp(argv[i], "inflate"); mt |= !strcmp(argv[i], "mt"); }
+        auto org = load<float>(dir + "/org.f32"); auto dd = load<float>(dir + "/dir.f32");
+        const int64_t R = (int64_t)org.size() / 3;
+        int64_t miss = 0, boxmiss = 0; double nodes = 0;
+#pragma omp parallel for reduction(+ : miss, nodes) schedule(dynamic, 4096)
+        for (int64_t r = 0; r < R; r++) {
+            float o[3] = {org[3 * r], org[3 * r + 1], org[3 * r + 2]}, d[3] = {dd[3 * r], dd[3 * r + 1], dd[3 * r + 2]}, id[3], ood[3];
+            for (int a = 0; a < 3; a++) { float x = fabsf(d[a]) > 8.271806e-25f ? d[a] : copysignf(8.271806e-25f, d[a]); id[a] = 1.f / x; ood[a] = o[a] * id[a]; }
+            float ht = INFINITY; int slot = -1;
+            std::vector<int> stk; int node = 0;
+            float wmx[3] = {0, 0, 0}, wmy[3] = {0, 0, 0}, wmz[3] = {0, 0, 0};
+            {
+                int kz = 0; if (fabsf(d[1]) > fabsf(d[kz])) kz = 1; if (fabsf(d[2]) > fabsf(d[kz])) kz = 2;
+                int kx = (kz + 1) % 3, ky = (kx + 1) % 3; if (d[kz] < 0.f) std::swap(kx, ky);
+                float Sz = 1.f / d[kz], Sx = d[kx] * Sz, Sy = d[ky] * Sz;
+                wmx[kx] = 1.f; wmx[kz] = -Sx; wmy[ky] = 1.f; wmy[kz] = -Sy; wmz[kz] = Sz;
+            }
+            while (node != kSent) {
+                if (node >= 0) {
+                    nodes++;
+                    const GpuNode4& n = h.nodes4[node];
+                    const float cell[3] = {n.cell_x, n.cell_y, n.cell_z};
+                    const uint32_t lo[3] = {n.lox, n.loy, n.loz}, hi[3] = {n.hix, n.hiy, n.hiz};
+                    float key[4]; int code[4];
+                    for (int k = 0; k < 4; k++) {
+                        float tn = 0.f, tf = ht;
+                        for (int a = 0; a < 3; a++) {
+                            float sc = cell[a] * id[a];
+                            float b = sub ? (n.origin[a] - o[a]) * id[a] : fmaf(n.origin[a], id[a], -ood[a]);
+                            uint32_t nq = id[a] < 0.f ? hi[a] : lo[a], fq = id[a] < 0.f ? lo[a] : hi[a];
+                            int nb = (int)((nq >> (8 * k)) & 255u), fb = (int)((fq >> (8 * k)) & 255u);
+                            if (inflate && !(((lo[a] >> (8 * k)) & 255u) > ((hi[a] >> (8 * k)) & 255u))) { if (id[a] < 0.f) { nb += 1; fb -= 1; } else { nb -= 1; fb += 1; } }
+                            float tnn = fmaf((float)nb, sc, b), tff = fmaf((float)fb, sc, b);
+                            if (pad) tff *= 1.0000005f;
+                            tn = fmaxf(tn, tnn); tf = fminf(tf, tff);
+                        }
+                        key[k] = tn <= tf ? tn : INFINITY; code[k] = n.c[k];
+                    }
+                    for (int k = 0; k < 4; k++) if (key[k] < INFINITY) stk.push_back(code[k]);
+                } else {
+                    uint32_t code = ~(uint32_t)node; int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
+                    for (int i = first; i < first + cnt; i++) {
+                        const GpuTri& tr = h.tris[i];
+#if TEXIR_TRI_WATERTIGHT
+                        // Woop/Benthin/Wald: shear to ray space (per-ray vectors mx, my, mz), exact-sign 2D edge functions
+                        float P[3][3];
+                        const float* vv[3] = {tr.v0, tr.e1, tr.e2};
+                        for (int k = 0; k < 3; k++) {
+                            float A0 = vv[k][0] - o[0], A1 = vv[k][1] - o[1], A2 = vv[k][2] - o[2];
+                            P[k][0] = fmaf(A2, wmx[2], fmaf(A1, wmx[1], A0 * wmx[0]));
+                            P[k][1] = fmaf(A2, wmy[2], fmaf(A1, wmy[1], A0 * wmy[0]));
+                            P[k][2] = fmaf(A2, wmz[2], fmaf(A1, wmz[1], A0 * wmz[0]));
+                        }
+                        auto edge2 = [&](const float* b_, const float* c_) {        // Cx*By - Cy*Bx with an exact sign
+                            float p_ = c_[0] * b_[1], q_ = c_[1] * b_[0], r_ = p_ - q_;
+                            if (r_ == 0.f) r_ = fmaf(c_[0], b_[1], -p_) - fmaf(c_[1], b_[0], -q_);
+                            return r_; };
+                        auto edge2f = [&](const float* b_, const float* c_) { return c_[0] * b_[1] - c_[1] * b_[0]; };
+                        float U = edge2(P[1], P[2]), V = edge2(P[2], P[0]), W = edge2(P[0], P[1]);
+                        float Uf = edge2f(P[1], P[2]), Vf = edge2f(P[2], P[0]), Wf = edge2f(P[0], P[1]);
+                        float mn = fminf(fminf(U, V), W), mx = fmaxf(fmaxf(U, V), W);
+                        float det = Uf + Vf + Wf;
+                        float T_ = Uf * P[0][2] + Vf * P[1][2] + Wf * P[2][2], t = T_ / det;
+                        bool ok = !(mn < 0.f && mx > 0.f) && det != 0.f && t > 0.f && t < ht;
+                        if (ok) { ht = t; slot = i; }
+#endif
+                    }
+                }
+                if (stk.empty()) node = kSent; else { node = stk.back(); stk.pop_back(); }
+            }
+            if (slot < 0) miss++;
+        }
+        printf("rays %lld: %lld escaped (pad=%d sub=%d inflate=%d), %.1f node visits per ray (unordered, no early-out)\n", (long long)R, (long long)miss, pad, sub, inflate, nodes / R);
+        (void)boxmiss; (void)mt;
+        return 0;
+    }
+    Counters tot;
+    const int64_t n_ids = (int64_t)ids.size();
+    const int64_t n_grp_total = n_ids / 64;
+#pragma omp parallel
+    {
+        Counters c;
+        std::vector<Ray> R(64);
+#pragma omp for schedule(dynamic, 1)
+        for (int gi = 0; gi < n_groups; gi++) {
+            const int64_t g = (int64_t)((double)gi / n_groups * n_grp_total);
+            Frame fr[64];
+            for (int l = 0; l < 64; l++) { int t = ids[g * 64 + l]; fr[l] = make_frame(nrm[3 * t], nrm[3 * t + 1], nrm[3 * t + 2]); }
+            for (int pj = 0; pj < n_pass; pj++) {
+                const uint32_t J = (uint32_t)((double)pj / n_pass * N);
+                for (int l = 0; l < 64; l++) {
+                    int t = ids[g * 64 + l];
+                    float sh0 = shift[2 * t], sh1 = shift[2 * t + 1];
+                    uint32_t i = sample_index(cell_to_pass(J, sh0, sh1, log2N), log2N);
+                    float s0 = swc((float)i / (float)N, sh0), s1 = swc((float)((double)brev(i) * 2.3283064365386963e-10), sh1);
+                    float phi = 6.283185307179586f * s1 - 3.141592653589793f, ct = 1.f - s0, st = sqrtf(1.f - ct * ct);
+                    float sp = sinf(phi) * st, cp = -(cosf(phi) * st);
+                    Ray& r = R[l];
+                    for (int a = 0; a < 3; a++) { r.o[a] = pos[3 * t + a]; r.d[a] = fr[l].V[a] * sp + fr[l].n[a] * ct + fr[l].U[a] * cp; }
+                    for (int a = 0; a < 3; a++) { float d = fabsf(r.d[a]) > 8.271806e-25f ? r.d[a] : copysignf(8.271806e-25f, r.d[a]); r.id[a] = 1.f / d; r.ood[a] = r.o[a] * r.id[a]; }
+                    r.t = INFINITY; r.slot = -1; r.node = 0; r.stk.clear(); r.stk_t.clear();
+                }
+                c.rays += 64;
+                auto pop = [&](Ray& r) -> int {
+                    for (;;) {
+                        if (r.stk.empty()) return kSent;
+                        int v = r.stk.back(); float tn = r.stk_t.back(); r.stk.pop_back(); r.stk_t.pop_back();
+                        if (cull && tn >= r.t) { c.culled++; continue; }
+                        return v;
+                    }
+                };
+                for (;;) {
+                    bool any = false; for (auto& r : R) any |= r.node != kSent;
+                    if (!any) break;
+                    for (;;) {
+                        bool anyn = false; for (auto& r : R) anyn |= (r.node >= 0 && r.node != kSent);
+                        if (!anyn) break;
+                        c.wnode++;
+                        {   // wave-uniform step? (all lanes that take part hold the same node); how deep are the stacks; distinct 128-B lines fetched
+                            int first = -1; bool uni = true; size_t deep = 0; std::vector<int> ln;
+                            for (auto& r : R) if (r.node >= 0 && r.node != kSent) { if (first < 0) first = r.node; else if (r.node != first) uni = false; if (r.stk.size() > deep) deep = r.stk.size(); ln.push_back(r.node >> 1); }
+                            if (uni) c.wuni++;
+                            if (deep + 3 > 8) c.wdeep[0]++; if (deep + 3 > 10) c.wdeep[1]++; if (deep + 3 > 11) c.wdeep[2]++; if (deep + 3 > 16) c.wdeep[3]++;
+                            std::sort(ln.begin(), ln.end()); c.lines += (double)(std::unique(ln.begin(), ln.end()) - ln.begin());
+                        }
+                        for (auto& r : R) {
+                            if (!(r.node >= 0 && r.node != kSent)) continue;
+                            c.nodes++;
+                            const GpuNode4& n = h.nodes4[r.node];
+                            float key[4]; int code[4];
+                            const float cell[3] = {n.cell_x, n.cell_y, n.cell_z};
+                            const uint32_t lo[3] = {n.lox, n.loy, n.loz}, hi[3] = {n.hix, n.hiy, n.hiz};
+                            for (int k = 0; k < 4; k++) {
+                                float tn = 0.f, tf = r.t;
+                                for (int a = 0; a < 3; a++) {
+                                    float s = cell[a] * r.id[a], b = n.origin[a] * r.id[a] - r.ood[a];
+                                    uint32_t nq = r.id[a] < 0.f ? hi[a] : lo[a], fq = r.id[a] < 0.f ? lo[a] : hi[a];
+                                    float tnn = (float)((nq >> (8 * k)) & 255u) * s + b, tff = (float)((fq >> (8 * k)) & 255u) * s + b;
+                                    tn = fmaxf(tn, tnn); tf = fminf(tf, tff);
+                                }
+                                key[k] = tn <= tf ? tn : INFINITY; code[k] = n.c[k];
+                            }
+                            if (!nosort) {
+#define CS(a, b) if (key[b] < key[a]) { std::swap(key[a], key[b]); std::swap(code[a], code[b]); }
+                                CS(0, 1) CS(2, 3) CS(0, 2) CS(1, 3) CS(1, 2)
+#undef CS
+                            }
+                            for (int k = 3; k >= 1; k--) if (key[k] < INFINITY) { r.stk.push_back(code[k]); r.stk_t.push_back(cull8 ? q8(key[k]) : key[k]); }
+                            if ((double)r.stk.size() > c.maxsp) c.maxsp = (double)r.stk.size();
+                            if (key[0] < INFINITY) r.node = code[0]; else r.node = pop(r);
+                        }
+                    }
+                    for (;;) {
+                        bool anyl = false; for (auto& r : R) anyl |= r.node < 0;
+                        if (!anyl) break;
+                        int mx = 0;
+                        for (auto& r : R) {
+                            if (r.node >= 0) continue;
+                            uint32_t code = ~(uint32_t)r.node;
+                            int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
+                            if (cnt > mx) mx = cnt;
+                            for (int i = first; i < first + cnt; i++) {
+                                c.tris++;
+                                const GpuTri& tr = h.tris[i];
+                                float px = r.d[1] * tr.e2[2] - r.d[2] * tr.e2[1], py = r.d[2] * tr.e2[0] - r.d[0] * tr.e2[2], pz = r.d[0] * tr.e2[1] - r.d[1] * tr.e2[0];
+                                float det = tr.e1[0] * px + tr.e1[1] * py + tr.e1[2] * pz, inv = 1.f / det;
+                                float tx = r.o[0] - tr.v0[0], ty = r.o[1] - tr.v0[1], tz = r.o[2] - tr.v0[2];
+                                float u = (tx * px + ty * py + tz * pz) * inv;
+                                float qx = ty * tr.e1[2] - tz * tr.e1[1], qy = tz * tr.e1[0] - tx * tr.e1[2], qz = tx * tr.e1[1] - ty * tr.e1[0];
+                                float v = (r.d[0] * qx + r.d[1] * qy + r.d[2] * qz) * inv, t = (tr.e2[0] * qx + tr.e2[1] * qy + tr.e2[2] * qz) * inv;
+                                if (det != 0.f && u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t > 0.f && t < r.t) { r.t = t; r.slot = i; }
+                            }
+                            r.node = pop(r);
+                        }
+                        c.wtri += mx;
+                    }
+                }
+                for (auto& r : R) if (r.slot >= 0) c.hits++;
+            }
+        }
+#pragma omp critical
+        { tot.rays += c.rays; tot.nodes += c.nodes; tot.tris += c.tris; tot.wnode += c.wnode; tot.wtri += c.wtri; tot.culled += c.culled; tot.hits += c.hits; tot.wuni += c.wuni; tot.lines += c.lines; for (int q = 0; q < 4; q++) tot.wdeep[q] += c.wdeep[q]; if (c.maxsp > tot.maxsp) tot.maxsp = c.maxsp; }
+    }
+    double wr = tot.rays / 64.0;
+    printf("per ray: %.2f node visits, %.2f tri tests, %.2f culled pops, hit %.4f, max stack %.0f\n", tot.nodes / tot.rays, tot.tris / tot.rays, tot.culled / tot.rays, tot.hits / tot.rays, tot.maxsp);
+    printf("per pass: %.2f wave node steps (util %.3f), %.2f wave tri steps (util %.3f)\n", tot.wnode / wr, tot.nodes / (64.0 * tot.wnode), tot.wtri / wr, tot.tris / (64.0 * tot.wtri));
+    printf("wave node steps: %.3f uniform, %.2f distinct node lines per step; steps whose push could pass 8/10/11/16 entries: %.4f %.4f %.4f %.4f\n", tot.wuni / tot.wnode, tot.lines / tot.wnode,
+           tot.wdeep[0] / tot.wnode, tot.wdeep[1] / tot.wnode, tot.wdeep[2] / tot.wnode, tot.wdeep[3] / tot.wnode);
+    printf("VALU model (124/node step, 62/tri step): %.0f per pass\n", 124.0 * tot.wnode / wr + 62.0 * tot.wtri / wr);
+    return 0;
+}

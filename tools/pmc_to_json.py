@@ -1,0 +1,39 @@
+"""Fold the per-pass counter CSVs of tools/profile_round.sh into profiles/pmc_<workload>.json (read by bench.py's roofline):
+usage: python tools/pmc_to_json.py <dir with pmc_*.csv> <workload> <out.json>"""
+import collections, csv, glob, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+d, wl, out = sys.argv[1], sys.argv[2], sys.argv[3]
+c = collections.defaultdict(float)
+kernel, dur = None, []
+for f in sorted(glob.glob(os.path.join(d, "pmc_*.csv"))):
+    for r in csv.DictReader(open(f)):
+        kernel = r["Kernel_Name"].split("(")[0]
+        c[r["Counter_Name"]] += float(r["Counter_Value"])
+    rows = list(csv.DictReader(open(f)))
+    if rows:
+        dur.append((int(rows[0]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])) / 1e6)
+res = {"workload": wl, "kernel": kernel, "kernel_src_sha": bench.kernel_src_sha(),
+       "source": "rocprofv3 --pmc, separate passes, one launch each (tools/profile_round.sh -> %s)" % os.path.relpath(d, ROOT),
+       "counters": dict(c), "kernel_ms_under_pmc": dur}
+rd = c.get("TCC_EA0_RDREQ_sum", 0.0)
+if rd:
+    # every read request of this kernel is a 128-byte line (TCC_EA0_RDREQ_128B == RDREQ, profiles/r01_calib); WRITE_SIZE is in KB
+    res["fabric_bytes_per_launch"] = rd * 128.0 + c.get("WRITE_SIZE", 0.0) * 1024.0
+if c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0) > 0:
+    res["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
+if c.get("SQ_INSTS_VALU", 0):
+    res["SQ_INSTS_VALU"] = c["SQ_INSTS_VALU"]
+    if c.get("SQ_THREAD_CYCLES_VALU", 0):
+        res["valu_lane_utilisation"] = round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"]), 4)
+if c.get("GRBM_GUI_ACTIVE", 0) and dur:
+    res["effective_clock_ghz"] = round(c["GRBM_GUI_ACTIVE"] / (dur[0] * 1e-3) / 1e9, 3)
+if c.get("SQ_WAVE_CYCLES", 0):
+    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+        if k in c:
+            res[k.lower() + "_frac"] = round(c[k] / c["SQ_WAVE_CYCLES"], 4)
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps({k: v for k, v in res.items() if k != "counters"}))
