@@ -105,10 +105,14 @@ TEXIR_API int texir_irt_kernel_name(const texir_scene* scene, int64_t n_ids, int
 /* Replaces MaterialModel.render + specular_reflectance (models/mat_nvdiffrast.py:201-249, 260-279), forward:
  *   rgb = irr*albedo/pi + (1/S) sum_i Ls_i * w_i(roughness)        
  * normal,albedo,points,irr [P,3] dev; rough [P] dev; cam [3] dev; shift [P,2] dev (GGX sample shift, as above)
- * Ls_ws [P,S,3] dev, nullable: traced radiance saved for texir_spec_backward. */
-TEXIR_API int texir_spec_forward(const texir_scene* scene, const float* normal, const float* albedo, const float* rough,
+ * Ls_ws [P,S,3] dev, nullable: traced radiance saved for texir_spec_backward.
+ * clamp_eps: the floor of the BRDF denominators -- 1e-14 (TINY_TINY_NUMBER) in models/mat_nvdiffrast.py:270-279, 1e-6 (TINY_NUMBER) in
+ * the evaluation model models/test_nvdiffrast.py:320-333.
+ * ls_given = 1: Ls_ws is an INPUT (the `lighting` argument of specular_reflectance, function seam 3 of SURVEY 8b) and nothing is
+ * traced -- specular_reflectance(lighting, h, n, v, l, roughness)/S + irr*albedo/pi on the caller's lighting. */
+TEXIR_API int texir_spec_forward(const texir_scene* scene /*nullable when ls_given*/, const float* normal, const float* albedo, const float* rough,
                        const float* points, const float* irr, const float* cam, const float* shift, int64_t P,
-                       int32_t S, float* rgb /*dev [P,3]*/, float* Ls_ws /*dev, nullable*/, void* stream);
+                       int32_t S, float clamp_eps, int32_t ls_given, float* rgb /*dev [P,3]*/, float* Ls_ws /*dev, nullable*/, void* stream);
 
 /* Analytic backward of the above (what autograd computes in the reference): given d_rgb [P,3],
  *   d_albedo [P,3] = d_rgb*irr/pi ;  d_rough [P] = sum_c d_rgb_c * (1/S) sum_i Ls_ic * dw_i/dr
@@ -116,7 +120,14 @@ TEXIR_API int texir_spec_forward(const texir_scene* scene, const float* normal, 
  * torch clamp sub-gradients).  Either output may be NULL. */
 TEXIR_API int texir_spec_backward(const float* normal, const float* rough, const float* points, const float* irr,
                         const float* cam, const float* shift, const float* Ls_ws, const float* d_rgb, int64_t P,
-                        int32_t S, float* d_albedo /*dev, nullable*/, float* d_rough /*dev, nullable*/, void* stream);
+                        int32_t S, float clamp_eps, float* d_albedo /*dev, nullable*/, float* d_rough /*dev, nullable*/, void* stream);
+
+/* Replaces the lighting integral of diffuse_reflectance (models/mat_nvdiffrast.py:252-258; live in the evaluation model's
+ * relighting branch, models/test_nvdiffrast.py:268-274): per point  E = (2*pi/N) sum_i L_i * clamp(n.l_i, 0, 1)  over uniform
+ * directions (sample_type 0: the IrT estimator) or  E = (pi/N) sum_i L_i  over cosine-distributed directions (sample_type 1), so that
+ * diffuse_reflectance(...)/N == E * albedo / pi.  pos (already offset), nrm [P,3], shift [P,2] dev -> irr [P,3] dev. */
+TEXIR_API int texir_diffuse_irradiance(const texir_scene* scene, const float* pos, const float* nrm, const float* shift, int64_t P,
+                        int32_t N, int32_t sample_type, float* irr /*dev [P,3]*/, void* stream);
 
 /* Replaces RenderLoss.forward + SegLoss.forward + hdr_scale (models/loss.py:81-115, 214-295; utils/general.py:61-66),
  * value AND gradient in one call.  The reference's one-hot mask tensors (seg_mask/floor_max_mask [C,6,h,w,1],
@@ -203,9 +214,13 @@ TEXIR_API int texir_adam_step(float* param, const float* grad, float* exp_avg, f
 /* The same step (trainer/train_material.py:448-458) for a texture [H,W,C] whose gradient is grad + 0.25 * grad_level1[y/2][x/2] (texir_tex_fetch_backward_deferred): the
  * last mip fold is fused into the optimiser's read of the gradient; results equal fold + texir_adam_step bit for bit.
  * grad == NULL: no pixel of the step sampled mip level 0, the level-0 gradient is neither materialised nor read.
+ * grad_mask != NULL: grad is a buffer that is never cleared; only the texels a view's tap lists touch (their bit is set) carry this
+ * step's values, all others count as zero -- the usual case of a handful of level-0 taps costs 1 bit per texel instead of a fill + a read.
  * mip_level1 != NULL: level 1 of the NEXT forward's mip stack (models/mat_nvdiffrast.py:131-134 rebuild it from the updated
  * texture every step) is written on the way: texir_mip_build(..., from_level = 1) then skips the pass over the full texture. */
-TEXIR_API int texir_adam_step_tex(float* param, const float* grad /*nullable: level-0 gradient identically zero*/, const float* grad_level1,
+TEXIR_API int texir_adam_step_tex(float* param, const float* grad /*nullable: level-0 gradient identically zero*/,
+                       const uint32_t* grad_mask /*nullable: 1 bit per texel (bit t&31 of word t>>5): grad is valid -- and read -- only where set*/,
+                       const float* grad_level1,
                        float* exp_avg, float* exp_avg_sq, float* mip_level1 /*nullable: [H/2,W/2,C] <- 2x2 average of the updated texels*/,
                        int32_t H, int32_t W, int32_t C, float lr, float beta1, float beta2, float eps, int32_t step, float clamp_lo,
                        float clamp_hi, void* stream);

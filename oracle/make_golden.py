@@ -14,6 +14,8 @@ Fixtures (SURVEY.md 8c pins):
   cube2pano.npz    utils/Cube2Pano.py:119-144 ToPano
   mat_trajectory.npz  trainer/train_material.py:245-356,408-605 the trainer loop itself (3 steps per stage) on a pixel-parameter model
   pano2cube.npz    utils/Pano2Cube.py:24-102 grids + Tocube (nearest and bilinear); cv2.Rodrigues answered by scipy
+  diffuse.npz      models/mat_nvdiffrast.py:252-258 diffuse_reflectance (uniform / cosine) on the reference's own traced lighting
+  test_render.npz  models/test_nvdiffrast.py:256-304,336-367 the evaluation model's render (1e-6 clamps; traced diffuse when relighting), S = 256
   nirf.npz         models/tracer_o3d_irrf.py:72-136 forward (GT irradiance at mesh points + MatNetwork prediction), models/loss.py:28-52 IRFLoss
 """
 import os
@@ -204,6 +206,75 @@ def irt_box():
 def irt_room():
     sc = synth.make_scene(20000, seed=666, tex_res=256)
     save("irt_room.npz", **_irt_forward(sc, 64, 256, "uniform", 666))
+
+
+def diffuse():
+    """models/mat_nvdiffrast.py:252-258 diffuse_reflectance (both sample types) on lighting traced by the reference's own query_irf
+    (tracer_o3d_irt.py:240-269, cast_rays answered by the f64 brute-force tracer), 20k-tri room, 48 surface points, N = 256"""
+    sc = synth.make_scene(20000, seed=666, tex_res=256)
+    pos, nrm, valid = synth.make_texel_gbuffer(sc, 64)
+    osc = O.Scene(sc["verts"], sc["tris"], sc["tri_uvs"], sc["hdr"])
+    m = object.__new__(ref_irt.TracerO3d)
+    torch.nn.Module.__init__(m)
+    m.scene = IR.FakeScene(osc, "brute")
+    m.triangle_uvs = sc["tri_uvs"].astype(np.float64)
+    m.texture = torch.from_numpy(sc["hdr"]).permute(2, 0, 1).unsqueeze(0).float()
+    rng = np.random.default_rng(12)
+    pick = rng.choice(np.flatnonzero(valid.reshape(-1) > 0), 48, replace=False)
+    P, N = pick.size, 256
+    pts, n = torch.from_numpy(pos.reshape(-1, 3)[pick].copy()), torch.from_numpy(nrm.reshape(-1, 3)[pick].copy())
+    n[3] *= 1.3                                   # raw (non-unit) normal in the n.l factor
+    albedo = torch.rand(P, 3, generator=torch.Generator().manual_seed(5))
+    out = dict(verts=sc["verts"], tris=sc["tris"], tri_uvs=sc["tri_uvs"], hdr=sc["hdr"], points=pts.numpy(), normal=n.numpy(), albedo=albedo.numpy(), N=N)
+    for k, mode in enumerate(("uniform", "cosine")):
+        seed = 900 + k
+        torch.manual_seed(seed)
+        l = su.generate_dir(n, N, None, mode=mode)
+        lighting = m.query_irf(pts.unsqueeze(1).expand_as(l), l.unsqueeze(-2), N)
+        d = ref_mat.MaterialModel.diffuse_reflectance(None, lighting, l, n, albedo, mode) / N
+        torch.manual_seed(seed)
+        out["shift_" + mode] = torch.rand(P, 1, 2).reshape(P, 2).numpy()
+        out["diffuse_" + mode] = d.numpy()
+    save("diffuse.npz", **out)
+
+
+def test_render():
+    """models/test_nvdiffrast.py:256-304 (the evaluation model's render: 1e-6 BRDF clamps, traced diffuse when relighting) with its own
+    query_irf (:336-367), S = 256, on the 20k-tri room; P = 6 * 3 * 3 pixels"""
+    import models.test_nvdiffrast as ref_test
+    sc = synth.make_scene(20000, seed=666, tex_res=256)
+    pos, nrm, valid = synth.make_texel_gbuffer(sc, 64)
+    osc = O.Scene(sc["verts"], sc["tris"], sc["tri_uvs"], sc["hdr"])
+    c = 3
+    P, S, N0 = 6 * c * c, 256, 64
+    rng = np.random.default_rng(33)
+    pick = rng.choice(np.flatnonzero(valid.reshape(-1) > 0), P, replace=False)
+    normal = torch.from_numpy(nrm.reshape(-1, 3)[pick].copy()).reshape(6, c, c, 3)
+    points = torch.from_numpy(pos.reshape(-1, 3)[pick].copy()).reshape(6, c, c, 3)
+    g = torch.Generator().manual_seed(8)
+    albedo = torch.rand(6, c, c, 3, generator=g)
+    rough = torch.rand(6, c, c, 1, generator=g) * 0.79 + 0.01
+    irr = torch.rand(6, c, c, 3, generator=g) * 2
+    cam = torch.tensor([4.0, 1.5, 3.0])
+    out = dict(verts=sc["verts"], tris=sc["tris"], tri_uvs=sc["tri_uvs"], hdr=sc["hdr"], normal=normal.numpy(), points=points.numpy(), albedo=albedo.numpy(),
+               roughness=rough.numpy(), irr=irr.numpy(), cam=cam.numpy(), S=S, N0=N0)
+    for relight in (False, True):
+        m = object.__new__(ref_test.MaterialModel)
+        torch.nn.Module.__init__(m)
+        m.cube_res, m.sample_l, m.sample_type, m.relighting = c, [N0, S], ["uniform", "importance"], relight
+        m.scene = IR.FakeScene(osc, "brute")
+        m.triangle_uvs = sc["tri_uvs"].astype(np.float64)
+        m.texture = torch.from_numpy(sc["hdr"]).permute(2, 0, 1).unsqueeze(0).float()
+        seed = 70 + int(relight)
+        torch.manual_seed(seed)
+        res = m.render(normal, albedo, rough, points, cam, irr)
+        torch.manual_seed(seed)
+        tag = "relight" if relight else "plain"
+        if relight:
+            out["shift_diff_" + tag] = torch.rand(P, 1, 2).reshape(P, 2).numpy()
+        out["shift_spec_" + tag] = torch.rand(P, 1, 2).reshape(P, 2).numpy()
+        out["rgb_" + tag] = res["rgb"].numpy()
+    save("test_render.npz", **out)
 
 
 def render_loss():
@@ -423,6 +494,6 @@ def nirf():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gen_dir", "spec_render", "query_irf", "irt_box", "irt_room", "render_loss", "cube2pano", "mat_trajectory", "pano2cube", "nirf"]
+    which = sys.argv[1:] or ["gen_dir", "spec_render", "query_irf", "irt_box", "irt_room", "render_loss", "cube2pano", "mat_trajectory", "pano2cube", "nirf", "diffuse", "test_render"]
     for w in which:
         globals()[w]()

@@ -39,7 +39,7 @@ def lib():
         L.txo_hammersley.argtypes = [i32, vp]
         L.txo_generate_dir.argtypes = [vp, i32, i32, i32, vp, vp, vp]
         L.txo_irt_generate.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp]
-        L.txo_spec_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]
+        L.txo_spec_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, C.c_float]
         L.txo_num_threads.restype = i32
         L.txo_set_num_threads.argtypes = [i32]
         L.txo_set_num_threads.restype = None
@@ -127,18 +127,19 @@ class Scene:
         lib().txo_trace_shade(self.h, _p(org), _p(dir), org.shape[0], 0 if tracer == "brute" else 1, _p(out), _p(counters))
         return out
 
-    def irt_generate(self, pos, nrm, valid, shift, n, mode="uniform", tracer="bvh", counters=None):
+    def irt_generate(self, pos, nrm, valid, shift, n, mode="uniform", tracer="bvh", counters=None, cosine_estimator=False):
+        """cosine_estimator: (pi / n) sum L instead of (2 pi / n) sum L n.l -- the cosine branch of diffuse_reflectance"""
         pos = _f32(pos).reshape(-1, 3)
         nrm = _f32(nrm).reshape(-1, 3)
         Nt = pos.shape[0]
         shift = _f32(shift).reshape(Nt, 2)
         v = None if valid is None else np.ascontiguousarray(valid, np.uint8).reshape(Nt)
         out = np.zeros((Nt, 3), np.float32)
-        lib().txo_irt_generate(self.h, _p(pos), _p(nrm), _p(v), _p(shift), Nt, n, MODES[mode],
+        lib().txo_irt_generate(self.h, _p(pos), _p(nrm), _p(v), _p(shift), Nt, n, MODES[mode] | (4 if cosine_estimator else 0),
                                0 if tracer == "brute" else 1, _p(out), _p(counters))
         return out
 
-    def spec_forward(self, normal, albedo, rough, points, irr, cam, shift, S, tracer="bvh", return_ls=False):
+    def spec_forward(self, normal, albedo, rough, points, irr, cam, shift, S, tracer="bvh", return_ls=False, lighting=None, clamp_eps=1e-14):
         normal = _f32(normal).reshape(-1, 3)
         P = normal.shape[0]
         albedo = _f32(albedo).reshape(P, 3)
@@ -149,8 +150,9 @@ class Scene:
         shift = _f32(shift).reshape(P, 2)
         rgb = np.empty((P, 3), np.float32)
         ls = np.empty((P, S, 3), np.float32) if return_ls else None
+        lin = None if lighting is None else _f32(lighting).reshape(P, S, 3)
         lib().txo_spec_forward(self.h, _p(normal), _p(albedo), _p(rough), _p(points), _p(irr), _p(cam), _p(shift),
-                               P, S, 0 if tracer == "brute" else 1, _p(rgb), _p(ls))
+                               P, S, 0 if tracer == "brute" else 1, _p(rgb), _p(ls), _p(lin), C.c_float(clamp_eps))
         return (rgb, ls) if return_ls else rgb
 
 

@@ -481,6 +481,9 @@ TXO_API void txo_irt_generate(const TxoScene *s, const float *pos, const float *
     txo_hammersley(N, ham);
     uint64_t tn = 0, tt = 0, tr = 0, th = 0;
     const float pi = (float)3.141592653589793;
+    /* mode | 4: the cosine branch of diffuse_reflectance (models/mat_nvdiffrast.py:256-257): sum L * pi / N, no n.l factor */
+    const int cosw = (mode & 4) != 0;
+    mode &= 3;
 #pragma omp parallel
     {
         float *dirs = (float *)malloc(sizeof(float) * 3 * (size_t)N);
@@ -521,10 +524,10 @@ TXO_API void txo_irt_generate(const TxoScene *s, const float *pos, const float *
             double acc[3] = {0, 0, 0};
             for (int i = 0; i < N; i++) {
                 float ndl = n[0] * dirs[3 * i] + n[1] * dirs[3 * i + 1] + n[2] * dirs[3 * i + 2];
-                ndl = fminf(fmaxf(ndl, 0.f), 1.f);
+                ndl = cosw ? 1.f : fminf(fmaxf(ndl, 0.f), 1.f);
                 for (int c = 0; c < 3; c++) acc[c] += (double)(rad[3 * i + c] * ndl);
             }
-            for (int c = 0; c < 3; c++) irr[3 * p + c] = (((float)acc[c] * 2.f) * pi) / (float)N;
+            for (int c = 0; c < 3; c++) irr[3 * p + c] = (((float)acc[c] * (cosw ? 1.f : 2.f)) * pi) / (float)N;
         }
         free(dirs); free(orgs); free(rad); free(th_); free(pid); free(puv);
     }
@@ -540,11 +543,13 @@ static inline float clamp01(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
 
 TXO_API void txo_spec_forward(const TxoScene *s, const float *normal, const float *albedo, const float *rough,
                               const float *points, const float *irr, const float *cam, const float *shift,
-                              int64_t P, int S, int tracer, float *rgb /* [P,3] */, float *Ls_out /* [P,S,3] or NULL */)
+                              int64_t P, int S, int tracer, float *rgb /* [P,3] */, float *Ls_out /* [P,S,3] or NULL */,
+                              const float *Ls_in /* [P,S,3] or NULL: the `lighting` argument of specular_reflectance -- nothing is traced */,
+                              float clamp_eps /* 1e-14 mat_nvdiffrast.py:270-279; 1e-6 test_nvdiffrast.py:320-333 */)
 {
     float *ham = (float *)malloc(sizeof(float) * 2 * (size_t)S);
     txo_hammersley(S, ham);
-    const float pi = (float)3.141592653589793, eps14 = 1e-14f;
+    const float pi = (float)3.141592653589793, eps14 = clamp_eps;
 #pragma omp parallel for schedule(dynamic, 16)
     for (int64_t p = 0; p < P; p++) {
         const float *n = normal + 3 * p, *pt = points + 3 * p;
@@ -565,7 +570,8 @@ TXO_API void txo_spec_forward(const TxoScene *s, const float *normal, const floa
             float vdh = clamp01(h[0] * vv[0] + h[1] * vv[1] + h[2] * vv[2]);
             for (int a = 0; a < 3; a++) l[a] = 2.f * vdh * h[a] - vv[a];
             float Ls[3];
-            txo_trace_shade(s, pt, l, 1, tracer, Ls, NULL);
+            if (Ls_in) memcpy(Ls, Ls_in + 3 * ((size_t)p * S + i), sizeof(float) * 3);
+            else txo_trace_shade(s, pt, l, 1, tracer, Ls, NULL);
             if (Ls_out) memcpy(Ls_out + 3 * ((size_t)p * S + i), Ls, sizeof(float) * 3);
             float ndl = clamp01(n[0] * l[0] + n[1] * l[1] + n[2] * l[2]);
             float ndh = clamp01(n[0] * h[0] + n[1] * h[1] + n[2] * h[2]);

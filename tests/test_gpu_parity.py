@@ -155,6 +155,17 @@ def test_spec_forward_vs_oracle(room):
         assert rel_l2(rgb.cpu().numpy(), ref) < 5e-5, Sn
 
 
+def test_spec_forward_on_reference_lighting(golden, tx):
+    """direct pin of the HIP render + specular_reflectance: the reference's own traced radiance `Ls` from the
+    fixture goes in as the lighting (texir_spec_forward, ls_given = 1), the reference's `rgb` must come out -- no tracer in between"""
+    g = golden("spec_render.npz")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    rgb = tx.spec_render(None, t(g["normal"]), t(g["albedo"]), t(g["roughness"].reshape(-1)), t(g["points"]), t(g["irr"]), t(g["cam"]), t(g["shift"]),
+                         int(g["S"]), lighting=t(g["Ls"]))
+    assert rel_l2(rgb.cpu().numpy(), g["rgb"]) < 1e-3
+    assert rel_l2(rgb.cpu().numpy(), g["rgb"]) < 1e-5
+
+
 def test_spec_backward_matches_reference_autograd(golden, tx):
     """d rgb / d albedo, d roughness from the reference's autograd graph (golden) vs texir_spec_backward"""
     from texir_code_amd import _lib
@@ -166,7 +177,7 @@ def test_spec_backward_matches_reference_autograd(golden, tx):
     d_a = torch.empty((P, 3), device="cuda")
     d_r = torch.empty((P,), device="cuda")
     _lib.check(_lib.lib().texir_spec_backward(_lib.ptr(normal), _lib.ptr(rough), _lib.ptr(pts), _lib.ptr(irr), _lib.ptr(cam), _lib.ptr(shift),
-                                              _lib.ptr(Ls), _lib.ptr(d_rgb), P, S, _lib.ptr(d_a), _lib.ptr(d_r), _lib.stream_ptr()))
+                                              _lib.ptr(Ls), _lib.ptr(d_rgb), P, S, 1e-14, _lib.ptr(d_a), _lib.ptr(d_r), _lib.stream_ptr()))
     assert rel_l2(d_a.cpu().numpy(), g["d_albedo"]) < 1e-6
     ref = g["d_roughness"].reshape(-1)
     got = d_r.cpu().numpy()

@@ -1,7 +1,9 @@
 """Watertightness of the HIP tracer (VERDICT r1 weak #1 / Embree semantics cited at SURVEY 8c, models/tracer_o3d_irt.py:244-248):
 rays fired from inside CLOSED meshes straight at shared edges and vertices (+- ulp-scale jitter) must never escape, and their hit
 distance must agree with the float64 brute-force oracle.  Embree (Open3D's RaycastingScene) does not leak there; a
-Moeller-Trumbore test with independent per-triangle edge tests does."""
+Moeller-Trumbore test with independent per-triangle edge tests does (6 % of these rays escape it on the box, 80 ppm on the
+sphere; measured in round 2, profiles/r02/watertight_mt.txt).  What makes the HIP path tight: exact-sign 2D edge functions in the
+ray's sheared space (device_common.h edge2_exact) + an absolute slack on the quantised BVH boxes (bvh_build.cpp emit4_fill)."""
 import numpy as np
 import pytest
 import torch
@@ -98,7 +100,7 @@ def test_no_ray_escapes_through_shared_edges_or_vertices(mesh):
     t = t.cpu().numpy()
     miss = ~np.isfinite(t)
     assert miss.sum() == 0, "%d of %d rays escaped a closed mesh (first: org %s dir %s)" % (miss.sum(), t.size, org[miss][:1], d[miss][:1])
-    assert (rad.cpu().numpy() == 1.0).all()                      # constant texture: every hit shades to exactly 1
+    assert np.abs(rad.cpu().numpy() - 1.0).max() < 1e-6          # constant texture: every ray hit something and shades to 1 (bilinear weights sum to 1 +- 1 ulp)
     # distance against the float64 brute force on a sample (the oracle costs rays x triangles)
     pick = rng.choice(t.size, 60000, replace=False)
     t_ref, _, _ = O.Scene(verts, tris, uvs, hdr).cast_rays(org[pick], d[pick], tracer="brute")

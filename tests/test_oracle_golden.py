@@ -64,6 +64,16 @@ def test_irt_forward_bvh_matches(golden, name):
     assert c[0] > c[2] and c[1] > 0
 
 
+def test_oracle_spec_forward_on_reference_lighting(golden):
+    """direct pin of the C oracle's render + specular_reflectance: the fixture's traced radiance `Ls` (what the reference's query_irf
+    returned) goes in as the lighting, the reference's own `rgb` must come out (mat_nvdiffrast.py:201-249,260-279)"""
+    g = golden("spec_render.npz")
+    sc = O.Scene(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), np.array([[0, 1, 2]], np.int32),
+                 np.zeros((3, 2), np.float32), np.ones((2, 2, 3), np.float32))           # (never traced: the lighting is given)
+    rgb = sc.spec_forward(g["normal"], g["albedo"], g["roughness"].reshape(-1), g["points"], g["irr"], g["cam"], g["shift"], int(g["S"]), lighting=g["Ls"])
+    assert rel_l2(rgb, g["rgb"]) < 1e-5
+
+
 def test_spec_forward_matches_reference_render(golden):
     g = golden("spec_render.npz")
     P, S = g["normal"].shape[0], int(g["S"])
@@ -89,3 +99,31 @@ def test_spec_forward_matches_reference_render(golden):
     w = brdf * ndl * 4 * vdh / np.maximum(ndh, 1e-14)
     rgb = irr * a / math.pi + (Ls * w[..., None]).sum(1) / S
     assert rel_l2(rgb, g["rgb"]) < 1e-5
+
+
+def test_oracle_diffuse_reflectance_matches_reference(golden):
+    """diffuse_reflectance(query_irf(...), l, n, albedo, type) / N of the reference (mat_nvdiffrast.py:252-258, both sample types) ==
+    the oracle's per-point irradiance integral x albedo / pi"""
+    import math
+    g = golden("diffuse.npz")
+    s = O.Scene(g["verts"], g["tris"], g["tri_uvs"], g["hdr"])
+    for mode in ("uniform", "cosine"):
+        E = s.irt_generate(g["points"], g["normal"], None, g["shift_" + mode], int(g["N"]), mode, tracer="brute", cosine_estimator=mode == "cosine")
+        assert rel_l2(E * g["albedo"] / math.pi, g["diffuse_" + mode]) < 1e-5, mode
+
+
+def test_oracle_evaluation_render_matches_reference(golden):
+    """the evaluation model's render (models/test_nvdiffrast.py:256-304: BRDF denominators floored at 1e-6, diffuse term traced when
+    relighting) at S = 256, with its own query_irf"""
+    import math
+    g = golden("test_render.npz")
+    s = O.Scene(g["verts"], g["tris"], g["tri_uvs"], g["hdr"])
+    P = g["normal"].reshape(-1, 3).shape[0]
+    f = lambda k, c: g[k].reshape(P, c)
+    for tag in ("plain", "relight"):
+        irr = f("irr", 3)
+        if tag == "relight":
+            irr = s.irt_generate(f("points", 3), f("normal", 3), None, g["shift_diff_relight"], int(g["N0"]), "uniform", tracer="brute")
+        rgb = s.spec_forward(f("normal", 3), f("albedo", 3), f("roughness", 1).reshape(-1), f("points", 3), irr, g["cam"], g["shift_spec_" + tag], int(g["S"]),
+                             tracer="brute", clamp_eps=1e-6)
+        assert rel_l2(rgb, g["rgb_" + tag].reshape(P, 3)) < 2e-5, tag

@@ -188,20 +188,35 @@ int texir_irt_kernel_name(const texir_scene* s, int64_t n_ids, int32_t N, char* 
 }
 
 int texir_spec_forward(const texir_scene* s, const float* normal, const float* albedo, const float* rough, const float* points, const float* irr,
-                       const float* cam, const float* shift, int64_t P, int32_t S, float* rgb, float* Ls_ws, void* stream)
+                       const float* cam, const float* shift, int64_t P, int32_t S, float clamp_eps, int32_t ls_given, float* rgb, float* Ls_ws, void* stream)
 {
-    if (!s || !normal || !albedo || !rough || !points || !irr || !cam || !shift || !rgb) return fail(TEXIR_ERR_INVALID, "texir_spec_forward: null argument");
-    if (P < 0 || S <= 0) return fail(TEXIR_ERR_INVALID, "texir_spec_forward: bad sizes P=%lld S=%d", (long long)P, S);
-    HIP_TRY(launch_spec_fwd(s->dev, normal, albedo, rough, points, irr, cam, shift, P, S, rgb, Ls_ws, (hipStream_t)stream));
+    if ((!s && !ls_given) || !normal || !albedo || !rough || !points || !irr || !cam || !shift || !rgb) return fail(TEXIR_ERR_INVALID, "texir_spec_forward: null argument");
+    if (ls_given && !Ls_ws) return fail(TEXIR_ERR_INVALID, "texir_spec_forward: ls_given needs the lighting in Ls_ws");
+    if (P < 0 || S <= 0 || !(clamp_eps > 0.f)) return fail(TEXIR_ERR_INVALID, "texir_spec_forward: bad sizes P=%lld S=%d clamp_eps=%g", (long long)P, S, (double)clamp_eps);
+    SceneDev none{};
+    HIP_TRY(launch_spec_fwd(s ? s->dev : none, normal, albedo, rough, points, irr, cam, shift, P, S, clamp_eps, ls_given ? 1 : 0, rgb, Ls_ws, (hipStream_t)stream));
     return TEXIR_OK;
 }
 
 int texir_spec_backward(const float* normal, const float* rough, const float* points, const float* irr, const float* cam, const float* shift,
-                        const float* Ls_ws, const float* d_rgb, int64_t P, int32_t S, float* d_albedo, float* d_rough, void* stream)
+                        const float* Ls_ws, const float* d_rgb, int64_t P, int32_t S, float clamp_eps, float* d_albedo, float* d_rough, void* stream)
 {
     if (!normal || !rough || !points || !irr || !cam || !shift || !Ls_ws || !d_rgb) return fail(TEXIR_ERR_INVALID, "texir_spec_backward: null argument");
-    if (P < 0 || S <= 0) return fail(TEXIR_ERR_INVALID, "texir_spec_backward: bad sizes P=%lld S=%d", (long long)P, S);
-    HIP_TRY(launch_spec_bwd(normal, rough, points, irr, cam, shift, Ls_ws, d_rgb, P, S, d_albedo, d_rough, (hipStream_t)stream));
+    if (P < 0 || S <= 0 || !(clamp_eps > 0.f)) return fail(TEXIR_ERR_INVALID, "texir_spec_backward: bad sizes P=%lld S=%d", (long long)P, S);
+    HIP_TRY(launch_spec_bwd(normal, rough, points, irr, cam, shift, Ls_ws, d_rgb, P, S, clamp_eps, d_albedo, d_rough, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
+int texir_diffuse_irradiance(const texir_scene* s, const float* pos, const float* nrm, const float* shift, int64_t P, int32_t N, int32_t sample_type,
+                             float* irr, void* stream)
+{
+    if (!s || !pos || !nrm || !shift || !irr) return fail(TEXIR_ERR_INVALID, "texir_diffuse_irradiance: null argument");
+    if (sample_type < 0 || sample_type > 1) return fail(TEXIR_ERR_INVALID, "texir_diffuse_irradiance: sample_type must be uniform(0) or cosine(1)");
+    if (N <= 0 || P < 0 || P >= (1ll << 31)) return fail(TEXIR_ERR_INVALID, "texir_diffuse_irradiance: bad sizes N=%d P=%lld", N, (long long)P);
+    unsigned long long* work = s->d_work + (s->work_next.fetch_add(1) % texir_scene::kWorkSlots);
+    // uniform: (2 pi / N) sum L n.l -- the IrT estimator; cosine: (pi / N) sum L over cosine-distributed directions
+    const int mode = sample_type == 1 ? (1 | 4) : 0;
+    HIP_TRY(launch_irt(s->dev, pos, nrm, shift, nullptr, P, N, mode, irr, nullptr, work, (hipStream_t)stream));
     return TEXIR_OK;
 }
 
@@ -303,12 +318,13 @@ int texir_tex_gather_backward(float* d_tex, float* grad_rest, int32_t H, int32_t
     return TEXIR_OK;
 }
 
-int texir_adam_step_tex(float* param, const float* grad, const float* grad_level1, float* exp_avg, float* exp_avg_sq, float* mip_level1, int32_t H,
-                        int32_t W, int32_t C, float lr, float beta1, float beta2, float eps, int32_t step, float clamp_lo, float clamp_hi, void* stream)
+int texir_adam_step_tex(float* param, const float* grad, const uint32_t* grad_mask, const float* grad_level1, float* exp_avg, float* exp_avg_sq,
+                        float* mip_level1, int32_t H, int32_t W, int32_t C, float lr, float beta1, float beta2, float eps, int32_t step, float clamp_lo,
+                        float clamp_hi, void* stream)
 {
     if (!param || !grad_level1 || !exp_avg || !exp_avg_sq) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex: null argument");
     if (H < 2 || W < 2 || (H & 1) || (W & 1) || C < 1 || C > 4 || step < 1) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex: bad H/W/C/step");
-    HIP_TRY(launch_adam_tex(param, grad, grad_level1, exp_avg, exp_avg_sq, mip_level1, H, W, C, lr, beta1, beta2, eps, step, clamp_lo, clamp_hi, (hipStream_t)stream));
+    HIP_TRY(launch_adam_tex(param, grad, grad_mask, grad_level1, exp_avg, exp_avg_sq, mip_level1, H, W, C, lr, beta1, beta2, eps, step, clamp_lo, clamp_hi, (hipStream_t)stream));
     return TEXIR_OK;
 }
 

@@ -17,9 +17,10 @@ hipError_t launch_trace_shade(const SceneDev& sc, const float* org, const float*
                               uint32_t* prim, float* puv, hipStream_t st);
 hipError_t launch_gen_dir(const float* normals, const float* rough, const float* shift, int64_t b, int N, int mode, float* L, hipStream_t st);
 hipError_t launch_spec_fwd(const SceneDev& sc, const float* normal, const float* albedo, const float* rough, const float* points,
-                           const float* irr, const float* cam, const float* shift, int64_t P, int S, float* rgb, float* Ls_ws, hipStream_t st);
+                           const float* irr, const float* cam, const float* shift, int64_t P, int S, float clamp_eps, int ls_given, float* rgb, float* Ls_ws,
+                           hipStream_t st);
 hipError_t launch_spec_bwd(const float* normal, const float* rough, const float* points, const float* irr, const float* cam,
-                           const float* shift, const float* Ls_ws, const float* d_rgb, int64_t P, int S, float* d_albedo, float* d_rough,
+                           const float* shift, const float* Ls_ws, const float* d_rgb, int64_t P, int S, float clamp_eps, float* d_albedo, float* d_rough,
                            hipStream_t st);
 size_t loss_workspace_bytes(int64_t P, int C, int R);
 hipError_t launch_loss(int stage, int l2, const float* gt, const float* rgb, const float* albedo, const float* rough, const float* rough_womip,
@@ -39,7 +40,8 @@ hipError_t launch_tex_taps(int H, int W, int C, int levels, const float* uv, con
 hipError_t launch_tex_gather_bwd(float* d_tex, float* grad_rest, int H, int W, int C, int levels, const long long* seg_key, const int* seg_start,
                                  const int* seg_count, int n_seg, const int* pix, const float* w, const float* d_out, int trilinear,
                                  int fold_to_level, hipStream_t st);
-hipError_t launch_adam_tex(float* p, const float* g /*nullable*/, const float* g1, float* m, float* v, float* mip1 /*nullable*/, int H, int W, int C, float lr,
+hipError_t launch_adam_tex(float* p, const float* g /*nullable*/, const uint32_t* l0_mask /*nullable*/, const float* g1, float* m, float* v, float* mip1 /*nullable*/,
+                           int H, int W, int C, float lr,
                            float beta1, float beta2, float eps, int step, float lo, float hi, hipStream_t st);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step,
                        float lo, float hi, hipStream_t st);

@@ -47,6 +47,7 @@ __device__ __forceinline__ void irt_stats_flush(unsigned long long* stats, int l
 #define TEXIR_CULL 1
 #endif
 constexpr bool kCull = TEXIR_CULL != 0;
+constexpr int kEstimatorCosine = 4;      // or-ed into the IrT kernels' `mode`: the cosine branch of diffuse_reflectance (mat_nvdiffrast.py:256-257)
 #ifndef TEXIR_GROUP_LSTK
 #define TEXIR_GROUP_LSTK (TEXIR_CULL ? 11 : 16)         // 8-byte entries with culling: 11 x 2 KiB = 22 KiB per block, 7 blocks = 154 of 160 KiB
 #endif
@@ -65,6 +66,8 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_kernel(SceneDev sc, c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + wave, nw = (int64_t)gridDim.x * (kBlock / 64);
     uint32_t c_nodes = 0, c_tris = 0, c_rays = 0, c_hits = 0, wi[2] = {0, 0};
+    const bool cosw = (mode & kEstimatorCosine) != 0;        // diffuse_reflectance's cosine branch: sum L * pi / N, no n.l factor
+    mode &= 3;
     const int passes = (N + 63) >> 6;
     for (int64_t k = gw; k < n_ids; k += nw) {
         const int64_t t = ids ? (int64_t)ids[k] : k;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_kernel(SceneDev sc, c
                     float L[3];
                     shade_hit(sc, h.slot, h.u, h.v, L);
                     // :170 clamp(n . l, 0, 1) with the RAW normal
-                    float ndl = fminf(fmaxf(nx * d[0] + ny * d[1] + nz * d[2], 0.f), 1.f);
+                    float ndl = cosw ? 1.f : fminf(fmaxf(nx * d[0] + ny * d[1] + nz * d[2], 0.f), 1.f);
                     acc0 += L[0] * ndl; acc1 += L[1] * ndl; acc2 += L[2] * ndl;
                     if (STATS) c_hits++;
                 }
@@ -94,11 +97,11 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_kernel(SceneDev sc, c
         }
         acc0 = wave_sum(acc0); acc1 = wave_sum(acc1); acc2 = wave_sum(acc2);
         if (lane == 0) {
-            // :171  sum * 2 * np.pi / N
-            const float pi = 3.141592653589793f;
-            irr[3 * t] = ((acc0 * 2.f) * pi) / (float)N;
-            irr[3 * t + 1] = ((acc1 * 2.f) * pi) / (float)N;
-            irr[3 * t + 2] = ((acc2 * 2.f) * pi) / (float)N;
+            // :171  sum * 2 * np.pi / N      (cosine estimator, mat_nvdiffrast.py:256-257: sum * np.pi / N)
+            const float pi = 3.141592653589793f, two = cosw ? 1.f : 2.f;
+            irr[3 * t] = ((acc0 * two) * pi) / (float)N;
+            irr[3 * t + 1] = ((acc1 * two) * pi) / (float)N;
+            irr[3 * t + 2] = ((acc2 * two) * pi) / (float)N;
         }
     }
     if (STATS) irt_stats_flush(stats, lane, c_rays, c_nodes, c_tris, c_hits, wi[0], wi[1]);
@@ -143,6 +146,8 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
     const int grp = lane >> LOG2M, sub = lane & (M - 1);
     const int n_cells = N >> LOG2M;
     uint32_t cn = 0, ct = 0, c_rays = 0, c_hits = 0, wi[2] = {0, 0};
+    const bool cosw = (mode & kEstimatorCosine) != 0;
+    mode &= 3;
     // A chunk = GRP texels x (all passes / 2^log2parts).  With parts > 1 the raw partial sums go to partial[part][k][3] and
     // irt_combine_kernel adds them in part order: the result depends on N only, never on how the texel list is cut or scheduled.
     const int part_cells = n_cells >> log2parts;
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
                 if (h.slot >= 0 && h.t > 1e-4f) {          // tracer_o3d_irt.py:248
                     float L[3];
                     shade_hit(sc, h.slot, h.u, h.v, L);
-                    float ndl = fminf(fmaxf(nx * d[0] + ny * d[1] + nz * d[2], 0.f), 1.f);       // :170, RAW normal
+                    float ndl = cosw ? 1.f : fminf(fmaxf(nx * d[0] + ny * d[1] + nz * d[2], 0.f), 1.f);       // :170, RAW normal
                     acc0 += L[0] * ndl; acc1 += L[1] * ndl; acc2 += L[2] * ndl;
                     if (STATS) c_hits++;
                 }
@@ -190,10 +195,10 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
                 float* o = partial + ((int64_t)part * n_ids + k) * 3;
                 o[0] = acc0; o[1] = acc1; o[2] = acc2;
             } else {
-                const float pi = 3.141592653589793f;
-                irr[3 * t] = ((acc0 * 2.f) * pi) / (float)N;
-                irr[3 * t + 1] = ((acc1 * 2.f) * pi) / (float)N;
-                irr[3 * t + 2] = ((acc2 * 2.f) * pi) / (float)N;
+                const float pi = 3.141592653589793f, two = cosw ? 1.f : 2.f;
+                irr[3 * t] = ((acc0 * two) * pi) / (float)N;
+                irr[3 * t + 1] = ((acc1 * two) * pi) / (float)N;
+                irr[3 * t + 2] = ((acc2 * two) * pi) / (float)N;
             }
         }
     }
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
 
 // irr[t] = (2 pi / N) * (partial sums of the texel's pass ranges, added in part order)          (tracer_o3d_irt.py:171)
 __global__ __launch_bounds__(256) void irt_combine_kernel(const float* __restrict__ partial, const int32_t* __restrict__ ids, int64_t n_ids,
-                                                          int parts, int N, float* __restrict__ irr)
+                                                          int parts, int N, float two, float* __restrict__ irr)
 {
     const float pi = 3.141592653589793f;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < 3 * n_ids; e += (int64_t)gridDim.x * 256) {
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(256) void irt_combine_kernel(const float* __restric
         float a = partial[e];
         for (int p = 1; p < parts; p++) a += partial[(int64_t)p * n_ids * 3 + e];
         const int64_t t = ids ? (int64_t)ids[k] : k;
-        irr[3 * t + c] = ((a * 2.f) * pi) / (float)N;
+        irr[3 * t + c] = ((a * two) * pi) / (float)N;
     }
 }
 
@@ -318,7 +323,7 @@ struct SpecSample { Dual w; float l[3]; };
 
 // one GGX sample of pixel (n, v, r): returns the reflected direction l and the estimator weight w (+dw/dr)
 __device__ __forceinline__ SpecSample spec_sample(const Frame& f, float nx, float ny, float nz, float vx, float vy, float vz,
-                                                  float r, float s0, float s1)
+                                                  float r, float s0, float s1, float ceps)
 {
     // generate_dir importance branch (sample_util.py:133-143)
     Dual rr = {r, 1.f};
@@ -349,11 +354,11 @@ __device__ __forceinline__ SpecSample spec_sample(const Frame& f, float nx, floa
     Dual fr = {0.04f + 0.96f * p2, 0.96f * p2 * 0.6931471805599453f * e.d};
     Dual kk = dscale(dmul(dadd(rr, dconst(1.f)), dadd(rr, dconst(1.f))), 0.125f);
     Dual omk = dsub(dconst(1.f), kk);
-    Dual g1v = ddiv(dconst(ndv), dclamp_min(dadd(dscale(omk, ndv), kk), 1e-14f));
-    Dual g1l = ddiv(ndl, dclamp_min(dadd(dmul(ndl, omk), kk), 1e-14f));
+    Dual g1v = ddiv(dconst(ndv), dclamp_min(dadd(dscale(omk, ndv), kk), ceps));
+    Dual g1l = ddiv(ndl, dclamp_min(dadd(dmul(ndl, omk), kk), ceps));
     Dual g = dmul(g1l, g1v);
-    Dual brdf = ddiv(dmul(fr, g), dclamp_min(dscale(ndl, 4.f * ndv), 1e-14f));
-    Dual w = ddiv(dmul(dscale(dmul(brdf, ndl), 4.f), vdh), dclamp_min(ndh, 1e-14f));
+    Dual brdf = ddiv(dmul(fr, g), dclamp_min(dscale(ndl, 4.f * ndv), ceps));
+    Dual w = ddiv(dmul(dscale(dmul(brdf, ndl), 4.f), vdh), dclamp_min(ndh, ceps));
     SpecSample o;
     o.w = w;
     for (int k = 0; k < 3; k++) o.l[k] = l[k].v;
@@ -362,13 +367,23 @@ __device__ __forceinline__ SpecSample spec_sample(const Frame& f, float nx, floa
 #pragma clang fp contract(fast)
 
 // lanes-per-pixel = S when S is a power of two <= 64 (several pixels per wave), else 64 with ceil(S/64) passes
+#ifndef TEXIR_SPEC_WAVES
+#define TEXIR_SPEC_WAVES 0
+#endif
 template <bool BWD, int WIDTH>
-__global__ __launch_bounds__(kBlock) void spec_kernel(SceneDev sc, const float* __restrict__ normal, const float* __restrict__ albedo,
+__global__
+#if TEXIR_SPEC_WAVES
+__launch_bounds__(kBlock, TEXIR_SPEC_WAVES)
+#else
+__launch_bounds__(kBlock)
+#endif
+void spec_kernel(SceneDev sc, const float* __restrict__ normal, const float* __restrict__ albedo,
                                                       const float* __restrict__ rough, const float* __restrict__ points,
                                                       const float* __restrict__ irr, const float* __restrict__ cam,
                                                       const float* __restrict__ shift, int64_t P, int S, int lpp,
                                                       float* __restrict__ rgb, float* __restrict__ Ls_ws,
-                                                      const float* __restrict__ d_rgb, float* __restrict__ d_albedo, float* __restrict__ d_rough)
+                                                      const float* __restrict__ d_rgb, float* __restrict__ d_albedo, float* __restrict__ d_rough, float ceps,
+                                                      int ls_given)
 {
     const int lane = threadIdx.x & 63;
     const int ppw = 64 / lpp;                              // pixels per wave
@@ -401,16 +416,22 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(SceneDev sc, const float* 
             if (live && i < S) {
                 float s0 = shift_wrap_clamp(ham0((uint32_t)i, (uint32_t)S), sh0);
                 float s1 = shift_wrap_clamp(ham1((uint32_t)i), sh1);
-                SpecSample ss = spec_sample(f, nx, ny, nz, vx, vy, vz, r, s0, s1);
+                SpecSample ss = spec_sample(f, nx, ny, nz, vx, vy, vz, r, s0, s1, ceps);
                 float L[3] = {0.f, 0.f, 0.f};
                 if (BWD) {
                     const float* lp = Ls_ws + 3 * ((size_t)p * S + i);
                     L[0] = lp[0]; L[1] = lp[1]; L[2] = lp[2];
                     dacc += (L[0] * g0 + L[1] * g1 + L[2] * g2) * ss.w.d;
                 } else {
-                    Hit h = trace_closest<false, kLstk, WIDTH, kCull>(sc, ox, oy, oz, ss.l[0], ss.l[1], ss.l[2], cn, ct);
-                    if (h.slot >= 0 && h.t > 1e-4f) shade_hit(sc, h.slot, h.u, h.v, L);
-                    if (Ls_ws) { float* lp = Ls_ws + 3 * ((size_t)p * S + i); lp[0] = L[0]; lp[1] = L[1]; lp[2] = L[2]; }
+                    if (ls_given) {
+                        // specular_reflectance on the caller's lighting (mat_nvdiffrast.py:260-279 as a function seam): no tracing
+                        const float* lp = Ls_ws + 3 * ((size_t)p * S + i);
+                        L[0] = lp[0]; L[1] = lp[1]; L[2] = lp[2];
+                    } else {
+                        Hit h = trace_closest<false, kLstk, WIDTH, kCull>(sc, ox, oy, oz, ss.l[0], ss.l[1], ss.l[2], cn, ct);
+                        if (h.slot >= 0 && h.t > 1e-4f) shade_hit(sc, h.slot, h.u, h.v, L);
+                        if (Ls_ws) { float* lp = Ls_ws + 3 * ((size_t)p * S + i); lp[0] = L[0]; lp[1] = L[1]; lp[2] = L[2]; }
+                    }
                     acc[0] += L[0] * ss.w.v; acc[1] += L[1] * ss.w.v; acc[2] += L[2] * ss.w.v;
                 }
             }
@@ -534,7 +555,7 @@ hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, co
     else TEXIR_IRT(((n_ids + 63) / 64) << log2parts, pow2 ? l2 : -1, irt_group_kernel, 4, 6)   // any N (natural sample order if not 2^k)
 #undef TEXIR_IRT
     if (log2parts) {
-        hipLaunchKernelGGL(irt_combine_kernel, dim3(grid_for(256, 3 * n_ids)), dim3(256), 0, st, partial, ids, n_ids, 1 << log2parts, N, irr);
+        hipLaunchKernelGGL(irt_combine_kernel, dim3(grid_for(256, 3 * n_ids)), dim3(256), 0, st, partial, ids, n_ids, 1 << log2parts, N, (mode & kEstimatorCosine) ? 1.f : 2.f, irr);
         if ((e = hipFreeAsync(partial, st)) != hipSuccess) return e;
     }
     return hipGetLastError();
@@ -556,25 +577,34 @@ hipError_t launch_gen_dir(const float* normals, const float* rough, const float*
     return hipGetLastError();
 }
 
-static int lanes_per_pixel(int S) { return (S <= 64 && (S & (S - 1)) == 0) ? S : 64; }
+// lanes per pixel: S when S is a power of two <= 64 (one pass), else 64.  TEXIR_SPEC_LPP = 1..64 (a power of two) forces fewer lanes and
+// more passes per pixel: the lanes of a wave then belong to more, neighbouring pixels and take the SAME sample indices in a pass
+// (more coherent rays, fewer and longer waves) -- A/B switch.
+static int lanes_per_pixel(int S)
+{
+    int lpp = (S <= 64 && (S & (S - 1)) == 0) ? S : 64;
+    if (const char* e = getenv("TEXIR_SPEC_LPP")) { const int v = atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0 && v <= lpp) lpp = v; }
+    return lpp;
+}
 
 hipError_t launch_spec_fwd(const SceneDev& sc, const float* normal, const float* albedo, const float* rough, const float* points,
-                           const float* irr, const float* cam, const float* shift, int64_t P, int S, float* rgb, float* Ls_ws, hipStream_t st)
+                           const float* irr, const float* cam, const float* shift, int64_t P, int S, float clamp_eps, int ls_given, float* rgb, float* Ls_ws,
+                           hipStream_t st)
 {
     if (P <= 0) return hipSuccess;
     int lpp = lanes_per_pixel(S);
     int64_t pix_per_block = (int64_t)(kBlock / 64) * (64 / lpp);
-    if (sc.nodes4)
+    if (sc.nodes4 || ls_given)
         hipLaunchKernelGGL((spec_kernel<false, 4>), dim3(grid_for(pix_per_block, P)), dim3(kBlock), 0, st, sc, normal, albedo, rough, points, irr, cam,
-                           shift, P, S, lpp, rgb, Ls_ws, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+                           shift, P, S, lpp, rgb, Ls_ws, (const float*)nullptr, (float*)nullptr, (float*)nullptr, clamp_eps, ls_given);
     else
         hipLaunchKernelGGL((spec_kernel<false, 2>), dim3(grid_for(pix_per_block, P)), dim3(kBlock), 0, st, sc, normal, albedo, rough, points, irr, cam,
-                           shift, P, S, lpp, rgb, Ls_ws, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+                           shift, P, S, lpp, rgb, Ls_ws, (const float*)nullptr, (float*)nullptr, (float*)nullptr, clamp_eps, ls_given);
     return hipGetLastError();
 }
 
 hipError_t launch_spec_bwd(const float* normal, const float* rough, const float* points, const float* irr, const float* cam,
-                           const float* shift, const float* Ls_ws, const float* d_rgb, int64_t P, int S, float* d_albedo, float* d_rough,
+                           const float* shift, const float* Ls_ws, const float* d_rgb, int64_t P, int S, float clamp_eps, float* d_albedo, float* d_rough,
                            hipStream_t st)
 {
     if (P <= 0) return hipSuccess;
@@ -582,7 +612,7 @@ hipError_t launch_spec_bwd(const float* normal, const float* rough, const float*
     int64_t pix_per_block = (int64_t)(kBlock / 64) * (64 / lpp);
     SceneDev none{};
     hipLaunchKernelGGL((spec_kernel<true, 2>), dim3(grid_for(pix_per_block, P)), dim3(kBlock), 0, st, none, normal, (const float*)nullptr, rough,
-                       points, irr, cam, shift, P, S, lpp, (float*)nullptr, const_cast<float*>(Ls_ws), d_rgb, d_albedo, d_rough);
+                       points, irr, cam, shift, P, S, lpp, (float*)nullptr, const_cast<float*>(Ls_ws), d_rgb, d_albedo, d_rough, clamp_eps, 0);
     return hipGetLastError();
 }
 

@@ -296,15 +296,21 @@ __global__ __launch_bounds__(256) void mip_pyr_fold_kernel(float* __restrict__ f
     // ancestors: levels top .. f+K (one texel each for this tile), folded from the top down by the first C threads
     if (K == 5 && (int)threadIdx.x < C) {
         const int c = threadIdx.x;
-        float acc = 0.f;
-        for (int l = top; l >= f + 5; l--) {
-            const int sh = l - f - 5;                           // tile coordinate -> texel of level l (tile = 32 texels of level f = 1 texel of level f+5)
-            const int Y = ty >> sh, X = tx >> sh;
-            const int Wl = d.W >> l;
-            const float g = rest[d.off[l] + ((size_t)Y * Wl + X) * C + c];
-            acc = l == top ? g : __builtin_fmaf(0.25f, acc, g);
+        // (all the loads first -- they are independent -- then the dependent chain of fused multiply-adds)
+        float gl[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int l = top - j;
+            gl[j] = 0.f;
+            if (l >= f + 5) {
+                const int sh = l - f - 5;                       // tile coordinate -> texel of level l (tile = 32 texels of level f = 1 texel of level f+5)
+                gl[j] = rest[d.off[l] + ((size_t)(ty >> sh) * (d.W >> l) + (tx >> sh)) * C + c];
+            }
         }
-        buf[0][c] = acc;                                         // folded level f+K, 1 texel (K == 5) -- see below for K < 5
+        float acc = gl[0];
+#pragma unroll
+        for (int j = 1; j < 16; j++) if (top - j >= f + 5) acc = __builtin_fmaf(0.25f, acc, gl[j]);
+        buf[0][c] = acc;                                         // folded level f+5: the tile's one texel there
     }
     // (K < 5 only for stacks with fewer than six levels above f: then level f+K is the top level and the tile covers all of it)
     int cur = 0;
@@ -631,54 +637,62 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 // Adam over a texture [H,W,C] whose gradient is level 0 + 0.25 * (level-1 gradient of the 2x2 block): the last fold of the mip
 // backward happens here, while the gradient is read anyway (saves one read-modify-write of the finest level per step).
-// Same arithmetic as mip_fold_kernel followed by adam_kernel, bit for bit.  One thread per 2x2 block of texels:
+// Same arithmetic as mip_fold_kernel followed by adam_kernel, bit for bit.
+//   * l0_mask (one bit per texel, nullable): g holds valid values only at the texels whose bit is set (the texels a cached view's
+//     tap lists write -- the buffer is never zero-filled); every other texel's level-0 gradient is zero;
 //   * g == nullptr: the level-0 part of the gradient is identically zero (no pixel of the step sampled mip level 0 -- the usual
 //     case for 4k textures seen through 128^2 cube faces), so it is neither zero-filled nor read (fma(0.25, g1, 0) is the same float);
 //   * mip1 != nullptr: the thread also writes the 2x2 average of the UPDATED texels = level 1 of the next forward's mip stack
 //     (same expression as the mip build), which removes the build's pass over the whole level-0 texture.
 template <int C>
-__global__ __launch_bounds__(256) void adam_tex_kernel(float* __restrict__ p, const float* __restrict__ g, const float* __restrict__ g1,
-                                                       float* __restrict__ m, float* __restrict__ v, float* __restrict__ mip1, int H, int W,
-                                                       float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float lo, float hi)
+__global__ __launch_bounds__(256) void adam_tex_kernel(float* __restrict__ p, const float* __restrict__ g, const uint32_t* __restrict__ l0_mask,
+                                                       const float* __restrict__ g1, float* __restrict__ m, float* __restrict__ v, float* __restrict__ mip1,
+                                                       int H, int W, float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float lo, float hi)
 {
-    const int bx = blockIdx.x * 256 + threadIdx.x;          // 2x2 block column
+    // one thread per (2x2 block column, channel): t = bx * C + ch.  Its level-1 element and its g1 element sit at index t of the
+    // half-resolution row (perfectly coalesced); its four texture elements are rows 2by / 2by+1 at bx * 2C + ch and + C (the two
+    // loads of a row together cover the row densely, every 128-byte line is fetched once).
+    const int t = blockIdx.x * 256 + threadIdx.x;
     const int Wh = W >> 1, Hh = H >> 1;
-    if (bx >= Wh) return;
+    if (t >= Wh * C) return;
+    const int bx = t / C, ch = t - bx * C;
+    const int e0 = bx * 2 * C + ch;
     for (int by = blockIdx.y; by < Hh; by += gridDim.y) {
-        float g1c[C], pn[2][2][C];
-#pragma unroll
-        for (int c = 0; c < C; c++) g1c[c] = g1[((size_t)by * Wh + bx) * C + c];
+        const float g1c = g1[(size_t)by * Wh * C + t];
+        float acc = 0.f;
 #pragma unroll
         for (int r = 0; r < 2; r++) {
-            const size_t i0 = ((size_t)(2 * by + r) * W + 2 * bx) * C;
 #pragma unroll
-            for (int e = 0; e < 2 * C; e++) {
-                const size_t i = i0 + e;
-                const float gi = __builtin_fmaf(0.25f, g1c[e % C], g ? g[i] : 0.f);
+            for (int q = 0; q < 2; q++) {
+                const size_t i = (size_t)(2 * by + r) * W * C + e0 + q * C;
+                float g0 = 0.f;
+                if (g) {
+                    // level-0 gradient: dense (no mask), or only where this view's tap lists wrote one (bit of the texel set)
+                    const size_t texel = (size_t)(2 * by + r) * W + 2 * bx + q;
+                    if (!l0_mask || ((l0_mask[texel >> 5] >> (texel & 31)) & 1u)) g0 = g[i];
+                }
+                const float gi = __builtin_fmaf(0.25f, g1c, g0);
                 float pi = p[i], mi = m[i], vi = v[i];
                 adam_update(pi, gi, mi, vi, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
                 p[i] = pi; m[i] = mi; v[i] = vi;
-                pn[r][e / C][e % C] = pi;
+                acc = (r == 0 && q == 0) ? pi : acc + pi;           // ((a + b) + c) + d, the mip build's order
             }
         }
-        if (mip1) {
-#pragma unroll
-            for (int c = 0; c < C; c++) mip1[((size_t)by * Wh + bx) * C + c] = 0.25f * (pn[0][0][c] + pn[0][1][c] + pn[1][0][c] + pn[1][1][c]);
-        }
+        if (mip1) mip1[(size_t)by * Wh * C + t] = 0.25f * acc;
     }
 }
 
-hipError_t launch_adam_tex(float* p, const float* g, const float* g1, float* m, float* v, float* mip1, int H, int W, int C, float lr, float beta1,
-                           float beta2, float eps, int step, float lo, float hi, hipStream_t st)
+hipError_t launch_adam_tex(float* p, const float* g, const uint32_t* l0_mask, const float* g1, float* m, float* v, float* mip1, int H, int W, int C, float lr,
+                           float beta1, float beta2, float eps, int step, float lo, float hi, hipStream_t st)
 {
     double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     float step_size = (float)((double)lr / bc1);
     float bc2_sqrt = (float)sqrt(bc2);
-    dim3 grid(((W >> 1) + 255) / 256, (H >> 1) > 4096 ? 4096 : (H >> 1));
-    if (C == 1) hipLaunchKernelGGL(adam_tex_kernel<1>, grid, dim3(256), 0, st, p, g, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
-    else if (C == 2) hipLaunchKernelGGL(adam_tex_kernel<2>, grid, dim3(256), 0, st, p, g, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
-    else if (C == 3) hipLaunchKernelGGL(adam_tex_kernel<3>, grid, dim3(256), 0, st, p, g, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
-    else hipLaunchKernelGGL(adam_tex_kernel<4>, grid, dim3(256), 0, st, p, g, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+    dim3 grid(((W >> 1) * C + 255) / 256, (H >> 1) > 4096 ? 4096 : (H >> 1));
+    if (C == 1) hipLaunchKernelGGL(adam_tex_kernel<1>, grid, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+    else if (C == 2) hipLaunchKernelGGL(adam_tex_kernel<2>, grid, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+    else if (C == 3) hipLaunchKernelGGL(adam_tex_kernel<3>, grid, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+    else hipLaunchKernelGGL(adam_tex_kernel<4>, grid, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
     return hipGetLastError();
 }
 

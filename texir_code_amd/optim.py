@@ -28,6 +28,8 @@ class FusedAdam(torch.optim.Optimizer):
             for p in group["params"]:
                 p._texir_grad_l1 = None
                 p._texir_l0_touched = False
+                p._texir_l0_mask = None
+                p._texir_l0_sparse = False
         super().zero_grad(set_to_none=set_to_none)
 
     def release(self):
@@ -64,12 +66,25 @@ class FusedAdam(torch.optim.Optimizer):
                 st["step"] += 1
                 lo, hi = self._clamps.get(id(p), (-math.inf, math.inf))
                 g = None if p.grad is None else p.grad.contiguous()      # None: level-0 gradient identically zero (texture.py backward)
+                mask = None
+                if g1 is not None and getattr(p, "_texir_l0_sparse", False):
+                    # texture.py's sparse level-0 gradient: valid only at the texels of the view's bit mask, in the parameter's own buffer
+                    mask = getattr(p, "_texir_l0_mask", None)
+                    if mask is not None:
+                        if g is None:
+                            g = p._texir_g0
+                        else:
+                            # (another fetch of the same parameter also produced a dense gradient in this backward pass: fold the sparse part in)
+                            H, W, C = p.shape
+                            bits = ((mask.view(-1, 1).to(torch.int64) >> torch.arange(32, device=p.device)) & 1).bool().reshape(-1)[:H * W].reshape(H, W)
+                            g[bits] += p._texir_g0[bits]
+                            mask = None
                 if g1 is not None:
                     H, W, C = p.shape
                     # level 1 of the next forward's mip stack is written on the way (texture._mips_for then builds levels 2.. only)
                     mips = getattr(p, "_texir_mips", None)
                     mip1 = mips[1] if (mips is not None and mips[1].numel() >= (H // 2) * (W // 2) * C and mips[1].device == p.device) else None
-                    _lib.check(L.texir_adam_step_tex(_lib.ptr(p), _lib.ptr(g), _lib.ptr(g1), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]),
+                    _lib.check(L.texir_adam_step_tex(_lib.ptr(p), _lib.ptr(g), _lib.ptr(mask), _lib.ptr(g1), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]),
                                                      _lib.ptr(mip1), H, W, C, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                                      int(st["step"]), lo, hi, _lib.stream_ptr()))
                     p._texir_mip1_version = (p.data_ptr(), p._version) if mip1 is not None else None

@@ -143,14 +143,16 @@ class _SpecRender(torch.autograd.Function):
     """render + specular_reflectance (mat_nvdiffrast.py:201-249,260-279) with its analytic backward."""
 
     @staticmethod
-    def forward(ctx, scene, normal, albedo, rough, points, irr, cam, shift, S):
+    def forward(ctx, scene, normal, albedo, rough, points, irr, cam, shift, S, clamp_eps=1e-14, lighting=None):
         P = normal.shape[0]
         rgb = torch.empty((P, 3), device=normal.device, dtype=torch.float32)
-        Ls = torch.empty((P, S, 3), device=normal.device, dtype=torch.float32)
-        _lib.check(_lib.lib().texir_spec_forward(scene.h, _lib.ptr(normal), _lib.ptr(albedo), _lib.ptr(rough), _lib.ptr(points), _lib.ptr(irr),
-                                                 _lib.ptr(cam), _lib.ptr(shift), P, S, _lib.ptr(rgb), _lib.ptr(Ls), _lib.stream_ptr()))
+        # lighting given: specular_reflectance on the caller's radiance (no tracing); else traced and kept for the backward
+        Ls = torch.empty((P, S, 3), device=normal.device, dtype=torch.float32) if lighting is None else lighting
+        _lib.check(_lib.lib().texir_spec_forward(None if scene is None else scene.h, _lib.ptr(normal), _lib.ptr(albedo), _lib.ptr(rough), _lib.ptr(points),
+                                                 _lib.ptr(irr), _lib.ptr(cam), _lib.ptr(shift), P, S, float(clamp_eps), 0 if lighting is None else 1,
+                                                 _lib.ptr(rgb), _lib.ptr(Ls), _lib.stream_ptr()))
         ctx.save_for_backward(normal, rough, points, irr, cam, shift, Ls)
-        ctx.S = S
+        ctx.S, ctx.clamp_eps = S, float(clamp_eps)
         return rgb
 
     @staticmethod
@@ -162,15 +164,30 @@ class _SpecRender(torch.autograd.Function):
         d_a = torch.empty((P, 3), device=normal.device, dtype=torch.float32) if need_a else None
         d_r = torch.empty((P,), device=normal.device, dtype=torch.float32) if need_r else None
         _lib.check(_lib.lib().texir_spec_backward(_lib.ptr(normal), _lib.ptr(rough), _lib.ptr(points), _lib.ptr(irr), _lib.ptr(cam),
-                                                  _lib.ptr(shift), _lib.ptr(Ls), _lib.ptr(d_rgb), P, ctx.S, _lib.ptr(d_a), _lib.ptr(d_r),
+                                                  _lib.ptr(shift), _lib.ptr(Ls), _lib.ptr(d_rgb), P, ctx.S, ctx.clamp_eps, _lib.ptr(d_a), _lib.ptr(d_r),
                                                   _lib.stream_ptr()))
-        return None, None, d_a, d_r, None, None, None, None, None
+        return None, None, d_a, d_r, None, None, None, None, None, None, None
 
 
-def spec_render(scene, normal, albedo, roughness, points, irr, cam_position, shift, num_samples):
-    """rgb [P,3] = irr*albedo/pi + GGX specular; differentiable wrt albedo [P,3] and roughness [P] / [P,1]."""
-    dev = scene.device
+def spec_render(scene, normal, albedo, roughness, points, irr, cam_position, shift, num_samples, clamp_eps=1e-14, lighting=None):
+    """rgb [P,3] = irr*albedo/pi + GGX specular; differentiable wrt albedo [P,3] and roughness [P] / [P,1].
+    clamp_eps: floor of the BRDF denominators (1e-14 in mat_nvdiffrast.py, 1e-6 in the evaluation model test_nvdiffrast.py).
+    lighting [P,S,3]: use the caller's radiance instead of tracing (the specular_reflectance function seam; scene may be None)."""
+    dev = scene.device if scene is not None else normal.device
     P = normal.reshape(-1, 3).shape[0]
     f = lambda t, s: t.to(device=dev, dtype=torch.float32).reshape(*s).contiguous()
+    S = int(num_samples)
     return _SpecRender.apply(scene, f(normal, (P, 3)), f(albedo, (P, 3)), f(roughness, (P,)), f(points, (P, 3)), f(irr, (P, 3)),
-                             f(cam_position, (3,)), f(shift, (P, 2)), int(num_samples))
+                             f(cam_position, (3,)), f(shift, (P, 2)), S, float(clamp_eps), None if lighting is None else f(lighting, (P, S, 3)))
+
+
+def diffuse_irradiance(scene, points, normals, shift, num_samples, sample_type="uniform"):
+    """the lighting integral of diffuse_reflectance (mat_nvdiffrast.py:252-258): diffuse_reflectance(query_irf(...), l, n, albedo, type)/N
+    == diffuse_irradiance(...) * albedo / pi.  points (already offset) / normals [P,3], shift [P,2] -> [P,3]"""
+    dev = scene.device
+    P = points.reshape(-1, 3).shape[0]
+    f = lambda t, s: t.to(device=dev, dtype=torch.float32).reshape(*s).contiguous()
+    out = torch.empty((P, 3), device=dev, dtype=torch.float32)
+    _lib.check(_lib.lib().texir_diffuse_irradiance(scene.h, _lib.ptr(f(points, (P, 3))), _lib.ptr(f(normals, (P, 3))), _lib.ptr(f(shift, (P, 2))), P,
+                                                   int(num_samples), MODES[sample_type], _lib.ptr(out), _lib.stream_ptr()))
+    return out

@@ -87,10 +87,19 @@ def _tap_lists(cache, H, W, C, levels, mode, uv, uv_da):
     seg_key, counts = torch.unique_consecutive(ks, return_counts=True)
     starts = (torch.cumsum(counts, 0) - counts).to(torch.int32)
     has_l0 = bool(seg_key.numel() > 0 and int(seg_key[0].item()) < H * W)        # keys are sorted: level-0 texels come first
+    l0_mask = None
+    if has_l0:
+        # one bit per level-0 texel these lists write (bit t & 31 of word t >> 5): lets the fused optimiser read the level-0 gradient only
+        # there, so that the (never cleared) gradient buffer needs neither a fill nor a full read per step
+        touched = torch.zeros(((H * W + 31) // 32) * 32, device=uv.device, dtype=torch.bool)
+        touched[seg_key[seg_key < H * W]] = True
+        w = (touched.view(-1, 32).to(torch.int64) << torch.arange(32, device=uv.device, dtype=torch.int64)).sum(1)
+        l0_mask = (w & 0xFFFFFFFF).to(torch.int64)
+        l0_mask = torch.where(l0_mask >= 2 ** 31, l0_mask - 2 ** 32, l0_mask).to(torch.int32).contiguous()
     hit = (seg_key.contiguous(), starts.contiguous(), counts.to(torch.int32).contiguous(), (order // 8).to(torch.int32).contiguous(),
-           wts[order].contiguous(), has_l0)
+           wts[order].contiguous(), has_l0, l0_mask)
     cache[key] = hit
-    _tap_bytes += sum(t.numel() * t.element_size() for t in hit[:5])
+    _tap_bytes += sum(t.numel() * t.element_size() for t in hit[:5]) + (0 if l0_mask is None else l0_mask.numel() * 4)
     return hit
 
 
@@ -141,25 +150,26 @@ class _TexFetch(torch.autograd.Function):
                 g_rest = torch.zeros(n_rest, device=d_out.device, dtype=torch.float32)
         # a deferred fetch over cached tap lists none of which samples level 0 has an identically zero level-0 gradient: it is not
         # materialised at all (no 4 * H * W * C byte fill, and the optimiser does not read it) -- autograd gets None for the texture
-        skip_l0 = bool(defer and ctx.taps is not None and not ctx.taps[5])
-        own_l0 = bool(defer and not skip_l0 and owner.grad is None)
-        if skip_l0:
+        # A deferred fetch over cached tap lists (single process): the level-0 gradient is SPARSE -- only the texels the lists name get a
+        # value, usually none or a handful (4k textures through 128^2 cube faces sample levels >= 3).  It goes to a buffer owned by the
+        # parameter that is never cleared; the view's bit mask (one bit per texel) tells the fused optimiser where to read it.  No
+        # 4*H*W*C-byte fill and no dense read per step, nothing allocated per step or per captured graph; autograd gets None.
+        import torch.distributed as dist
+        sparse_l0 = bool(defer and ctx.taps is not None and owner.grad is None and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1))
+        if sparse_l0:
             d_tex = None
-        elif own_l0:
-            # level 0 is sampled: its gradient also goes to a buffer owned by the parameter (shared by all steps and graphs) and is
-            # attached as .grad directly -- handing a buffer somebody else references to autograd would make it clone 4*H*W*C bytes
-            d_tex = getattr(owner, "_texir_g0", None)
-            if d_tex is None or d_tex.shape != (H, W, C) or d_tex.device != d_out.device:
-                if torch.cuda.is_current_stream_capturing():
-                    raise _lib.TexirError("gradient buffer must be allocated before hipGraph capture (run one eager step first)")
-                d_tex = torch.empty((H, W, C), device=d_out.device, dtype=torch.float32)
-                owner._texir_g0 = d_tex
-            d_tex.zero_()
+            if ctx.taps[5]:
+                d_tex = getattr(owner, "_texir_g0", None)
+                if d_tex is None or d_tex.shape != (H, W, C) or d_tex.device != d_out.device:
+                    if torch.cuda.is_current_stream_capturing():
+                        raise _lib.TexirError("gradient buffer must be allocated before hipGraph capture (run one eager step first)")
+                    d_tex = torch.zeros((H, W, C), device=d_out.device, dtype=torch.float32)
+                    owner._texir_g0 = d_tex
         else:
             d_tex = torch.zeros((H, W, C), device=d_out.device, dtype=torch.float32)
         if ctx.taps is not None:
             # fixed fetch coordinates (a cached view): deterministic gather over the pre-sorted tap lists instead of float atomics
-            seg_key, starts, counts, pix, wts, _ = ctx.taps
+            seg_key, starts, counts, pix, wts = ctx.taps[:5]
             _lib.check(L.texir_tex_gather_backward(_lib.ptr(d_tex), _lib.ptr(g_rest), H, W, C, levels, _lib.ptr(seg_key), _lib.ptr(starts),
                                                    _lib.ptr(counts), seg_key.numel(), _lib.ptr(pix), _lib.ptr(wts), _lib.ptr(d_out), mode,
                                                    1 if defer else 0, _lib.stream_ptr()))
@@ -177,10 +187,10 @@ class _TexFetch(torch.autograd.Function):
             # writes it.  Sticky over the fetches of one backward pass; FusedAdam.zero_grad resets it.
             wrote_l0 = (ctx.taps[5] if ctx.taps is not None else True) if defer else True
             owner._texir_l0_touched = bool(getattr(owner, "_texir_l0_touched", False)) or wrote_l0
-        if own_l0:
-            if owner.grad is None:
-                owner.grad = d_tex
-                return None, None, None, None, None, None, None, None
+        if sparse_l0:
+            owner._texir_l0_mask = ctx.taps[6] if ctx.taps[5] else None      # (None + no .grad: level-0 gradient identically zero)
+            owner._texir_l0_sparse = True
+            return None, None, None, None, None, None, None, None
         return d_tex, None, None, None, None, None, None, None
 
 
