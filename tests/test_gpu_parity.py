@@ -396,7 +396,7 @@ def test_fused_mip_fold_adam_is_bit_identical(tx):
         p = torch.rand(H, W, C, device="cuda")
         m, v = torch.rand_like(p) * 0.1, torch.rand_like(p) * 0.01
         if fused:
-            _lib.check(L.texir_adam_step_tex(_lib.ptr(p), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(m), _lib.ptr(v), None, H, W, C, 3e-2, 0.9, 0.999, 1e-8, 3, 0.0, 0.8,
+            _lib.check(L.texir_adam_step_tex(_lib.ptr(p), _lib.ptr(g0), None, _lib.ptr(g1), _lib.ptr(m), _lib.ptr(v), None, H, W, C, 3e-2, 0.9, 0.999, 1e-8, 3, 0.0, 0.8,
                                              _lib.stream_ptr()))
         else:
             _lib.check(L.texir_adam_step(_lib.ptr(p), _lib.ptr(folded), _lib.ptr(m), _lib.ptr(v), p.numel(), 3e-2, 0.9, 0.999, 1e-8, 3, 0.0, 0.8,
@@ -422,13 +422,13 @@ def test_fused_mip_fold_adam_is_bit_identical(tx):
     assert rel_l2(res[1], res[0]) < 1e-5
 
 
-def test_adam_tex_null_level0_gradient_and_fused_mip_level1(tx):
+def test_adam_tex_null_level0_gradient_and_fused_mip_level1(tx, monkeypatch):
     """texir_adam_step_tex: (a) grad = NULL equals an all-zero level-0 gradient bit for bit; (b) the level-1 texels it writes on the
     way equal texir_mip_build's level 1 of the updated texture bit for bit, and a build continued from them (from_level = 1) equals
     the full build; for C = 1 and 3 and a non-square texture"""
     from texir_code_amd import _lib
     L = _lib.lib()
-    for (H, W, C) in ((64, 64, 3), (128, 32, 1), (256, 256, 3)):
+    for (H, W, C) in ((64, 64, 3), (128, 32, 1), (256, 256, 3), (10, 6, 3), (2048, 1360, 3), (64, 64, 4), (32, 64, 2)):
         levels = int(L.texir_mip_levels(H, W, 13))
         n_rest = int(L.texir_mip_elems(H, W, C, levels))
         torch.manual_seed(H + C)
@@ -440,7 +440,7 @@ def test_adam_tex_null_level0_gradient_and_fused_mip_level1(tx):
             p, m, v = p0.clone(), m0.clone(), v0.clone()
             rest = torch.full((n_rest,), -7.0, device="cuda")
             g0 = None if null_g else torch.zeros(H, W, C, device="cuda")
-            _lib.check(L.texir_adam_step_tex(_lib.ptr(p), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(m), _lib.ptr(v), _lib.ptr(rest), H, W, C, 3e-2, 0.9, 0.999,
+            _lib.check(L.texir_adam_step_tex(_lib.ptr(p), _lib.ptr(g0), None, _lib.ptr(g1), _lib.ptr(m), _lib.ptr(v), _lib.ptr(rest), H, W, C, 3e-2, 0.9, 0.999,
                                              1e-8, 2, 1e-2, 0.8, _lib.stream_ptr()))
             _lib.check(L.texir_mip_build(_lib.ptr(p), _lib.ptr(rest), H, W, C, levels, 1, _lib.stream_ptr()))      # levels 2.. from the fused level 1
             full = torch.empty(n_rest, device="cuda")
@@ -450,6 +450,38 @@ def test_adam_tex_null_level0_gradient_and_fused_mip_level1(tx):
         for a, b in zip(*res):
             assert torch.equal(a, b)
         assert not torch.equal(res[0][0], p0)
+        # (c) a sparse level-0 gradient: garbage everywhere except at the masked texels == the dense gradient that is zero elsewhere
+        torch.manual_seed(3)
+        touched = torch.rand(H * W, device="cuda") < 0.01
+        gd = torch.randn(H, W, C, device="cuda") * touched.reshape(H, W, 1)
+        gs = torch.where(touched.reshape(H, W, 1), gd, torch.full_like(gd, 1e30))           # never-cleared buffer
+        bits = torch.zeros(((H * W + 31) // 32) * 32, device="cuda", dtype=torch.int64)
+        bits[: H * W] = touched.long()
+        w = (bits.view(-1, 32) << torch.arange(32, device="cuda")).sum(1)
+        mask = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
+        outs = []
+        for g0, mk in ((gd, None), (gs, mask)):
+            p, m, v = p0.clone(), m0.clone(), v0.clone()
+            _lib.check(L.texir_adam_step_tex(_lib.ptr(p), _lib.ptr(g0.contiguous()), _lib.ptr(mk), _lib.ptr(g1), _lib.ptr(m), _lib.ptr(v), None, H, W, C, 3e-2, 0.9,
+                                             0.999, 1e-8, 2, 1e-2, 0.8, _lib.stream_ptr()))
+            outs.append((p, m, v))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+        # (d) the 16-byte-access kernel and the one-float-per-access kernel agree bit for bit (rows that are not 16-byte multiples use the latter)
+        both = []
+        for scalar in (False, True):
+            if scalar:
+                monkeypatch.setenv("TEXIR_ADAM_SCALAR", "1")
+            else:
+                monkeypatch.delenv("TEXIR_ADAM_SCALAR", raising=False)
+            p, m, v = p0.clone(), m0.clone(), v0.clone()
+            l1 = torch.zeros((H // 2) * (W // 2) * C, device="cuda")
+            _lib.check(L.texir_adam_step_tex(_lib.ptr(p), _lib.ptr(gs.contiguous()), _lib.ptr(mask), _lib.ptr(g1), _lib.ptr(m), _lib.ptr(v), _lib.ptr(l1), H, W, C,
+                                             3e-2, 0.9, 0.999, 1e-8, 5, 0.0, 0.8, _lib.stream_ptr()))
+            both.append((p, m, v, l1))
+        monkeypatch.delenv("TEXIR_ADAM_SCALAR", raising=False)
+        for a, b in zip(*both):
+            assert torch.equal(a, b)
 
 
 def test_multi_level_mip_kernels_match_the_per_level_reference(tx, monkeypatch):

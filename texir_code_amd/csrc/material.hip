@@ -682,12 +682,79 @@ __global__ __launch_bounds__(256) void adam_tex_kernel(float* __restrict__ p, co
     }
 }
 
+// The same step with 16-byte accesses: a block owns EPB consecutive floats of a row pair (EPB = the largest multiple of 2C <= 1024, so
+// that no 2x2 texel block straddles two blocks), every thread one float4 of each row; the level-1 gradient segment and the updated
+// texels go through LDS so that the level-1 texels come out in the mip build's own summation order ((p00 + p01) + p10) + p11.
+// Needs W*C % 4 == 0 (16-byte aligned rows); launch_adam_tex falls back to adam_tex_kernel otherwise.  Identical bits.
+template <int C>
+__global__ __launch_bounds__(256) void adam_tex_vec_kernel(float* __restrict__ p, const float* __restrict__ g, const uint32_t* __restrict__ l0_mask,
+                                                           const float* __restrict__ g1, float* __restrict__ m, float* __restrict__ v, float* __restrict__ mip1,
+                                                           int H, int W, float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float lo, float hi)
+{
+    constexpr int EPB = (1024 / (2 * C)) * (2 * C);
+    __shared__ float g1s[EPB / 2];
+    __shared__ float ps[2][EPB];
+    const int row_elems = W * C, Wh = W >> 1, Hh = H >> 1;
+    const int e_base = blockIdx.x * EPB;
+    const int n_here = min(EPB, row_elems - e_base);                 // multiple of 2C and of 4
+    const int j4 = threadIdx.x * 4;
+    const bool active = j4 < n_here;
+    const int h_base = e_base / 2, n_half = n_here / 2;              // this block's segment of the half-resolution row
+    for (int by = blockIdx.y; by < Hh; by += gridDim.y) {
+        for (int k = threadIdx.x; k < n_half; k += 256) g1s[k] = g1[(size_t)by * Wh * C + h_base + k];
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const size_t i = (size_t)(2 * by + r) * row_elems + e_base + j4;
+                float4 pv = *reinterpret_cast<const float4*>(p + i), mv = *reinterpret_cast<const float4*>(m + i), vv = *reinterpret_cast<const float4*>(v + i);
+                float pe[4] = {pv.x, pv.y, pv.z, pv.w}, me[4] = {mv.x, mv.y, mv.z, mv.w}, ve[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int el = j4 + q;                           // element inside the block's segment
+                    const int tx = el / C, ch = el - tx * C;
+                    float g0 = 0.f;
+                    if (g) {
+                        const size_t texel = (size_t)(2 * by + r) * W + (e_base / C) + tx;
+                        if (!l0_mask || ((l0_mask[texel >> 5] >> (texel & 31)) & 1u)) g0 = g[i + q];
+                    }
+                    const float gi = __builtin_fmaf(0.25f, g1s[(tx >> 1) * C + ch], g0);
+                    adam_update(pe[q], gi, me[q], ve[q], beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+                    ps[r][el] = pe[q];
+                }
+                *reinterpret_cast<float4*>(p + i) = make_float4(pe[0], pe[1], pe[2], pe[3]);
+                *reinterpret_cast<float4*>(m + i) = make_float4(me[0], me[1], me[2], me[3]);
+                *reinterpret_cast<float4*>(v + i) = make_float4(ve[0], ve[1], ve[2], ve[3]);
+            }
+        }
+        __syncthreads();
+        if (mip1) {
+            for (int k = threadIdx.x; k < n_half; k += 256) {
+                const int txh = k / C, ch = k - txh * C;
+                const int a = (2 * txh) * C + ch;
+                mip1[(size_t)by * Wh * C + h_base + k] = 0.25f * (ps[0][a] + ps[0][a + C] + ps[1][a] + ps[1][a + C]);
+            }
+        }
+        // (the next iteration's first barrier orders these LDS reads before the rewrite of ps; g1s is rewritten before it, and nobody
+        // reads g1s after the barrier above)
+    }
+}
+
 hipError_t launch_adam_tex(float* p, const float* g, const uint32_t* l0_mask, const float* g1, float* m, float* v, float* mip1, int H, int W, int C, float lr,
                            float beta1, float beta2, float eps, int step, float lo, float hi, hipStream_t st)
 {
     double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     float step_size = (float)((double)lr / bc1);
     float bc2_sqrt = (float)sqrt(bc2);
+    if ((W * C) % 4 == 0 && !getenv("TEXIR_ADAM_SCALAR")) {
+        const int epb = (1024 / (2 * C)) * (2 * C);
+        dim3 gridv((W * C + epb - 1) / epb, (H >> 1) > 2048 ? 2048 : (H >> 1));
+        if (C == 1) hipLaunchKernelGGL(adam_tex_vec_kernel<1>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+        else if (C == 2) hipLaunchKernelGGL(adam_tex_vec_kernel<2>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+        else if (C == 3) hipLaunchKernelGGL(adam_tex_vec_kernel<3>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+        else hipLaunchKernelGGL(adam_tex_vec_kernel<4>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+        return hipGetLastError();
+    }
     dim3 grid(((W >> 1) * C + 255) / 256, (H >> 1) > 4096 ? 4096 : (H >> 1));
     if (C == 1) hipLaunchKernelGGL(adam_tex_kernel<1>, grid, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
     else if (C == 2) hipLaunchKernelGGL(adam_tex_kernel<2>, grid, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);

@@ -59,6 +59,46 @@
 #define I_SALU(k) "s_add_u32 s40, s40, 1\n"
 #define I_FMA_SALU(k) "v_fma_f32 %" S(k) ", %" S(k) ", %8, %9\ns_add_u32 s42, s42, 1\n"
 
+#define I_FMA_MAX(k) "v_fma_f32 %" S(k) ", %" S(k) ", %8, %9\nv_max_f32 %" S(k) ", %" S(k) ", %8\n"
+#define I_FMA_CVT(k) "v_fma_f32 %" S(k) ", %" S(k) ", %8, %9\nv_cvt_f32_ubyte0 %" S(k) ", %" S(k) "\n"
+#define I_FMA_CND(k) "v_fma_f32 %" S(k) ", %" S(k) ", %8, %9\nv_cndmask_b32 %" S(k) ", %" S(k) ", %8, s[40:41]\n"
+#define I_FMA_CMP(k) "v_fma_f32 %" S(k) ", %" S(k) ", %8, %9\nv_cmp_lt_f32 s[40:41], %" S(k) ", %8\n"
+#define I_MAX_CVT(k) "v_max_f32 %" S(k) ", %" S(k) ", %8\nv_cvt_f32_ubyte0 %" S(k) ", %" S(k) "\n"
+#define I_FMA2_MAX(k) "v_fma_f32 %" S(k) ", %" S(k) ", %8, %9\nv_mul_f32 %" S(k) ", %" S(k) ", %8\nv_max_f32 %" S(k) ", %" S(k) ", %8\n"
+#define I_FMA3_MAX(k) "v_fma_f32 %" S(k) ", %" S(k) ", %8, %9\nv_mul_f32 %" S(k) ", %" S(k) ", %8\nv_add_f32 %" S(k) ", %" S(k) ", %9\nv_max_f32 %" S(k) ", %" S(k) ", %8\n"
+#define I_AND_OR(k) "v_and_b32 %" S(k) ", %" S(k) ", %8\nv_or_b32 %" S(k) ", %" S(k) ", %9\n"
+#define I_OR(k) "v_or_b32 %" S(k) ", %" S(k) ", %8\n"
+#define I_XOR(k) "v_xor_b32 %" S(k) ", %" S(k) ", %8\n"
+#define I_SUBF(k) "v_sub_f32 %" S(k) ", %" S(k) ", %8\n"
+#define I_SUBU(k) "v_sub_u32 %" S(k) ", %" S(k) ", %8\n"
+#define I_LSHR(k) "v_lshrrev_b32 %" S(k) ", 8, %" S(k) "\n"
+#define I_MINU(k) "v_min_u32 %" S(k) ", %" S(k) ", %8\n"
+#define I_ORSDWA(k) "v_or_b32_sdwa %" S(k) ", %8, %" S(k) " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n"
+#define I_ANDOR3(k) "v_and_or_b32 %" S(k) ", %" S(k) ", %8, %9\n"
+#define I_LSHLOR(k) "v_lshl_or_b32 %" S(k) ", %" S(k) ", 8, %9\n"
+#define I_ADD3(k) "v_add3_u32 %" S(k) ", %" S(k) ", %8, %9\n"
+#define I_CVTPKFP8(k) "v_cvt_f32_fp8 %" S(k) ", %" S(k) "\n"
+#define I_MAXI(k) "v_max_i32 %" S(k) ", %" S(k) ", %8\n"
+KERNEL(k_fma_max, BODY(I_FMA_MAX))
+KERNEL(k_fma_cvt, BODY(I_FMA_CVT))
+KERNEL(k_fma_cnd, BODY(I_FMA_CND))
+KERNEL(k_fma_cmp, BODY(I_FMA_CMP))
+KERNEL(k_max_cvt, BODY(I_MAX_CVT))
+KERNEL(k_fma2_max, BODY(I_FMA2_MAX))
+KERNEL(k_fma3_max, BODY(I_FMA3_MAX))
+KERNEL(k_and_or, BODY(I_AND_OR))
+KERNEL(k_or, BODY(I_OR))
+KERNEL(k_xor, BODY(I_XOR))
+KERNEL(k_subf, BODY(I_SUBF))
+KERNEL(k_subu, BODY(I_SUBU))
+KERNEL(k_lshr, BODY(I_LSHR))
+KERNEL(k_minu, BODY(I_MINU))
+KERNEL(k_orsdwa, BODY(I_ORSDWA))
+KERNEL(k_andor3, BODY(I_ANDOR3))
+KERNEL(k_lshlor, BODY(I_LSHLOR))
+KERNEL(k_add3, BODY(I_ADD3))
+KERNEL(k_cvtfp8, BODY(I_CVTPKFP8))
+KERNEL(k_maxi, BODY(I_MAXI))
 KERNEL(k_fma, BODY(I_FMA))
 KERNEL(k_mul, BODY(I_MUL))
 KERNEL(k_add, BODY(I_ADD))
@@ -104,7 +144,13 @@ int main()
         {"v_cmp + dependent v_cndmask (per instr)", k_cmpcnd, 2}, {"v_cmp + 4 dependent v_cndmask (per instr)", k_cmpcnd4, 5},
         {"v_add_u32", k_addu, 1}, {"v_lshlrev_b32", k_lshl, 1}, {"v_and_b32", k_and, 1}, {"v_bfe_u32", k_bfe, 1}, {"v_perm_b32", k_perm, 1},
         {"v_rcp_f32", k_rcp, 1}, {"v_sqrt_f32", k_sqrt, 1}, {"v_sin_f32", k_sin, 1}, {"v_exp_f32", k_exp, 1}, {"v_mul_lo_u32", k_mullo, 1}, {"v_mad_u32_u24", k_mad24, 1},
-        {"v_mov_b32", k_mov, 1}, {"v_fma_mix_f32", k_fmamix, 1}, {"s_add_u32 (SALU)", k_salu, 1}, {"v_fma_f32 + s_add_u32 interleaved (per pair)", k_fma_salu, 1},
+        {"v_mov_b32", k_mov, 1}, {"v_fma_mix_f32", k_fmamix, 1},
+        {"v_or_b32", k_or, 1}, {"v_xor_b32", k_xor, 1}, {"v_sub_f32", k_subf, 1}, {"v_sub_u32", k_subu, 1}, {"v_lshrrev_b32", k_lshr, 1}, {"v_min_u32", k_minu, 1},
+        {"v_max_i32", k_maxi, 1}, {"v_or_b32_sdwa (src1 BYTE_2)", k_orsdwa, 1}, {"v_and_or_b32", k_andor3, 1}, {"v_lshl_or_b32", k_lshlor, 1}, {"v_add3_u32", k_add3, 1},
+        {"v_cvt_f32_fp8", k_cvtfp8, 1},
+        {"PAIR v_fma + v_max (per pair)", k_fma_max, 1}, {"PAIR v_fma + v_cvt_ubyte (per pair)", k_fma_cvt, 1}, {"PAIR v_fma + v_cndmask (per pair)", k_fma_cnd, 1},
+        {"PAIR v_fma + v_cmp (per pair)", k_fma_cmp, 1}, {"PAIR v_max + v_cvt_ubyte (per pair)", k_max_cvt, 1}, {"TRIPLE fma mul max (per triple)", k_fma2_max, 1},
+        {"QUAD fma mul add max (per quad)", k_fma3_max, 1}, {"PAIR v_and + v_or (per pair)", k_and_or, 1}, {"s_add_u32 (SALU)", k_salu, 1}, {"v_fma_f32 + s_add_u32 interleaved (per pair)", k_fma_salu, 1},
     };
     int cus = 256; hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
     float* out; hipMalloc(&out, sizeof(float) * 256 * cus * 8);
