@@ -134,7 +134,8 @@ TEXIR_API int texir_diffuse_irradiance(const texir_scene* scene, const float* po
  * room_seg_mask [R,6,h,w,1], built at trainer/train_material.py:255-296) are passed in their compact form:
  *   seg_id [P] u8: class of the pixel (255 = none); hl [P] u8: floor_max_mask of the pixel's own class;
  *   room_id [P] u8 (255 = none; stage 2 only, else NULL).
- * stage 0/1/2 as in RenderLoss.forward; loss_type 0 = 'L1', 1 = 'L2' (applies to the rendered-radiance term only).
+ * stage 0/1/2 as in RenderLoss.forward; loss_type 0 = 'L1', 1 = 'L2' (applies to the rendered-radiance term only), 2 = no
+ * rendered-radiance term (SegLoss alone: the psnr / ssim / msssim variants of loss.py:65-73 add their own image term).
  * gt,rgb,albedo [P,3]; rough,rough_womip,empty_mask,gt_mask [P] (all dev; inputs a stage does not read may be NULL).
  * out [2] dev: (total loss, seg term) = the reference's (loss, seg_loss.item()).
  * d_rgb [P,3], d_albedo [P,3] (stage 0), d_rough [P] (stages 1,2): d loss / d input for an upstream gradient of 1

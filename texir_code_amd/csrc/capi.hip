@@ -345,7 +345,7 @@ int texir_loss_forward(int32_t stage, int32_t loss_type, const float* gt, const 
                        float* d_albedo, float* d_rough, void* stream)
 {
     if (stage < 0 || stage > 2) return fail(TEXIR_ERR_INVALID, "texir_loss_forward: stage must be 0, 1 or 2 (got %d)", stage);
-    if (loss_type < 0 || loss_type > 1) return fail(TEXIR_ERR_INVALID, "texir_loss_forward: loss_type must be 0 (L1) or 1 (L2)");
+    if (loss_type < 0 || loss_type > 2) return fail(TEXIR_ERR_INVALID, "texir_loss_forward: loss_type must be 0 (L1), 1 (L2) or 2 (segmentation term only)");
     if (!gt || !rgb || !empty_mask || !seg_id || !workspace || !out || !d_rgb) return fail(TEXIR_ERR_INVALID, "texir_loss_forward: null argument");
     if (P <= 0 || C <= 0 || C > 255) return fail(TEXIR_ERR_INVALID, "texir_loss_forward: bad sizes P=%lld C=%d", (long long)P, C);
     if (stage == 0 && (!albedo || !gt_mask || !d_albedo)) return fail(TEXIR_ERR_INVALID, "texir_loss_forward: stage 0 needs albedo, gt_mask, d_albedo");

@@ -7,6 +7,10 @@
 
 #include "bvh_build.h"
 
+#ifndef TEXIR_FAST_DEQUANT
+#define TEXIR_FAST_DEQUANT 1
+#endif
+
 namespace texir {
 
 struct SceneDev {
@@ -277,6 +281,30 @@ __device__ __forceinline__ void traverse(const SceneDev& sc, RayState& r, typena
                 float key[4]; int code[4] = {ch.x, ch.y, ch.z, ch.w};
                 // the ray's direction signs decide once per node (for all four children at a time: the bytes stay packed) which of
                 // the lo/hi planes is the entry and which the exit plane -- no per-child min/max of the two slab distances
+#if TEXIR_FAST_DEQUANT
+                // gfx950 issues fma / mul / add / sub / and / or / xor / lshr at full rate but cvt, min/max, cmp and cndmask at ~0.6 of it, on
+                // a unit that runs beside the full-rate one (tools/issue_rate.hip): this loop is bound by that slower unit.  So the byte ->
+                // float conversions (24 v_cvt_f32_ubyte per node) and the sign selects are rewritten in full-rate operations:
+                //   byte | 0x4B000000 is the float 2^23 + byte, minus 2^23 gives the byte exactly (bytes 1 / 2 are taken in place, as 256 x
+                //   byte, against a cell size divided by 256); x ^ ((x ^ y) & m) selects with a per-ray mask instead of v_cndmask.
+                // (the instructions are pinned with inline asm: left to itself hipcc re-fuses them into v_bfe_u32 / v_lshl_or_b32 / v_or_b32_sdwa /
+                // v_bitop3_b32 -- all on the slow unit)
+                const uint32_t nx_ = idx < 0.f ? q1.w : q1.x, fx_ = idx < 0.f ? q1.x : q1.w;
+                const uint32_t ny_ = idy < 0.f ? q2.x : q1.y, fy_ = idy < 0.f ? q1.y : q2.x;
+                const uint32_t nz_ = idz < 0.f ? q2.y : q1.z, fz_ = idz < 0.f ? q1.z : q2.y;
+                const float sx8 = sx * 0.00390625f, sy8 = sy * 0.00390625f, sz8 = sz * 0.00390625f;
+                auto unbias = [](uint32_t a) { float f; asm("v_or_b32 %0, 0x4b000000, %1\n\tv_add_f32 %0, 0xcb000000, %0" : "=v"(f) : "v"(a)); return f; };
+                auto b0 = [&](uint32_t p) { uint32_t a; asm("v_and_b32 %0, 0xff, %1" : "=v"(a) : "v"(p)); return unbias(a); };                             // byte 0
+                auto b1 = [&](uint32_t p) { uint32_t a; asm("v_and_b32 %0, 0xff00, %1" : "=v"(a) : "v"(p)); return unbias(a); };                           // 256 x byte 1
+                auto b2 = [&](uint32_t p) { uint32_t a; asm("v_lshrrev_b32 %0, 8, %1\n\tv_and_b32 %0, 0xff00, %0" : "=v"(a) : "v"(p)); return unbias(a); };  // 256 x byte 2
+                auto b3 = [&](uint32_t p) { uint32_t a; asm("v_lshrrev_b32 %0, 24, %1" : "=v"(a) : "v"(p)); return unbias(a); };                           // byte 3
+#define TEXIR_CHILD(k, B, SX, SY, SZ) { \
+                    const float nxt = B(nx_) * SX + bx, fxt = B(fx_) * SX + bx, nyt = B(ny_) * SY + by, fyt = B(fy_) * SY + by, nzt = B(nz_) * SZ + bz, fzt = B(fz_) * SZ + bz; \
+                    const float tn = fmaxf(fmaxf(nxt, nyt), fmaxf(nzt, 0.f)), tf = fminf(fminf(fxt, fyt), fminf(fzt, h.t)); \
+                    key[k] = tn <= tf ? tn : __builtin_inff(); }
+                TEXIR_CHILD(0, b0, sx, sy, sz) TEXIR_CHILD(1, b1, sx8, sy8, sz8) TEXIR_CHILD(2, b2, sx8, sy8, sz8) TEXIR_CHILD(3, b3, sx, sy, sz)
+#undef TEXIR_CHILD
+#else
                 const uint32_t nx_ = idx < 0.f ? q1.w : q1.x, fx_ = idx < 0.f ? q1.x : q1.w;
                 const uint32_t ny_ = idy < 0.f ? q2.x : q1.y, fy_ = idy < 0.f ? q1.y : q2.x;
                 const uint32_t nz_ = idz < 0.f ? q2.y : q1.z, fz_ = idz < 0.f ? q1.z : q2.y;
@@ -291,6 +319,7 @@ __device__ __forceinline__ void traverse(const SceneDev& sc, RayState& r, typena
                     // (unused slots: inverted box, and if ever entered they lead to a degenerate dummy triangle -- no test needed here)
                     key[k] = tn <= tf ? tn : __builtin_inff();
                 }
+#endif
                 // sort the four (key, code) pairs ascending: 5-comparator network
 #define TEXIR_CSWAP(a, b) { bool s_ = key[b] < key[a]; float ka = s_ ? key[b] : key[a], kb = s_ ? key[a] : key[b]; int ca = s_ ? code[b] : code[a], cb = s_ ? code[a] : code[b]; key[a] = ka; key[b] = kb; code[a] = ca; code[b] = cb; }
                 TEXIR_CSWAP(0, 1) TEXIR_CSWAP(2, 3) TEXIR_CSWAP(0, 2) TEXIR_CSWAP(1, 3) TEXIR_CSWAP(1, 2)

@@ -198,7 +198,8 @@ __global__ __launch_bounds__(kLB) void loss_main_kernel(LossArgs a, LossWs ws)
             if (m != 0.f) {
                 float x = a.rgb[3 * p + k] * e * m, y = a.gt[3 * p + k] * m;
                 float d = logf(x + 1.f) - logf(y + 1.f);
-                if (a.l2) { direct += (double)(d * d); g = 2.f * d * kd * e * m / (x + 1.f); }
+                if (a.l2 == 2) {}                                         // segmentation term only: the caller supplies its own image term
+                else if (a.l2) { direct += (double)(d * d); g = 2.f * d * kd * e * m / (x + 1.f); }
                 else { direct += (double)fabsf(d); g = sgnf(d) * kd * e * m / (x + 1.f); }
             }
             a.d_rgb[3 * p + k] = g;

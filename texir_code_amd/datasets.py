@@ -174,6 +174,41 @@ class ImageCubeSyn(ImageCubeDerived):
         return out
 
 
+class ImageCubeNovel(Dataset):
+    """datasets/dataset.py:552-667: no images, a fly-through of 60 cameras -- camera 2 of final_extrinsics.txt moved by (-0.2, 0, -0.6)
+    and then along +x in steps of 6/60 -- each as six cube-face mvps built like ImageCubeDerived's (tester --teststage View)"""
+
+    start_index, offset, direction, num, length = 2, (-0.2, 0.0, -0.6), (1.0, 0.0, 0.0), 60, 6.0
+
+    def __init__(self, path_mesh, resolution=[1000, 2000], hdr_exposure=5.0):
+        super().__init__()
+        self.path_mesh, self.path_root = path_mesh, find_root(path_mesh)
+        self.resolution, self.cube_res, self.hdr_exposure = resolution, int(resolution[1] / 4), hdr_exposure
+        self.ids = []
+        self.extrinsics_list, self.cam_position_list = self.read_extrinsic()
+
+    def __len__(self):
+        return len(self.extrinsics_list)
+
+    def __getitem__(self, index):
+        return {"cam_to_world": self.extrinsics_list[index], "cam_position": self.cam_position_list[index]}
+
+    def read_extrinsic(self):
+        with open(os.path.join(self.path_root, "info", "final_extrinsics.txt"), "r") as f:
+            lines = [l.replace(" \n", "\n") for l in f.readlines()]
+        ext = np.loadtxt(lines[1:], delimiter=" ").reshape(-1, 4, 4)
+        start = ext[min(self.start_index, ext.shape[0] - 1)].astype(np.float32).copy()
+        start[0:3, 3] += np.asarray(self.offset, np.float32)
+        mvps, cams = [], []
+        for i in range(self.num):
+            E = start.copy()
+            E[0:3, 3] += np.asarray(self.direction, np.float32) * np.float32(self.length / self.num * i)
+            mvp, cam = cameras.cube_mvps(E)
+            mvps.append(mvp)
+            cams.append(cam)
+        return mvps, cams
+
+
 def parse_roomseg(path):
     """utils/general.py:115-125"""
     with open(os.path.join(path, "originOccupancyGrid_f0.meta"), "r") as f:
@@ -199,6 +234,14 @@ def write_synthetic_dataset(root, T=20000, texel_res=256, tex_res=256, n_side=2,
     idx = np.zeros((texel_res, texel_res, 3), np.uint16)
     idx[valid[::-1] > 0] = (1, 1, 0)                                               # non-zero code: not a seam; codes unused with texel_gbuffer
     IO.write_png(os.path.join(d, "0.png"), idx[..., ::-1])                        # cv2 stores BGR
+    # class-id texture of the evaluation model (models/test_nvdiffrast.py:79-81): the chart's class in every texel of its rect (+ gutter)
+    seg = np.zeros((texel_res, texel_res), np.uint8)
+    for p in sc["patches"]:
+        x, y, w, h = p.rect
+        c0, c1 = max(0, int(np.floor((x - synth.GUTTER / 2) * texel_res))), min(texel_res, int(np.ceil((x + w + synth.GUTTER / 2) * texel_res)))
+        r0, r1 = max(0, int(np.floor((y - synth.GUTTER / 2) * texel_res))), min(texel_res, int(np.ceil((y + h + synth.GUTTER / 2) * texel_res)))
+        seg[r0:r1, c0:c1] = p.cls
+    IO.write_png(os.path.join(d, "0_seg_gray.png"), np.ascontiguousarray(seg[::-1]))
     cams = cameras.grid_cameras(n_side)
     with open(os.path.join(root, "info", "aligned.txt"), "w") as f:
         f.write("\n".join("view%03d" % i for i in range(len(cams))) + "\n")
@@ -235,6 +278,16 @@ def write_conf(path, root, cube_res=32, spp=(64, 16), albedo_res=256, rough_res=
     roughness_res = %d
     path_mesh_open3d = %s
 }
+test{
+    expname = synthetic
+    dataset_class = datasets.dataset.ImageCubeSyn
+    model_class = models.test_nvdiffrast.MaterialModel
+    irf_loss_class = models.loss.RenderLoss
+    pano_img_res = [%d,%d]
+    sample_light = [%d, %d]
+    hdr_exposure = 0
+    path_mesh_open3d = %s
+}
 render_loss
 {
     loss_type = L1
@@ -246,7 +299,8 @@ models{
     }
 }
 """ % ("models.mat_nvdiffrast.MaterialModel" if model == "mat" else "models.tracer_o3d_irt.TracerO3d", epochs, cube_res * 2, cube_res * 4,
-       spp[0], spp[1], albedo_res, rough_res, os.path.join(root, "vrproc", "hdr_texture", "out1.obj"))
+       spp[0], spp[1], albedo_res, rough_res, os.path.join(root, "vrproc", "hdr_texture", "out1.obj"),
+       cube_res * 2, cube_res * 4, spp[0], max(spp[1], 32), os.path.join(root, "vrproc", "hdr_texture", "out1.obj"))
     with open(path, "w") as f:
         f.write(txt)
 

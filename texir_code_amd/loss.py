@@ -11,6 +11,8 @@ from . import _lib
 
 NO_CLASS = 255
 _LOSS_TYPES = {"L1": 0, "L2": 1}
+# the other image terms of models/loss.py:65-73: evaluated with stock torch ops on top of the fused SegLoss (kernel loss_type 2)
+_VARIANTS = ("psnr", "ssim", "msssim")
 
 
 def compact_masks(seg_mask, floor_max_mask=None, room_seg_mask=None):
@@ -81,10 +83,9 @@ class RenderLoss(nn.Module):
         `seg_loss.item()` forces a host sync every step, which also forbids hipGraph capture of the step)"""
         super().__init__()
         self.lazy_item = lazy_item
-        if loss_type not in _LOSS_TYPES:
-            # psnr / ssim / msssim variants (loss.py:67-75) are evaluation-side options, outside the hot path
-            raise NotImplementedError("RenderLoss loss_type %r is out of scope; use 'L1' or 'L2'" % (loss_type,))
-        print("Using %s loss for comparing re-rendered radiance!" % loss_type)
+        if loss_type not in _LOSS_TYPES and loss_type not in _VARIANTS:
+            raise Exception("Unknown loss_type!")                          # loss.py:76
+        print("Using %s loss for comparing re-rendered radiance!" % {"msssim": "ms-ssim", "psnr": "PSNR"}.get(loss_type, loss_type))
         self.loss_type = loss_type
         self.w_gradient = w_gradient
         self._cache = {}
@@ -108,6 +109,8 @@ class RenderLoss(nn.Module):
         dev = rgb.device
         seg_id, hl, room_id, C, R = self._compact(seg_mask, floor_max_mask, room_seg_mask if stage == 2 else None, dev)
         hw = int(rgb.shape[1] * rgb.shape[2])
+        if self.loss_type in _VARIANTS:
+            return self._variant(gt_img, preds, gt_mask, seg_id, hl, C, stage, hw)
         out = _LossFn.apply(rgb, preds["albedo"] if stage == 0 else None, preds["roughness"] if stage != 0 else None,
                             preds["roughness_womipmap"] if stage == 1 else None, gt_img, preds["empty_mask"], gt_mask if stage == 0 else None,
                             seg_id, hl, room_id if stage == 2 else None, stage, _LOSS_TYPES[self.loss_type], C, R if stage == 2 else 0, hw)
@@ -115,3 +118,25 @@ class RenderLoss(nn.Module):
         if stage == 0:
             return loss, seg_item
         return loss, seg_item, (0. if stage == 1 else 0)
+
+    def _variant(self, gt_img, preds, gt_mask, seg_id, hl, C, stage, hw):
+        """loss_type psnr / ssim / msssim (models/loss.py:65-73,117-140): the image term in stock torch, SegLoss in the fused kernel.
+        The reference's PSNRLoss / SSIMLoss / MSSSIMLoss permute their inputs as [b,h,w,c] images, which only stage 0's tensors are
+        (stages 1 and 2 pass [49,6,h,w,3] products and fail inside permute): the same restriction is kept, with a clear message."""
+        from . import metrics as M
+        from .models import hdr_scale
+        if stage != 0:
+            raise ValueError("RenderLoss(loss_type=%r) supports stage 0 only (the reference's image-shaped losses cannot take the "
+                             "[classes,6,h,w,3] tensors of stages 1 and 2: models/loss.py:101,111,124,132)" % self.loss_type)
+        rgb = preds["rgb"]
+        a = hdr_scale(rgb * preds["empty_mask"] * gt_mask).permute(0, 3, 1, 2)
+        b = hdr_scale(gt_img * gt_mask).permute(0, 3, 1, 2)
+        if self.loss_type == "psnr":
+            direct = -M.mse_to_psnr(torch.mean((b - a) ** 2))
+        elif self.loss_type == "ssim":
+            direct = 1.0 - M.ssim(b, a)
+        else:
+            direct = 1.0 - M.ms_ssim(b, a)
+        out = _LossFn.apply(rgb.detach(), preds["albedo"], None, None, gt_img, preds["empty_mask"], gt_mask, seg_id, hl, None, 0, 2, C, 0, hw)
+        loss, seg_item = direct + out[0], (out[1].detach() if self.lazy_item else out[1].item())
+        return loss, seg_item

@@ -10,6 +10,9 @@ _REGISTRY = {
     "models.loss.RenderLoss": "texir_code_amd.loss.RenderLoss",
     "datasets.dataset.ImageCubeDerived": "texir_code_amd.datasets.ImageCubeDerived",
     "datasets.dataset.ImageCubeSyn": "texir_code_amd.datasets.ImageCubeSyn",
+    # evaluation re-use: the tester runners' model and datasets
+    "models.test_nvdiffrast.MaterialModel": "texir_code_amd.tester.test_model.MaterialModel",
+    "datasets.dataset.ImageCubeNovel": "texir_code_amd.datasets.ImageCubeNovel",
     # NIrF slice
     "models.tracer_o3d_irrf.TracerO3d": "texir_code_amd.nirf.TracerO3dIrrF",
     "models.incidentNet.MatNetwork": "texir_code_amd.nirf.MatNetwork",
@@ -20,7 +23,7 @@ _REGISTRY = {
 
 # everything else the reference registers is a baseline / alternative lighting representation: out of scope
 _OUT_OF_SCOPE = ("models.mat_nvdiffrast_", "models.mat_redner", "models.mat_mlp", "models.tracer_o3d.", "models.tracer_o3d_pil",
-                 "models.incidentNet", "models.test_")
+                 "models.incidentNet", "models.test_redner")
 
 
 def get_class(kls):

@@ -270,5 +270,85 @@ class MatTrainRunner:
 
 
 class MatTrainSynRunner(MatTrainRunner):
-    """trainer/train_material_syn.py: same step loop; the GT-material metrics / novel-view renders that follow it are
-    evaluation output, outside the hot path."""
+    """trainer/train_material_syn.py: the same three-stage loop (its run(), :535-733, is MatTrainRunner.run) followed by the tail
+    `self.model.sample_l[1] = 256; self.render_calculate()` (:735-736): every training view and every novel view re-rendered at 256
+    specular samples and scored against the synthetic ground truth."""
+
+    def postprocessing_materials(self, segs, albedo, roughness):
+        """train_material_syn.py:374-392: lamps (27) and ceiling (43) get fixed materials for all methods"""
+        for cls, a, r in ((27.0, 0.8, 1.0), (43.0, 0.9, 0.8)):
+            m = segs == cls
+            albedo = torch.where(m, torch.full_like(albedo, a), albedo)
+            roughness = torch.where(m, torch.full_like(roughness, r), roughness)
+        return albedo, roughness
+
+    def render_calculate(self, stage=2):
+        """train_material_syn.py:394-523: MSE / PSNR / SSIM of the tone-mapped re-renderings (training and novel views) and of the
+        albedo (least-squares scaled, :440) and roughness panoramas against the dataset's ground truth.  (LPIPS is commented out in
+        the reference and prints 0.)  Returns the numbers it prints."""
+        from .. import metrics as M
+        from ..cube2pano import Cube2Pano
+        self.model.eval()
+        c2p = Cube2Pano(pano_width=self.pano_res[1], pano_height=self.pano_res[0], cube_lenth=self.cube_lenth)
+        c = self.cube_lenth
+
+        def pano(x):
+            return c2p.ToPano(x.detach().cpu().permute(0, 3, 1, 2).reshape(1, -1, c, c))[0].permute(1, 2, 0)
+
+        def ssim_err(a, b):
+            return 1.0 - float(M.ssim(a.unsqueeze(0).permute(0, 3, 1, 2), b.unsqueeze(0).permute(0, 3, 1, 2)))
+
+        def mse(a, b):
+            return float(torch.mean((a - b) ** 2))
+
+        ds = self.train_dataset
+        acc = {k: 0.0 for k in ("mse", "ssim", "albedo_mse", "albedo_ssim", "roughness_mse", "roughness_ssim")}
+        n_mat = 0
+        with torch.no_grad():
+            for i in range(len(ds.ids)):
+                it = ds.images_items[i]
+                gt_img = pano(it["color"])
+                res = self.model(ds.extrinsics_list[i], ds.ids[i], ds.cam_position_list[i].cuda(), stage)
+                pred_img = pano(res["rgb"])
+                acc["ssim"] += ssim_err(M.tonemapping(gt_img), M.tonemapping(pred_img))
+                acc["mse"] += mse(M.tonemapping(gt_img), M.tonemapping(pred_img))
+                if "gt_albedo" in it and "gt_roughness" in it:
+                    segs = it["segs_pano"].expand(-1, -1, 3).float()
+                    pred_albedo, pred_r = pano(res["albedo"]), pano(res["roughness"].expand(-1, -1, -1, 3))
+                    gt_a = it["gt_albedo"]
+                    gt_r = it["gt_roughness"] if it["gt_roughness"].dim() == 3 else it["gt_roughness"].unsqueeze(-1).expand(-1, -1, 3)
+                    pred_albedo, pred_r = self.postprocessing_materials(segs, M.scale_compute(gt_a, pred_albedo) * pred_albedo, pred_r)
+                    acc["albedo_ssim"] += ssim_err(gt_a, torch.clamp(pred_albedo, 0.0, 1.0))
+                    acc["albedo_mse"] += mse(gt_a, torch.clamp(pred_albedo, 0.0, 1.0))
+                    acc["roughness_ssim"] += ssim_err(gt_r, torch.clamp(pred_r, 0.0, 1.0))
+                    acc["roughness_mse"] += mse(gt_r, torch.clamp(pred_r, 0.0, 1.0))
+                    n_mat += 1
+            n = max(1, len(ds.ids))
+            out = {"mse": acc["mse"] / n, "ssim": acc["ssim"] / n}
+            out["psnr"] = float(M.mse_to_psnr(torch.tensor(out["mse"])))
+            print("re-rendering error: mse: {}, psnr: {}, ssim: {}, lpips: {}".format(out["mse"], out["psnr"], out["ssim"], 0.0))
+            for k in ("albedo", "roughness"):
+                if n_mat:
+                    out[k + "_mse"], out[k + "_ssim"] = acc[k + "_mse"] / n_mat, acc[k + "_ssim"] / n_mat
+                    out[k + "_psnr"] = float(M.mse_to_psnr(torch.tensor(out[k + "_mse"])))
+                    print("{} error: mse: {}, psnr: {}, ssim: {}, lpips: {}".format(k, out[k + "_mse"], out[k + "_psnr"], out[k + "_ssim"], 0.0))
+            nv = getattr(ds, "novel_ids", [])
+            if nv:
+                m_, s_ = 0.0, 0.0
+                for i in range(len(nv)):
+                    gt_img = pano(ds.novel_images_items[i]["color"])
+                    res = self.model(ds.novel_extrinsics_list[i], nv[i], ds.novel_cam_position_list[i].cuda(), stage)
+                    pred_img = pano(res["rgb"])
+                    s_ += ssim_err(M.tonemapping(gt_img), M.tonemapping(pred_img))
+                    m_ += mse(M.tonemapping(gt_img), M.tonemapping(pred_img))
+                out["novel_mse"], out["novel_ssim"] = m_ / len(nv), s_ / len(nv)
+                out["novel_psnr"] = float(M.mse_to_psnr(torch.tensor(out["novel_mse"])))
+                print("novel view re-rendering error: mse: {}, psnr: {}, ssim: {}, lpips: {}".format(out["novel_mse"], out["novel_psnr"], out["novel_ssim"], 0.0))
+        self.model.train()
+        self.metrics = out
+        return out
+
+    def run(self):
+        super().run()
+        self.model.sample_l[1] = 256                      # train_material_syn.py:735
+        self.render_calculate()                           # :736

@@ -1,0 +1,19 @@
+#!/bin/bash
+# round-2 GPU session 5: fast (full-rate-unit) dequantisation A/B, new tester / evaluation tests
+R=${GRAFT_REPO_ROOT:-/root/repo}
+out=$R/gpurun_out/r02_s5
+mkdir -p $out
+cd $R
+export TEXIR_SYNTH_CACHE=/tmp/texir_synth
+ab() { label=$1; shift
+  for W in "${WLS[@]}"; do
+    v=$(env "$@" timeout 600 python bench.py --workload $W --steps 2 --warmup 1 --no-cpu --no-mat 2>>$out/ab.err | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel'])" 2>&1 | tail -1)
+    echo "$label $W $v" | tee -a $out/ab.txt
+  done
+}
+WLS=(c4 c2 c4_scan)
+ab fastdq X=1
+ab nofdq TEXIR_HIP_LIB=$R/build_ab/libtexir_hip_nofdq.so
+ab fastdq_again X=1
+timeout 2400 python -m pytest tests/test_gpu_tester.py tests/test_gpu_parity.py tests/test_gpu_watertight.py -m gpu -q > $out/pytest_gpu.txt 2>&1
+tail -n 30 $out/pytest_gpu.txt | cut -c1-220
