@@ -226,6 +226,14 @@ TEXIR_API int texir_adam_step_tex(float* param, const float* grad /*nullable: le
                        int32_t H, int32_t W, int32_t C, float lr, float beta1, float beta2, float eps, int32_t step, float clamp_lo,
                        float clamp_hi, void* stream);
 
+/* ---- host-side codec loops of the file formats around the path (both take HOST pointers) ----------------------------
+ * PNG scanline un-filtering (filters 0-4, PNG spec 9.2) of zlib-inflated IDAT data: raw [H][stride+1] -> out [H][stride]; replaces the
+ * decode half of cv2.imread("0.png", -1) (models/tracer_o3d_irt.py:91, datasets/dataset.py:489-492). */
+TEXIR_API int texir_png_unfilter(const uint8_t* raw /*host*/, int32_t H, int32_t stride, int32_t bytes_per_pixel, uint8_t* out /*host*/);
+/* Radiance .hdr scanlines (flat or new-style RLE, per scanline) after the resolution line -> RGBE bytes [H][W][4]; returns the bytes
+ * consumed (< 0: error).  Replaces the decode half of cv2.imread(".hdr", -1) (models/tracer_o3d_irt.py:77, datasets/dataset.py:480). */
+TEXIR_API int64_t texir_hdr_decode_scanlines(const uint8_t* data /*host*/, int64_t n, int32_t W, int32_t H, uint8_t* rgbe /*host*/);
+
 #ifdef __cplusplus
 }
 #endif

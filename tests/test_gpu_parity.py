@@ -233,8 +233,8 @@ def test_render_loss_rejects_non_onehot_masks(golden, tx):
     seg[1] = 1
     with pytest.raises(ValueError):
         compact_masks(seg)
-    with pytest.raises(NotImplementedError):
-        RenderLoss(loss_type="ssim")
+    with pytest.raises(Exception):
+        RenderLoss(loss_type="huber")            # models/loss.py:76: only L1 / L2 / psnr / ssim / msssim exist
 
 
 def test_texture_fetch_fwd_bwd_vs_torch_restatement(tx):

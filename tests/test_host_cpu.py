@@ -191,3 +191,100 @@ def test_denoise_standin_removes_noise_keeps_edges_and_seams():
     v = clean > 0
     assert np.abs(out - clean)[v].mean() < 0.4 * np.abs(noisy - clean)[v].mean()          # noise down by > 2.5x
     assert abs(out[:, :28].mean() - 1.0) < 0.05 and abs(out[:, 36:].mean() - 4.0) < 0.1   # the edge did not bleed
+
+
+def _png_filtered(path, img, filters):
+    """test-side PNG writer that applies scanline filter `filters[y % len]` (0 None, 1 Sub, 2 Up, 3 Average, 4 Paeth; PNG spec 9.2), the way
+    libpng / cv2.imwrite pick them adaptively"""
+    import struct
+    import zlib
+    img = np.ascontiguousarray(img)
+    H, W, C = img.shape
+    depth = 16 if img.dtype == np.uint16 else 8
+    bpp = C * depth // 8
+    raw = np.frombuffer(img.astype(">u2" if depth == 16 else np.uint8).tobytes(), np.uint8).reshape(H, -1).astype(np.int32)
+    lines = bytearray()
+    prev = np.zeros(raw.shape[1], np.int32)
+    for y in range(H):
+        cur, ft = raw[y], filters[y % len(filters)]
+        a = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+        c = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+        if ft == 0:
+            pred = 0
+        elif ft == 1:
+            pred = a
+        elif ft == 2:
+            pred = prev
+        elif ft == 3:
+            pred = (a + prev) >> 1
+        else:
+            p = a + prev - c
+            pa, pb, pc = np.abs(p - a), np.abs(p - prev), np.abs(p - c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+        lines += bytes([ft]) + ((cur - pred) & 255).astype(np.uint8).tobytes()
+        prev = cur
+    chunk = lambda tag, payload: struct.pack(">I", len(payload)) + tag + payload + struct.pack(">I", zlib.crc32(tag + payload) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, depth, {1: 0, 3: 2, 4: 6}[C], 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(bytes(lines), 6)) + chunk(b"IEND", b""))
+
+
+def test_png_adaptive_filters_palette_and_rle_hdr(tmp_path):
+    """the decoders must read what cv2 / libpng actually write: 16-bit PNGs with Sub / Up / Average / Paeth scanlines (the
+    index texture 0.png), palette PNGs, and new-style RLE Radiance files -- through the library's C++ codec loops"""
+    import struct
+    import zlib
+    from texir_code_amd import io_formats as IO
+    rng = np.random.default_rng(3)
+    for dtype, C in ((np.uint16, 3), (np.uint8, 4), (np.uint8, 1), (np.uint16, 1)):
+        img = rng.integers(0, 65535 if dtype == np.uint16 else 255, (37, 53, C)).astype(dtype)
+        img[5:20, 7:30] = img[5, 7]                      # flat region: filters produce runs
+        p = str(tmp_path / ("f_%s_%d.png" % (np.dtype(dtype).name, C)))
+        _png_filtered(p, img, [4, 1, 2, 3, 0, 4, 4])
+        assert np.array_equal(IO.read_png(p), img)
+    # palette image (colour type 3) -> RGB
+    pal = rng.integers(0, 255, (7, 3)).astype(np.uint8)
+    idx = rng.integers(0, 7, (9, 11)).astype(np.uint8)
+    chunk = lambda tag, payload: struct.pack(">I", len(payload)) + tag + payload + struct.pack(">I", zlib.crc32(tag + payload) & 0xFFFFFFFF)
+    raw = b"".join(b"\x00" + idx[y].tobytes() for y in range(9))
+    p = str(tmp_path / "pal.png")
+    with open(p, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 11, 9, 8, 3, 0, 0, 0)) + chunk(b"PLTE", pal.tobytes())
+                + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    assert np.array_equal(IO.read_png(p), pal[idx])
+    # new-style RLE .hdr: every scanline = (2, 2, W>>8, W&255) + 4 channel planes of runs / literals
+    H, W = 6, 40
+    rgbe = rng.integers(0, 255, (H, W, 4)).astype(np.uint8)
+    rgbe[:, 5:30, :] = rgbe[:, 5:6, :]                   # long runs
+    body = bytearray()
+    for y in range(H):
+        body += bytes([2, 2, W >> 8, W & 255])
+        for c in range(4):
+            x = 0
+            row = rgbe[y, :, c]
+            while x < W:
+                n = 1
+                while x + n < W and n < 127 and row[x + n] == row[x]:
+                    n += 1
+                if n >= 3:
+                    body += bytes([128 + n, row[x]])
+                else:
+                    n = min(8, W - x)
+                    body += bytes([n]) + row[x:x + n].tobytes()
+                x += n
+    p = str(tmp_path / "rle.hdr")
+    with open(p, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n" + ("-Y %d +X %d\n" % (H, W)).encode() + bytes(body))
+    assert np.array_equal(IO.read_hdr(p), IO.rgbe_decode(rgbe))
+    # roomSegs: the reference keeps cv2's channel 0 = BLUE of the colour image (utils/general.py:121-123)
+    import os
+    from texir_code_amd import datasets as D
+    d = tmp_path / "roomseg"
+    os.makedirs(d)
+    with open(d / "originOccupancyGrid_f0.meta", "w") as f:
+        f.write("0.05 8 6 -1 -2\n")
+    col = np.zeros((6, 8, 3), np.uint8)
+    col[..., 0], col[..., 1], col[..., 2] = 10, 20, 30     # R, G, B
+    IO.write_png(str(d / "roomSegs_uchar_f0.png"), col)
+    room = D.parse_roomseg(str(d))[-1]
+    assert room.shape == (1, 1, 6, 8) and float(room.unique()) == 30.0

@@ -67,6 +67,9 @@ def lib():
         L.texir_mip_elems.restype = i64
         L.texir_loss_workspace_bytes.argtypes = [i64, i32, i32]
         L.texir_loss_workspace_bytes.restype = i64
+        sig["texir_png_unfilter"] = [vp, i32, i32, i32, vp]
+        L.texir_hdr_decode_scanlines.argtypes = [vp, i64, i32, i32, vp]
+        L.texir_hdr_decode_scanlines.restype = i64
         for name, args in sig.items():
             fn = getattr(L, name)
             fn.argtypes = args

@@ -189,10 +189,30 @@ void emit4_fill(GpuNode4& g, const Box& nb, const Tmp* const* kids, int nk, cons
     g.lox = lo[0]; g.loy = lo[1]; g.loz = lo[2]; g.hix = hi[0]; g.hiy = hi[1]; g.hiz = hi[2];
 }
 
+#if TEXIR_NODE_F32
+static std::vector<GpuNode4F>* g_out4f = nullptr;
+
+static void emit4f_fill(GpuNode4F& g, const Tmp* const* kids, int nk, const int32_t* codes, int32_t dummy_leaf)
+{
+    for (int k = 0; k < 4; k++) {
+        for (int a = 0; a < 3; a++) {
+            // unused slot: inverted box.  Used slot: the child's box widened by the absolute slack, rounded outwards
+            g.plane[2 * a][k] = k < nk ? std::nextafter((float)((double)kids[k]->box.mn[a] - (double)g_slack), -FLT_MAX) : 1e30f;
+            g.plane[2 * a + 1][k] = k < nk ? std::nextafter((float)((double)kids[k]->box.mx[a] + (double)g_slack), FLT_MAX) : -1e30f;
+        }
+        g.c[k] = k < nk ? codes[k] : dummy_leaf;
+        g.pad[k] = 0;
+    }
+}
+#endif
+
 int32_t emit4(const Tmp* t, std::vector<GpuNode4>& out, int depth, int& max_depth, int32_t dummy_leaf)
 {
     int32_t idx = (int32_t)out.size();
     out.emplace_back();
+#if TEXIR_NODE_F32
+    g_out4f->emplace_back();
+#endif
     if (depth > max_depth) max_depth = depth;
     const Tmp* kids[4]; int nk = 0;
     if (t->count) { kids[nk++] = t; }                      // degenerate root leaf
@@ -207,6 +227,9 @@ int32_t emit4(const Tmp* t, std::vector<GpuNode4>& out, int depth, int& max_dept
     int32_t codes[4];
     for (int k = 0; k < nk; k++) codes[k] = kids[k]->count ? leaf_code(kids[k]) : emit4(kids[k], out, depth + 1, max_depth, dummy_leaf);
     emit4_fill(out[idx], t->box, kids, nk, codes, dummy_leaf);
+#if TEXIR_NODE_F32
+    emit4f_fill((*g_out4f)[idx], kids, nk, codes, dummy_leaf);
+#endif
     return idx;
 }
 
@@ -255,6 +278,11 @@ void build_bvh(const float* verts, int V, const int32_t* tris, int T, const floa
     out.nodes4.clear();
     out.nodes4.reserve((size_t)T / 2 + 16);
     int d4 = 0;
+#if TEXIR_NODE_F32
+    out.nodes4f.clear();
+    out.nodes4f.reserve((size_t)T / 2 + 16);
+    g_out4f = &out.nodes4f;
+#endif
     // slot T holds a degenerate (all-zero) triangle: the target of unused child slots
     const int32_t dummy_leaf = ~(int32_t)(((uint32_t)T << 3) | 0u);
     emit4(root.get(), out.nodes4, 1, d4, dummy_leaf);

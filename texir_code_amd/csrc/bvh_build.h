@@ -53,6 +53,20 @@ struct alignas(16) GpuNode4 {
 };
 static_assert(sizeof(GpuNode4) == 64, "wide node must be 64 bytes");
 
+// TEXIR_NODE_F32 = 1: the same 4-wide tree with full float child boxes, 128 bytes per node (A/B variant: no byte -> float conversion
+// and no sign select in the node step -- the near / far planes are picked by per-ray load offsets -- for twice the node bytes):
+//   f0..f5 = (lo.x[4], hi.x[4], lo.y[4], hi.y[4], lo.z[4], hi.z[4])   one float per child, child k in lane k
+//   f6     = (child0..3),  f7 = padding
+#ifndef TEXIR_NODE_F32
+#define TEXIR_NODE_F32 0
+#endif
+struct alignas(16) GpuNode4F {
+    float plane[6][4];
+    int32_t c[4];
+    int32_t pad[4];
+};
+static_assert(sizeof(GpuNode4F) == 128, "float wide node must be 128 bytes");
+
 constexpr int32_t kEmptyChild = INT32_MIN;   // child slot with an inverted box, never entered
 constexpr int kMaxLeaf = 2;
 constexpr int kMaxDepth = 60;                // traversal stack bound (LDS part + private overflow)
@@ -60,6 +74,7 @@ constexpr int kMaxDepth = 60;                // traversal stack bound (LDS part 
 struct BvhHost {
     std::vector<GpuNode> nodes;
     std::vector<GpuNode4> nodes4;
+    std::vector<GpuNode4F> nodes4f;     // filled (index-for-index with nodes4) when TEXIR_NODE_F32
     std::vector<GpuTri> tris;
     std::vector<GpuTriUV> uvs;
     int max_depth = 0, max_depth4 = 0;

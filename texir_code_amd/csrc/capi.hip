@@ -62,7 +62,7 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
     if (!verts || !tris || !tri_uvs || !hdr_tex || !out) return fail(TEXIR_ERR_INVALID, "texir_scene_create: null argument");
     if (V <= 0 || T <= 0 || Ht <= 0 || Wt <= 0) return fail(TEXIR_ERR_INVALID, "texir_scene_create: empty mesh or texture");
     // the traversal addresses nodes and triangles with 32-bit byte offsets (64-byte nodes, 48-byte triangle records)
-    if ((uint64_t)(T + 1) * 48u >= (1ull << 32)) return fail(TEXIR_ERR_INVALID, "texir_scene_create: too many triangles (%d; limit 89 M)", (int)T);
+    if ((uint64_t)(T + 1) * 48u >= (1ull << 32) || (TEXIR_NODE_F32 && (uint64_t)T * 64u >= (1ull << 32))) return fail(TEXIR_ERR_INVALID, "texir_scene_create: too many triangles (%d; limit 89 M)", (int)T);
     for (int64_t i = 0; i < 3 * (int64_t)T; i++)
         if (tris[i] < 0 || tris[i] >= V) return fail(TEXIR_ERR_INVALID, "texir_scene_create: triangle index %d out of range", (int)tris[i]);
     HIP_TRY(hipSetDevice(device));
@@ -83,8 +83,13 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
     s->width = (want_w == 4 && 3 * h.max_depth4 + 2 <= kStackCap) ? 4 : 2;
     if (s->width == 4) {
         s->n_nodes4 = (int64_t)h.nodes4.size(); s->max_depth = h.max_depth4;
+#if TEXIR_NODE_F32
+        if ((e = hipMalloc(&s->d_nodes4, h.nodes4f.size() * sizeof(GpuNode4F))) != hipSuccess) return bail(e, "hipMalloc nodes4");
+        if ((e = hipMemcpy(s->d_nodes4, h.nodes4f.data(), h.nodes4f.size() * sizeof(GpuNode4F), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload nodes4");
+#else
         if ((e = hipMalloc(&s->d_nodes4, h.nodes4.size() * sizeof(GpuNode4))) != hipSuccess) return bail(e, "hipMalloc nodes4");
         if ((e = hipMemcpy(s->d_nodes4, h.nodes4.data(), h.nodes4.size() * sizeof(GpuNode4), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload nodes4");
+#endif
     }
     if ((e = hipMalloc(&s->d_nodes, h.nodes.size() * sizeof(GpuNode))) != hipSuccess) return bail(e, "hipMalloc nodes");
     if ((e = hipMalloc(&s->d_tris, h.tris.size() * sizeof(GpuTri))) != hipSuccess) return bail(e, "hipMalloc tris");
@@ -142,7 +147,7 @@ int texir_scene_info(const texir_scene* s, int64_t out[8])
 {
     if (!s || !out) return fail(TEXIR_ERR_INVALID, "texir_scene_info: null argument");
     out[0] = s->width == 4 ? s->n_nodes4 : s->n_nodes; out[1] = s->n_tris; out[2] = s->max_depth;
-    out[3] = s->width == 4 ? s->n_nodes4 * (int64_t)sizeof(GpuNode4) : s->n_nodes * (int64_t)sizeof(GpuNode);
+    out[3] = s->width == 4 ? s->n_nodes4 * (int64_t)(TEXIR_NODE_F32 ? sizeof(GpuNode4F) : sizeof(GpuNode4)) : s->n_nodes * (int64_t)sizeof(GpuNode);
     out[4] = s->n_tris * (int64_t)sizeof(GpuTri); out[5] = s->n_tris * (int64_t)sizeof(GpuTriUV); out[6] = (int64_t)(s->d_tex_tiled ? s->tiled_bytes : s->tex_bytes); out[7] = s->device;
     return TEXIR_OK;
 }

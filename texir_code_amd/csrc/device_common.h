@@ -7,8 +7,10 @@
 
 #include "bvh_build.h"
 
+// 1: byte -> float conversions of the node step rewritten in full-rate operations (see traverse).  Measured -10 % (c4 13.7 vs 15.2
+// Grays/s, profiles/r02): kept as a documented experiment, off.
 #ifndef TEXIR_FAST_DEQUANT
-#define TEXIR_FAST_DEQUANT 1
+#define TEXIR_FAST_DEQUANT 0
 #endif
 
 namespace texir {
@@ -176,6 +178,9 @@ struct RayState {
 #if TEXIR_TRI_WATERTIGHT
     float mx[3], my[3], mz[3];       // rows of the ray-space shear: x' = A . mx, y' = A . my, z' = A . mz (A = vertex - origin)
 #endif
+#if TEXIR_NODE_F32
+    uint32_t offn[3];                // byte offset of the NEAR plane array of each axis inside a 128-byte float node (far = offset ^ 16)
+#endif
     Hit h;
     int node, sp;
 };
@@ -190,6 +195,9 @@ __device__ __forceinline__ void ray_begin(RayState& r, float ox, float oy, float
     r.oodx = ox * r.idx; r.oody = oy * r.idy; r.oodz = oz * r.idz;
     r.h.t = __builtin_inff(); r.h.u = 0.f; r.h.v = 0.f; r.h.slot = -1;
     r.node = 0; r.sp = 0;
+#if TEXIR_NODE_F32
+    r.offn[0] = r.idx < 0.f ? 16u : 0u; r.offn[1] = r.idy < 0.f ? 48u : 32u; r.offn[2] = r.idz < 0.f ? 80u : 64u;
+#endif
 #if TEXIR_TRI_WATERTIGHT
     {
         // kz = dominant axis of the direction, (kx, ky) the other two in an order that keeps the winding; the shear maps d to (0, 0, 1)
@@ -268,6 +276,28 @@ __device__ __forceinline__ void traverse(const SceneDev& sc, RayState& r, typena
         if (Leave::never ? node == kSentinel : (!__any(node != kSentinel) || leave(node))) break;
         if (WIDTH == 4) {
             while (node >= 0 && node != kSentinel) {
+#if TEXIR_NODE_F32
+                // full-float child boxes: the six plane arrays are fetched through per-ray offsets (near = the lo array if the direction
+                // component is positive, else the hi array), so the step has neither conversions nor selects: 24 fma + min/max
+                // (uniform base + ONE 32-bit byte offset per load: saddr-form loads, one full-rate add each)
+                const char* const nbase = reinterpret_cast<const char*>(sc.nodes4);
+                const uint32_t no = (uint32_t)node << 7;
+                auto ld = [&](uint32_t off) { return *reinterpret_cast<const float4*>(nbase + (no + off)); };
+                const float4 pnx = ld(r.offn[0]), pfx = ld(r.offn[0] ^ 16u), pny = ld(r.offn[1]), pfy = ld(r.offn[1] ^ 16u);
+                const float4 pnz = ld(r.offn[2]), pfz = ld(r.offn[2] ^ 16u);
+                const int4 ch = *reinterpret_cast<const int4*>(nbase + (no + 96u));
+                if (STATS) { n_nodes++; if (wave_iters && first_active()) wave_iters[0]++; }
+                float key[4]; int code[4] = {ch.x, ch.y, ch.z, ch.w};
+                const float nxa[4] = {pnx.x, pnx.y, pnx.z, pnx.w}, fxa[4] = {pfx.x, pfx.y, pfx.z, pfx.w}, nya[4] = {pny.x, pny.y, pny.z, pny.w};
+                const float fya[4] = {pfy.x, pfy.y, pfy.z, pfy.w}, nza[4] = {pnz.x, pnz.y, pnz.z, pnz.w}, fza[4] = {pfz.x, pfz.y, pfz.z, pfz.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float nxt = nxa[k] * idx - oodx, fxt = fxa[k] * idx - oodx, nyt = nya[k] * idy - oody, fyt = fya[k] * idy - oody;
+                    const float nzt = nza[k] * idz - oodz, fzt = fza[k] * idz - oodz;
+                    const float tn = fmaxf(fmaxf(nxt, nyt), fmaxf(nzt, 0.f)), tf = fminf(fminf(fxt, fyt), fminf(fzt, h.t));
+                    key[k] = tn <= tf ? tn : __builtin_inff();
+                }
+#else
                 // (uniform base + 32-bit byte offset: one VALU op of address arithmetic, saddr-form loads)
                 const float4* np = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.nodes4) + ((uint32_t)node << 6));
                 const float4 q0 = np[0];
@@ -282,9 +312,10 @@ __device__ __forceinline__ void traverse(const SceneDev& sc, RayState& r, typena
                 // the ray's direction signs decide once per node (for all four children at a time: the bytes stay packed) which of
                 // the lo/hi planes is the entry and which the exit plane -- no per-child min/max of the two slab distances
 #if TEXIR_FAST_DEQUANT
-                // gfx950 issues fma / mul / add / sub / and / or / xor / lshr at full rate but cvt, min/max, cmp and cndmask at ~0.6 of it, on
-                // a unit that runs beside the full-rate one (tools/issue_rate.hip): this loop is bound by that slower unit.  So the byte ->
-                // float conversions (24 v_cvt_f32_ubyte per node) and the sign selects are rewritten in full-rate operations:
+                // EXPERIMENT (off, -10 %).  gfx950 issues fma / mul / add / sub / and / or / xor / lshr at full rate but cvt, min/max, cmp and
+                // cndmask at ~0.6 of it; a stream that alternates the two classes overlaps them almost completely (tools/issue_rate.hip).  If
+                // this loop were bound by the slower class alone, trading each v_cvt_f32_ubyte for ~3 full-rate operations would pay: it does
+                // not -- the classes share issue, and the instruction count decides.
                 //   byte | 0x4B000000 is the float 2^23 + byte, minus 2^23 gives the byte exactly (bytes 1 / 2 are taken in place, as 256 x
                 //   byte, against a cell size divided by 256); x ^ ((x ^ y) & m) selects with a per-ray mask instead of v_cndmask.
                 // (the instructions are pinned with inline asm: left to itself hipcc re-fuses them into v_bfe_u32 / v_lshl_or_b32 / v_or_b32_sdwa /
@@ -319,6 +350,7 @@ __device__ __forceinline__ void traverse(const SceneDev& sc, RayState& r, typena
                     // (unused slots: inverted box, and if ever entered they lead to a degenerate dummy triangle -- no test needed here)
                     key[k] = tn <= tf ? tn : __builtin_inff();
                 }
+#endif
 #endif
                 // sort the four (key, code) pairs ascending: 5-comparator network
 #define TEXIR_CSWAP(a, b) { bool s_ = key[b] < key[a]; float ka = s_ ? key[b] : key[a], kb = s_ ? key[a] : key[b]; int ca = s_ ? code[b] : code[a], cb = s_ ? code[a] : code[b]; key[a] = ka; key[b] = kb; code[a] = ca; code[b] = cb; }

@@ -214,7 +214,10 @@ def parse_roomseg(path):
     with open(os.path.join(path, "originOccupancyGrid_f0.meta"), "r") as f:
         s, w, h, xmin, zmin = f.readline().strip().split(" ")
     img = IO.read_png(os.path.join(path, "roomSegs_uchar_f0.png")).astype(np.float32)
-    room = torch.from_numpy(img)[:, :, 0:1].unsqueeze(0).permute(0, 3, 1, 2)
+    if img.shape[2] == 1:
+        img = np.repeat(img, 3, axis=2)
+    # the reference reads the file with cv2.imread (3 channels, BGR order) and keeps channel 0, i.e. BLUE (utils/general.py:121-123)
+    room = torch.from_numpy(np.ascontiguousarray(img[:, :, 2:3])).unsqueeze(0).permute(0, 3, 1, 2)
     return float(s), float(w), float(h), float(xmin), float(zmin), room
 
 
@@ -276,6 +279,7 @@ def write_conf(path, root, cube_res=32, spp=(64, 16), albedo_res=256, rough_res=
     batch_size = 1
     albedo_res = %d
     roughness_res = %d
+    irt_res = native
     path_mesh_open3d = %s
 }
 test{

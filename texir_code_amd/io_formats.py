@@ -52,26 +52,13 @@ def read_hdr(path):
     buf = np.frombuffer(data, np.uint8, offset=end + 1)
     if buf.size == H * W * 4 and not (W >= 8 and W < 32768 and buf[0] == 2 and buf[1] == 2):
         return rgbe_decode(buf.reshape(H, W, 4))
+    # RLE (or mixed) scanlines: a byte-serial recurrence -> the library's C++ loop (texir_hdr_decode_scanlines)
+    from . import _lib
     out = np.empty((H, W, 4), np.uint8)
-    p = 0
-    for y in range(H):
-        if W < 8 or W >= 32768 or buf[p] != 2 or buf[p + 1] != 2 or (buf[p + 2] & 0x80):
-            out[y] = buf[p:p + 4 * W].reshape(W, 4)      # flat scanline
-            p += 4 * W
-            continue
-        if ((int(buf[p + 2]) << 8) | int(buf[p + 3])) != W:
-            raise ValueError("%s: bad RLE scanline width" % path)
-        p += 4
-        for c in range(4):
-            x = 0
-            while x < W:
-                n = int(buf[p]); p += 1
-                if n > 128:
-                    n -= 128
-                    out[y, x:x + n, c] = buf[p]; p += 1
-                else:
-                    out[y, x:x + n, c] = buf[p:p + n]; p += n
-                x += n
+    src = np.ascontiguousarray(buf)
+    used = _lib.lib().texir_hdr_decode_scanlines(_lib.ptr(src), int(src.size), W, H, _lib.ptr(out))
+    if used < 0:
+        raise ValueError("%s: corrupt Radiance scanline data" % path)
     return rgbe_decode(out)
 
 
@@ -97,56 +84,48 @@ def write_png(path, img):
 
 
 def read_png(path):
-    """-> [H,W,C] uint8/uint16 in the file's channel order (RGB[A]); non-interlaced, colour types 0/2/6, depth 8/16"""
+    """-> [H,W,C] uint8/uint16 in the file's channel order (RGB[A]); non-interlaced, colour types 0/2/6 at depth 8/16 and 8-bit palette
+    images (3, expanded to RGB); all five scanline filters"""
     with open(path, "rb") as f:
         data = f.read()
     if data[:8] != b"\x89PNG\r\n\x1a\n":
         raise ValueError("%s: not a PNG" % path)
-    p, idat, hdr = 8, [], None
+    p, idat, hdr, plte = 8, [], None, None
     while p < len(data):
         n, tag = struct.unpack(">I4s", data[p:p + 8])
         body = data[p + 8:p + 8 + n]
         if tag == b"IHDR":
             hdr = struct.unpack(">IIBBBBB", body)
+        elif tag == b"PLTE":
+            plte = body
         elif tag == b"IDAT":
             idat.append(body)
         elif tag == b"IEND":
             break
         p += 12 + n
     W, H, depth, ctype, _, _, interlace = hdr
-    if interlace or depth not in (8, 16) or ctype not in (0, 2, 6):
+    if interlace or depth not in (8, 16) or ctype not in (0, 2, 3, 6) or (ctype == 3 and depth != 8):
         raise ValueError("%s: unsupported PNG flavour (depth %d, colour type %d, interlace %d)" % (path, depth, ctype, interlace))
-    C = {0: 1, 2: 3, 6: 4}[ctype]
+    C = {0: 1, 2: 3, 3: 1, 6: 4}[ctype]
     bpp = C * depth // 8
     stride = W * bpp
-    raw = np.frombuffer(zlib.decompress(b"".join(idat)), np.uint8).reshape(H, stride + 1)
-    out = np.zeros((H, stride), np.uint8)
-    prev = np.zeros(stride, np.int32)
-    for y in range(H):
-        ft = int(raw[y, 0])
-        line = raw[y, 1:].astype(np.int32)
-        if ft == 0:
-            cur = line
-        elif ft == 2:
-            cur = (line + prev) & 255
-        elif ft == 1:
-            cur = line.copy()
-            for b in range(bpp):               # per byte lane prefix sums mod 256
-                cur[b::bpp] = np.cumsum(line[b::bpp]) & 255
-        else:
-            cur = np.zeros(stride, np.int32)
-            for x in range(stride):
-                a = cur[x - bpp] if x >= bpp else 0
-                b_ = prev[x]
-                c = prev[x - bpp] if x >= bpp else 0
-                if ft == 3:
-                    pred = (a + b_) >> 1
-                else:
-                    pa, pb, pc = abs(b_ - c), abs(a - c), abs(a + b_ - 2 * c)
-                    pred = a if (pa <= pb and pa <= pc) else (b_ if pb <= pc else c)
-                cur[x] = (line[x] + pred) & 255
-        out[y] = cur
-        prev = cur
+    raw = np.frombuffer(zlib.decompress(b"".join(idat)), np.uint8)
+    if raw.size != H * (stride + 1):
+        raise ValueError("%s: truncated PNG data" % path)
+    if not raw.reshape(H, stride + 1)[:, 0].any():
+        out = np.ascontiguousarray(raw.reshape(H, stride + 1)[:, 1:])        # every scanline unfiltered (our own writer)
+    else:
+        # Sub / Up / Average / Paeth are byte-serial recurrences: the library's C++ loop (texir_png_unfilter)
+        from . import _lib
+        out = np.empty((H, stride), np.uint8)
+        if _lib.lib().texir_png_unfilter(_lib.ptr(np.ascontiguousarray(raw)), H, stride, bpp, _lib.ptr(out)) != 0:
+            raise ValueError("%s: corrupt PNG scanline data" % path)
+    if ctype == 3:
+        # palette image -> RGB, as cv2.imread's colour conversion delivers it
+        if plte is None:
+            raise ValueError("%s: palette PNG without PLTE chunk" % path)
+        pal = np.frombuffer(plte, np.uint8).reshape(-1, 3)
+        return pal[out.reshape(H, W)]
     if depth == 16:
         return out.view(">u2").astype(np.uint16).reshape(H, W, C)
     return out.reshape(H, W, C)

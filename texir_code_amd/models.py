@@ -74,15 +74,17 @@ class TracerO3d(nn.Module):
         self.cube_res = 256
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.scene, self.obj, self.texture = _load_scene(conf, self.device.index)
-        # index texture at NATIVE resolution by default; the reference resizes to 1024^2 (tracer_o3d_irt.py:95).
-        # Optional key train.irt_res picks a nearest-neighbour resize.
+        # The reference resizes 0.png to 1024 x 1024 (tracer_o3d_irt.py:95) -- train.irt_res keeps that default size; `native` (or 0) opts
+        # out.  The resize here is NEAREST, the flag the reference passes: its call puts cv2.INTER_NEAREST in the `dst` slot, so it
+        # actually interpolates the uint16 row/col/panorama codes bilinearly -- an accident that is not reproduced.
         idx = IO.read_index_texture(_sibling(self.path_traced_mesh, "0.png"))
-        res = conf.get("train.irt_res", None)
-        if res:
+        res = conf.get("train.irt_res", 1024)
+        if res not in (None, 0, "0", "native"):
             res = int(res)
-            ry = (np.arange(res) * idx.shape[0] // res)
-            rx = (np.arange(res) * idx.shape[1] // res)
-            idx = idx[ry][:, rx]
+            if (res, res) != idx.shape[:2]:
+                ry = (np.arange(res) * idx.shape[0] // res)
+                rx = (np.arange(res) * idx.shape[1] // res)
+                idx = idx[ry][:, rx]
         self.index_texture = np.ascontiguousarray(idx)
         # optional exact texel G-buffer written by the synthetic generator (bypasses the panorama gather)
         self.texel_gbuffer_path = _sibling(self.path_traced_mesh, "texel_gbuffer.npz")

@@ -296,7 +296,8 @@ class MatTrainSynRunner(MatTrainRunner):
             return c2p.ToPano(x.detach().cpu().permute(0, 3, 1, 2).reshape(1, -1, c, c))[0].permute(1, 2, 0)
 
         def ssim_err(a, b):
-            return 1.0 - float(M.ssim(a.unsqueeze(0).permute(0, 3, 1, 2), b.unsqueeze(0).permute(0, 3, 1, 2)))
+            # the reference accumulates 1 - SSIMLoss = the SSIM value itself under the name "ssim_error" (:453)
+            return float(M.ssim(a.unsqueeze(0).permute(0, 3, 1, 2), b.unsqueeze(0).permute(0, 3, 1, 2)))
 
         def mse(a, b):
             return float(torch.mean((a - b) ** 2))
