@@ -157,7 +157,7 @@ def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5):
             data.append((mvp, cam.to(dev), gt["rgb"].clone(), gt["empty_mask"].clone(), seg, fm, room))
         model.materials_a.copy_(a0)
         model.materials_r.copy_(r0)
-    loss_fn = RenderLoss("L1", 1, lazy_item=True)
+    loss_fn = RenderLoss("L1", 1, lazy_item=True, unit_upstream=True)       # (as the runner's hipGraph path sets it)
     opt = FusedAdam([model.materials_a, model.materials_r], lr=3e-2, fuse_mip_fold=True)
     opt.set_clamp(model.materials_r, 1e-2, 0.8)
     opt.set_clamp(model.materials_a, 0.0, float("inf"))
@@ -253,12 +253,16 @@ def roofline(workload, kernel, kern_ms, rays_this_rank, world, alg):
     t = kern_ms * 1e-3
     out = {"bound": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
            "kernel": kernel, "kernel_ms": round(kern_ms, 3), "rays_per_launch": rays_this_rank}
-    pmc, why = load_pmc(workload, kernel) if world == 1 else (None, "PMC profiles are taken at N = 1")
+    pmc, why = load_pmc(workload, kernel)
     if pmc is None:
         out["note"] = "no measured bound: " + why
     else:
-        traffic = float(pmc["fabric_bytes_per_launch"])
-        valu = float(pmc["SQ_INSTS_VALU"])
+        # counters are per launch of the N = 1 profile; a rank of an N-GPU run traces 1/N of the rays with the same per-ray cost
+        scale = rays_this_rank / float(pmc.get("rays_per_launch", rays_this_rank))
+        traffic = float(pmc["fabric_bytes_per_launch"]) * scale
+        valu = float(pmc["SQ_INSTS_VALU"]) * scale
+        if world > 1:
+            out["note"] = "per-launch counters of the N = 1 profile scaled by this rank's share of the rays (%.4f)" % scale
         mem_frac = traffic / t / 1e9 / HBM_PEAK_GBS
         valu_frac = valu / (SIMDS * CLOCK_HZ / 2.0 * t)
         out.update({"bound": "hbm" if mem_frac >= valu_frac else "valu", "achieved": round(traffic / t / 1e9, 1), "frac": round(max(mem_frac, valu_frac), 4),

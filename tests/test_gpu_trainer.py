@@ -206,8 +206,12 @@ def test_index_texture_path_generate_positions_and_gather(tmp_path):
     assert rel_l2(got[close], ref[close]) < 1e-5
 
 
-def test_graphed_material_step_equals_eager(golden):
-    """hipGraph replay of forward+loss+backward must reproduce the eager step bit-for-bit (same shifts, same Adam)"""
+@pytest.mark.parametrize("fuse", [False, True])
+def test_graphed_material_step_equals_eager(golden, fuse):
+    """hipGraph replay of forward+loss+backward must reproduce the eager step (same shifts, same Adam) -- eight steps queued back to
+    back WITHOUT a host sync in between (the shifts' pinned staging ring must not be overwritten before its copy has run),
+    with the plain optimiser and with the trainer's fused one (last mip fold + mip level 1 inside the Adam kernel, sparse level-0
+    gradient, parameter-owned gradient stacks shared by the graphs)"""
     from texir_code_amd import cameras, conf as C
     from texir_code_amd.graph_step import GraphedMatStep
     from texir_code_amd.loss import RenderLoss
@@ -231,11 +235,11 @@ def test_graphed_material_step_equals_eager(golden):
         seg, fm, _ = build_masks(segs, torch.rand(6, c, c, 3, device="cuda") - 0.5)
         room = torch.ones((1, 6, c, c, 1), device="cuda")
         loss_fn = RenderLoss("L1", 1, lazy_item=True)
-        opt = FusedAdam([m.materials_a, m.materials_r], lr=3e-2)
+        opt = FusedAdam([m.materials_a, m.materials_r], lr=3e-2, fuse_mip_fold=fuse)
         opt.set_clamp(m.materials_r, 1e-2, 0.8)
         torch.manual_seed(9)
         if mode == "eager":
-            for _ in range(3):
+            for _ in range(8):
                 preds = m(mvp, "v", cam, 2)
                 loss = loss_fn(gt, preds, gmask, fm, seg, stage=2, room_seg_mask=room)[0]
                 opt.zero_grad()
@@ -245,8 +249,8 @@ def test_graphed_material_step_equals_eager(golden):
             gs = GraphedMatStep(m, loss_fn, opt, [m.materials_a, m.materials_r])
             gs.capture("v", mvp, cam, gt, gmask, seg, fm, room, 2)       # warm-up + capture draw shifts too: reseed after
             torch.manual_seed(9)
-            for _ in range(3):
-                loss = gs.step("v", 2)
+            for _ in range(8):
+                loss = gs.step("v", 2)                              # no .item() / synchronize between the steps
         res.append((m.materials_a.detach().cpu().numpy().copy(), m.materials_r.detach().cpu().numpy().copy(), float(loss)))
     # float atomics in the texture backward make the sums order-dependent: compare to float tolerance
     assert rel_l2(res[1][0], res[0][0]) < 1e-5 and rel_l2(res[1][1], res[0][1]) < 1e-5

@@ -9,6 +9,10 @@
 
 // 1: byte -> float conversions of the node step rewritten in full-rate operations (see traverse).  Measured -10 % (c4 13.7 vs 15.2
 // Grays/s, profiles/r02): kept as a documented experiment, off.
+// 1: wave-uniform node steps fetch the node once and broadcast it through LDS (A/B flag, see traverse)
+#ifndef TEXIR_UNIFORM_BCAST
+#define TEXIR_UNIFORM_BCAST 0
+#endif
 #ifndef TEXIR_FAST_DEQUANT
 #define TEXIR_FAST_DEQUANT 0
 #endif
@@ -244,6 +248,9 @@ __device__ __forceinline__ void traverse(const SceneDev& sc, RayState& r, typena
     // the traversal stack: LSTK entries per lane in LDS ([entry][thread]), deeper ones private.  The stack pointer is kept as
     // the LDS address of the next free entry (push = ds_write + one add, no index scaling in the node step).
     __shared__ Entry lds_all[LSTK * kBlock];
+#if TEXIR_UNIFORM_BCAST
+    __shared__ float4 bcast_all[4 * (kBlock / 64)];          // 64 bytes per wave: the node of a wave-uniform step
+#endif
     Entry* const base = lds_all + threadIdx.x;
     Entry* const lim = base + LSTK * kBlock;
     Entry* top = base + r.sp * kBlock;
@@ -298,12 +305,41 @@ __device__ __forceinline__ void traverse(const SceneDev& sc, RayState& r, typena
                     key[k] = tn <= tf ? tn : __builtin_inff();
                 }
 #else
+#if TEXIR_UNIFORM_BCAST
+                // Wave-uniform steps (the rays of a pass leave neighbouring points in nearly the same direction: they walk the upper
+                // levels together): when every participating lane holds the SAME node, one lane fetches its 64 bytes and the wave reads them
+                // back as an LDS broadcast -- 4 lane-loads instead of 4 x (participating lanes) through the L1.
+                float4 q0; uint4 q1, q2; int4 ch;
+                {
+                    const int n0 = __builtin_amdgcn_readfirstlane(node);
+                    const unsigned long long act = __ballot(1);
+                    if (!__any(node != n0) && __popcll(act) >= 8) {
+                        float4* const slot = bcast_all + 4 * (threadIdx.x >> 6);
+                        if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) {
+                            const float4* npu = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.nodes4) + ((uint32_t)n0 << 6));
+                            slot[0] = npu[0]; slot[1] = npu[1]; slot[2] = npu[2]; slot[3] = npu[3];
+                        }
+                        // (LDS operations of one wave execute in order: the reads below see the write above)
+                        q0 = slot[0];
+                        q1 = *reinterpret_cast<const uint4*>(slot + 1);
+                        q2 = *reinterpret_cast<const uint4*>(slot + 2);
+                        ch = *reinterpret_cast<const int4*>(slot + 3);
+                    } else {
+                        const float4* np = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.nodes4) + ((uint32_t)node << 6));
+                        q0 = np[0];
+                        q1 = *reinterpret_cast<const uint4*>(np + 1);
+                        q2 = *reinterpret_cast<const uint4*>(np + 2);
+                        ch = *reinterpret_cast<const int4*>(np + 3);
+                    }
+                }
+#else
                 // (uniform base + 32-bit byte offset: one VALU op of address arithmetic, saddr-form loads)
                 const float4* np = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.nodes4) + ((uint32_t)node << 6));
                 const float4 q0 = np[0];
                 const uint4 q1 = *reinterpret_cast<const uint4*>(np + 1);
                 const uint4 q2 = *reinterpret_cast<const uint4*>(np + 2);
                 const int4 ch = *reinterpret_cast<const int4*>(np + 3);
+#endif
                 if (STATS) { n_nodes++; if (wave_iters && first_active()) wave_iters[0]++; }
                 // cell size folded into the reciprocal direction; origin folded into the offset
                 const float sx = q0.w * idx, sy = __uint_as_float(q2.z) * idy, sz = __uint_as_float(q2.w) * idz;

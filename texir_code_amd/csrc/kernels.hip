@@ -580,6 +580,17 @@ hipError_t launch_gen_dir(const float* normals, const float* rough, const float*
 // lanes per pixel: S when S is a power of two <= 64 (one pass), else 64.  TEXIR_SPEC_LPP = 1..64 (a power of two) forces fewer lanes and
 // more passes per pixel: the lanes of a wave then belong to more, neighbouring pixels and take the SAME sample indices in a pass
 // (more coherent rays, fewer and longer waves) -- A/B switch.
+// the specular kernels' grid: one block per 4 waves of pixels up to this many blocks, grid-stride beyond (TEXIR_SPEC_GRID_CAP: A/B switch).
+// A pixel group is ~15 node steps of work with a long tail, so letting the hardware hand out many short blocks balances better than a
+// static stride over a few long ones.
+static int spec_grid(int64_t pix_per_block, int64_t P)
+{
+    int64_t cap = 1 << 16;
+    if (const char* e = getenv("TEXIR_SPEC_GRID_CAP")) { const int v = atoi(e); if (v >= 1) cap = v; }
+    const int64_t want = (P + pix_per_block - 1) / pix_per_block;
+    return (int)(want < 1 ? 1 : (want > cap ? cap : want));
+}
+
 static int lanes_per_pixel(int S)
 {
     int lpp = (S <= 64 && (S & (S - 1)) == 0) ? S : 64;
@@ -595,10 +606,10 @@ hipError_t launch_spec_fwd(const SceneDev& sc, const float* normal, const float*
     int lpp = lanes_per_pixel(S);
     int64_t pix_per_block = (int64_t)(kBlock / 64) * (64 / lpp);
     if (sc.nodes4 || ls_given)
-        hipLaunchKernelGGL((spec_kernel<false, 4>), dim3(grid_for(pix_per_block, P)), dim3(kBlock), 0, st, sc, normal, albedo, rough, points, irr, cam,
+        hipLaunchKernelGGL((spec_kernel<false, 4>), dim3(spec_grid(pix_per_block, P)), dim3(kBlock), 0, st, sc, normal, albedo, rough, points, irr, cam,
                            shift, P, S, lpp, rgb, Ls_ws, (const float*)nullptr, (float*)nullptr, (float*)nullptr, clamp_eps, ls_given);
     else
-        hipLaunchKernelGGL((spec_kernel<false, 2>), dim3(grid_for(pix_per_block, P)), dim3(kBlock), 0, st, sc, normal, albedo, rough, points, irr, cam,
+        hipLaunchKernelGGL((spec_kernel<false, 2>), dim3(spec_grid(pix_per_block, P)), dim3(kBlock), 0, st, sc, normal, albedo, rough, points, irr, cam,
                            shift, P, S, lpp, rgb, Ls_ws, (const float*)nullptr, (float*)nullptr, (float*)nullptr, clamp_eps, ls_given);
     return hipGetLastError();
 }
@@ -611,7 +622,7 @@ hipError_t launch_spec_bwd(const float* normal, const float* rough, const float*
     int lpp = lanes_per_pixel(S);
     int64_t pix_per_block = (int64_t)(kBlock / 64) * (64 / lpp);
     SceneDev none{};
-    hipLaunchKernelGGL((spec_kernel<true, 2>), dim3(grid_for(pix_per_block, P)), dim3(kBlock), 0, st, none, normal, (const float*)nullptr, rough,
+    hipLaunchKernelGGL((spec_kernel<true, 2>), dim3(spec_grid(pix_per_block, P)), dim3(kBlock), 0, st, none, normal, (const float*)nullptr, rough,
                        points, irr, cam, shift, P, S, lpp, (float*)nullptr, const_cast<float*>(Ls_ws), d_rgb, d_albedo, d_rough, clamp_eps, 0);
     return hipGetLastError();
 }

@@ -44,7 +44,7 @@ def compact_masks(seg_mask, floor_max_mask=None, room_seg_mask=None):
 
 class _LossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rgb, albedo, rough, rough_womip, gt, empty, gtm, seg_id, hl, room_id, stage, loss_type, C, R, hw):
+    def forward(ctx, rgb, albedo, rough, rough_womip, gt, empty, gtm, seg_id, hl, room_id, stage, loss_type, C, R, hw, unit_upstream=False):
         dev = rgb.device
         P = seg_id.numel()
         f = lambda t, n: None if t is None else t.detach().to(device=dev, dtype=torch.float32).reshape(P, n).contiguous()
@@ -60,6 +60,7 @@ class _LossFn(torch.autograd.Function):
                                         _lib.ptr(m_), _lib.ptr(seg_id), _lib.ptr(hl), _lib.ptr(room_id), P, C, R, hw, _lib.ptr(ws), _lib.ptr(out),
                                         _lib.ptr(d_rgb), _lib.ptr(d_alb), _lib.ptr(d_r), _lib.stream_ptr()))
         ctx.grads = (d_rgb, d_alb, d_r)
+        ctx.unit_upstream = unit_upstream
         ctx.shapes = (rgb.shape, None if albedo is None else albedo.shape, None if rough is None else rough.shape)
         return out
 
@@ -67,22 +68,31 @@ class _LossFn(torch.autograd.Function):
     def backward(ctx, g):
         d_rgb, d_alb, d_r = ctx.grads
         s_rgb, s_alb, s_r = ctx.shapes
-        g0 = g[0]      # only out[0] (total loss) is differentiable; out[1] is the detached .item() value
-        grgb = (d_rgb * g0).reshape(s_rgb) if ctx.needs_input_grad[0] else None
-        galb = (d_alb * g0).reshape(s_alb) if (d_alb is not None and ctx.needs_input_grad[1]) else None
-        gr = (d_r * g0).reshape(s_r) if (d_r is not None and ctx.needs_input_grad[2]) else None
-        return (grgb, galb, gr) + (None,) * 12
+        if ctx.unit_upstream:
+            # the loss is the root of the backward pass (trainer: loss.backward()): the upstream gradient is exactly 1 and the kernels'
+            # gradients are handed on as they are -- three elementwise launches fewer per step
+            sc = lambda t: t
+        else:
+            g0 = g[0]      # only out[0] (total loss) is differentiable; out[1] is the detached .item() value
+            sc = lambda t: t * g0
+        grgb = sc(d_rgb).reshape(s_rgb) if ctx.needs_input_grad[0] else None
+        galb = sc(d_alb).reshape(s_alb) if (d_alb is not None and ctx.needs_input_grad[1]) else None
+        gr = sc(d_r).reshape(s_r) if (d_r is not None and ctx.needs_input_grad[2]) else None
+        return (grgb, galb, gr) + (None,) * 13
 
 
 class RenderLoss(nn.Module):
     """models.loss.RenderLoss(loss_type='L1', w_gradient=0).forward(gt_img, preds, gt_mask, floor_max_mask, seg_mask,
     stage, room_seg_mask) -> (loss, seg_loss_item[, 0])  (loss.py:56,81-115)."""
 
-    def __init__(self, loss_type="L1", w_gradient=0, lazy_item=False):
+    def __init__(self, loss_type="L1", w_gradient=0, lazy_item=False, unit_upstream=False):
         """lazy_item=True returns the seg term as a 0-dim device tensor instead of calling .item() (the reference's
-        `seg_loss.item()` forces a host sync every step, which also forbids hipGraph capture of the step)"""
+        `seg_loss.item()` forces a host sync every step, which also forbids hipGraph capture of the step).
+        unit_upstream=True promises that the returned loss is back-propagated as the root (`loss.backward()`, what the trainers do):
+        the fused kernels' gradients are then passed on without the multiplication by the upstream gradient (= 1)."""
         super().__init__()
         self.lazy_item = lazy_item
+        self.unit_upstream = unit_upstream
         if loss_type not in _LOSS_TYPES and loss_type not in _VARIANTS:
             raise Exception("Unknown loss_type!")                          # loss.py:76
         print("Using %s loss for comparing re-rendered radiance!" % {"msssim": "ms-ssim", "psnr": "PSNR"}.get(loss_type, loss_type))
@@ -113,7 +123,8 @@ class RenderLoss(nn.Module):
             return self._variant(gt_img, preds, gt_mask, seg_id, hl, C, stage, hw)
         out = _LossFn.apply(rgb, preds["albedo"] if stage == 0 else None, preds["roughness"] if stage != 0 else None,
                             preds["roughness_womipmap"] if stage == 1 else None, gt_img, preds["empty_mask"], gt_mask if stage == 0 else None,
-                            seg_id, hl, room_id if stage == 2 else None, stage, _LOSS_TYPES[self.loss_type], C, R if stage == 2 else 0, hw)
+                            seg_id, hl, room_id if stage == 2 else None, stage, _LOSS_TYPES[self.loss_type], C, R if stage == 2 else 0, hw,
+                            self.unit_upstream)
         loss, seg_item = out[0], (out[1].detach() if self.lazy_item else out[1].item())
         if stage == 0:
             return loss, seg_item

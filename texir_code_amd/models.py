@@ -302,7 +302,17 @@ class MaterialModel(nn.Module):
         return {"rgb": rgb.reshape(face, h, w, 3), "albedo": albedo.reshape(face, h, w, 3), "normal": normal.reshape(face, h, w, 3).detach(),
                 "position": (position_out if position_out is not None else (points + 2e-2 * normal).detach()).reshape(face, h, w, 3)}
 
-    # -- API-complete helpers (dead on the default path, mat_nvdiffrast.py:252-258) ---------------------------------
+    # -- mat_nvdiffrast.py:252-258 (call sites commented out at :166-169, 221-226; live in the evaluation model's relighting branch) ------
+    def traced_diffuse(self, points, normal, albedo, shift=None):
+        """the traced diffuse term the commented-out call sites compute: diffuse_reflectance(query_irf(points, l), l, n, albedo, type) / N
+        with l = generate_dir(normal, N, mode=type) -- fused in texir_diffuse_irradiance (sample + trace + shade + reduce), times albedo/pi"""
+        from .scene import diffuse_irradiance
+        P = points.reshape(-1, 3).shape[0]
+        if shift is None:
+            shift = torch.rand(P, 1, 2).reshape(P, 2)                            # generate_dir's draw (sample_util.py:102)
+        E = diffuse_irradiance(self.scene, points.reshape(P, 3), normal.reshape(P, 3), shift, int(self.sample_l[0]), self.sample_type[0])
+        return E * albedo.reshape(P, 3) / np.pi
+
     def diffuse_reflectance(self, lighting, l, n, albedo, sample_type="uniform"):
         ndl = torch.clamp(torch.sum(n.unsqueeze(1) * l, dim=-1, keepdim=True), 0.0, 1.0)
         brdf = albedo.unsqueeze(1) / np.pi

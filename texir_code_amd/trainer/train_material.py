@@ -107,6 +107,7 @@ class MatTrainRunner:
         vid0 = vid[0] if isinstance(vid, (list, tuple)) else vid
         if getattr(self, "_gs", None) is None or self._gs.opt is not self.mat_optimizer:
             self.mat_loss.lazy_item = True
+            self.mat_loss.unit_upstream = True        # train_step back-propagates the loss itself (loss.backward())
             self._gs = GraphedMatStep(self.model, self.mat_loss, self.mat_optimizer, [self.model.materials_a, self.model.materials_r])
             self._gs_inputs = getattr(self, "_gs_inputs", {})
         if (vid0, stage) not in self._gs.graphs:

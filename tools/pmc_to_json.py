@@ -31,9 +31,20 @@ if c.get("SQ_INSTS_VALU", 0):
         res["valu_lane_utilisation"] = round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"]), 4)
 if c.get("GRBM_GUI_ACTIVE", 0) and dur:
     res["effective_clock_ghz"] = round(c["GRBM_GUI_ACTIVE"] / (dur[0] * 1e-3) / 1e9, 3)
+if c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0) and c.get("TCP_GATE_EN1_sum", 0):
+    # vector-L1 tag lookups per TCP clock (the 256 TCPs' busy clocks summed): the traversal's other limiter
+    res["tcp_cache_accesses"] = c["TCP_TOTAL_CACHE_ACCESSES_sum"]
+    res["tcp_lookups_per_clk"] = round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / c["TCP_GATE_EN1_sum"], 4)
 if c.get("SQ_WAVE_CYCLES", 0):
     for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
         if k in c:
             res[k.lower() + "_frac"] = round(c[k] / c["SQ_WAVE_CYCLES"], 4)
+# rays of the profiled launch = valid texels x spp of the workload (every PMC pass runs `bench.py --workload <wl> --steps 1`)
+try:
+    T, r_, tex_, spp_, style_ = bench.WORKLOADS[wl]
+    _, _, _, valid_, _, _, _ = bench.make_workload(wl)
+    res["rays_per_launch"] = int((valid_.reshape(-1) > 0).sum()) * spp_
+except Exception as e:      # (the json is still usable at N = 1)
+    res["rays_per_launch_error"] = str(e)
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "counters"}))

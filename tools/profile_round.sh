@@ -31,6 +31,8 @@ for wl in "${WLS[@]}"; do
   run $wl write WRITE_SIZE
   run $wl grbm GRBM_GUI_ACTIVE
   run $wl tccbusy TCC_BUSY_sum TCC_CYCLE_sum
+  run $wl tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum
+  run $wl tcpgate TCP_GATE_EN1_sum TCP_TOTAL_ACCESSES_sum
   python $R/tools/pmc_to_json.py $out/$wl $wl $R/gpurun_out/$tag/pmc_$wl.json
 done
 # kernel-trace stats of the default bench run (the headline), with the PMC json in place so that the line carries the measured bounds
