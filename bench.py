@@ -14,12 +14,13 @@ Multi-GPU: one process per GPU; the compacted valid-texel list is dealt block-cy
 (strong scaling of ONE texture), each rank writes its texels into a zero-initialised full texture and a single
 RCCL all_reduce(SUM) assembles it (disjoint support) -- inside the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline` carries two bounds that hold (both <= 1), each = a per-launch counter of the
+Prints ONE JSON line (rank 0).  `roofline` carries three bounds that hold (all <= 1), each = a per-launch counter of the
 dominant kernel (rocprofv3 --pmc, committed under profiles/pmc_<workload>.json together with a hash of the kernel sources
 -- a profile of other sources is refused) divided by the kernel time measured live with HIP events:
   * memory: fabric-side bytes (L2 <-> Infinity Cache/HBM read requests x 128 B + writes) / time / 8 TB/s,
-  * VALU issue: SQ_INSTS_VALU / (1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction x time).
-`bound` names the larger.  SURVEY.md 8(d)'s algorithmic bytes (canonical BVH2 visit counts x 32/36 B) are reported under
+  * VALU issue: SQ_INSTS_VALU / (1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction x time),
+  * vector L1: TCP_TOTAL_CACHE_ACCESSES / (the 256 TCPs' clocks over the same time) -- a TCP serves one access per clock.
+`bound` names the largest ("hbm" | "valu" | "l1"; `achieved` / `peak` / `traffic` stay the fabric-side GB/s figures).  SURVEY.md 8(d)'s algorithmic bytes (canonical BVH2 visit counts x 32/36 B) are reported under
 `algorithmic` -- they are served by L1/L2 hits of a 4x more compact tree and exceed the HBM peak, so they bound nothing.
 `cpu_baseline` = the CPU oracle (a port of the reference algorithm; Open3D/Embree is not installable here) timed
 on this box's host cores on a bounded sample of the same workload.
@@ -265,11 +266,23 @@ def roofline(workload, kernel, kern_ms, rays_this_rank, world, alg):
             out["note"] = "per-launch counters of the N = 1 profile scaled by this rank's share of the rays (%.4f)" % scale
         mem_frac = traffic / t / 1e9 / HBM_PEAK_GBS
         valu_frac = valu / (SIMDS * CLOCK_HZ / 2.0 * t)
-        out.update({"bound": "hbm" if mem_frac >= valu_frac else "valu", "achieved": round(traffic / t / 1e9, 1), "frac": round(max(mem_frac, valu_frac), 4),
+        # vector-L1 (TCP): the unit serves ONE cache access per clock (tools/tcp_rate.hip under the same counters: 1.00 per clock for
+        # contiguous and for scattered wave-wide dwordx4 loads alike); the kernel's accesses over the TCP clocks of this run's duration
+        l1 = None
+        if pmc.get("tcp_cache_accesses") and pmc.get("tcp_clocks") and pmc.get("kernel_ms_under_pmc"):
+            tcp_hz = float(pmc["tcp_clocks"]) / (float(np.mean(pmc["kernel_ms_under_pmc"])) * 1e-3)          # all 256 TCPs together
+            l1 = float(pmc["tcp_cache_accesses"]) * scale / (tcp_hz * t)
+        fr = {"hbm": mem_frac, "valu": valu_frac}
+        if l1 is not None:
+            fr["l1"] = l1
+        bound = max(fr, key=fr.get)
+        out.update({"bound": bound, "achieved": round(traffic / t / 1e9, 1), "frac": round(fr[bound], 4),
                     "traffic": traffic, "memory": {"fabric_bytes_per_launch": traffic, "gbs": round(traffic / t / 1e9, 1), "frac_of_8TBs": round(mem_frac, 4),
                                                    "bytes_per_ray": round(traffic / rays_this_rank, 1), "l2_hit_rate": pmc.get("l2_hit_rate")},
                     "valu_issue": {"insts_per_launch": valu, "peak_insts_per_s": SIMDS * CLOCK_HZ / 2.0, "frac": round(valu_frac, 4),
                                    "lane_utilisation": pmc.get("valu_lane_utilisation"), "insts_per_64_rays": round(valu / (rays_this_rank / 64.0), 1)},
+                    "l1_tcp": None if l1 is None else {"accesses_per_launch": float(pmc["tcp_cache_accesses"]) * scale, "frac": round(l1, 4),
+                                                        "note": "vector-L1 cache accesses / (256 TCPs x TCP clock x t); peak 1 access per clock per TCP"},
                     "profile": "profiles/pmc_%s.json (%s)" % (workload, pmc.get("source", ""))})
     if alg is not None:
         bpr, nbar, tbar, phit = alg

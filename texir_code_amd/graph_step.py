@@ -31,7 +31,9 @@ class GraphedMatStep:
         # grads are re-created by the backward itself (autograd assigns instead of accumulating): inside the captured graph their
         # addresses are static, and the zero-fill + accumulate passes over the full textures disappear
         self.opt.zero_grad(set_to_none=self.grads_to_none)
-        loss.backward()
+        if getattr(self, "_seed", None) is None or self._seed.device != loss.device:
+            self._seed = torch.ones((), device=loss.device)          # (a persistent unit seed: loss.backward() would fill a fresh one per step)
+        torch.autograd.backward(loss, self._seed)
         return loss
 
     def capture(self, key, mvp, cam, gt, gmask, seg, fm, room, stage):

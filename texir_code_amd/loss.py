@@ -62,10 +62,13 @@ class _LossFn(torch.autograd.Function):
         ctx.grads = (d_rgb, d_alb, d_r)
         ctx.unit_upstream = unit_upstream
         ctx.shapes = (rgb.shape, None if albedo is None else albedo.shape, None if rough is None else rough.shape)
-        return out
+        # two 0-dim outputs (views of the kernel's result pair): the loss, and the segmentation term the reference returns as .item()
+        loss, seg = out[0], out[1]
+        ctx.mark_non_differentiable(seg)
+        return loss, seg
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g0, _g_seg=None):
         d_rgb, d_alb, d_r = ctx.grads
         s_rgb, s_alb, s_r = ctx.shapes
         if ctx.unit_upstream:
@@ -73,7 +76,6 @@ class _LossFn(torch.autograd.Function):
             # gradients are handed on as they are -- three elementwise launches fewer per step
             sc = lambda t: t
         else:
-            g0 = g[0]      # only out[0] (total loss) is differentiable; out[1] is the detached .item() value
             sc = lambda t: t * g0
         grgb = sc(d_rgb).reshape(s_rgb) if ctx.needs_input_grad[0] else None
         galb = sc(d_alb).reshape(s_alb) if (d_alb is not None and ctx.needs_input_grad[1]) else None

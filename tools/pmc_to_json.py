@@ -30,11 +30,12 @@ if c.get("SQ_INSTS_VALU", 0):
     if c.get("SQ_THREAD_CYCLES_VALU", 0):
         res["valu_lane_utilisation"] = round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"]), 4)
 if c.get("GRBM_GUI_ACTIVE", 0) and dur:
-    res["effective_clock_ghz"] = round(c["GRBM_GUI_ACTIVE"] / (dur[0] * 1e-3) / 1e9, 3)
+    res["effective_clock_ghz"] = round(c["GRBM_GUI_ACTIVE"] / 8.0 / (dur[0] * 1e-3) / 1e9, 3)      # (the counter sums the 8 XCDs)
 if c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0) and c.get("TCP_GATE_EN1_sum", 0):
     # vector-L1 tag lookups per TCP clock (the 256 TCPs' busy clocks summed): the traversal's other limiter
     res["tcp_cache_accesses"] = c["TCP_TOTAL_CACHE_ACCESSES_sum"]
-    res["tcp_lookups_per_clk"] = round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / c["TCP_GATE_EN1_sum"], 4)
+    res["tcp_clocks"] = c["TCP_GATE_EN1_sum"]                      # summed over the 256 CUs' L1s
+    res["tcp_accesses_per_clk"] = round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / c["TCP_GATE_EN1_sum"], 4)
 if c.get("SQ_WAVE_CYCLES", 0):
     for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
         if k in c:
