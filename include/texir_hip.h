@@ -215,19 +215,14 @@ TEXIR_API int texir_adam_step(float* param, const float* grad, float* exp_avg, f
 /* The same step (trainer/train_material.py:448-458) for a texture [H,W,C] whose gradient is grad + 0.25 * grad_level1[y/2][x/2] (texir_tex_fetch_backward_deferred): the
  * last mip fold is fused into the optimiser's read of the gradient; results equal fold + texir_adam_step bit for bit.
  * grad == NULL: no pixel of the step sampled mip level 0, the level-0 gradient is neither materialised nor read.
- * active != NULL: row-pair segments of the texture that have never received a non-zero gradient (exp_avg = exp_avg_sq = 0; most of an
- * atlas' unoccupied or never-seen texels) are skipped: their update is exactly zero, so the result is bit-identical to the dense step
- * (the first step, `step == 1`, visits everything so that the clamp is applied once); a segment turns active with its first gradient.
  * grad_mask != NULL: grad is a buffer that is never cleared; only the texels a view's tap lists touch (their bit is set) carry this
  * step's values, all others count as zero -- the usual case of a handful of level-0 taps costs 1 bit per texel instead of a fill + a read.
  * mip_level1 != NULL: level 1 of the NEXT forward's mip stack (models/mat_nvdiffrast.py:131-134 rebuild it from the updated
  * texture every step) is written on the way: texir_mip_build(..., from_level = 1) then skips the pass over the full texture. */
-TEXIR_API int64_t texir_adam_tex_active_elems(int32_t H, int32_t W, int32_t C);
 TEXIR_API int texir_adam_step_tex(float* param, const float* grad /*nullable: level-0 gradient identically zero*/,
                        const uint32_t* grad_mask /*nullable: 1 bit per texel (bit t&31 of word t>>5): grad is valid -- and read -- only where set*/,
                        const float* grad_level1,
                        float* exp_avg, float* exp_avg_sq, float* mip_level1 /*nullable: [H/2,W/2,C] <- 2x2 average of the updated texels*/,
-                       uint8_t* active /*nullable: texir_adam_tex_active_elems() zero-initialised bytes kept with the optimiser state*/,
                        int32_t H, int32_t W, int32_t C, float lr, float beta1, float beta2, float eps, int32_t step, float clamp_lo,
                        float clamp_hi, void* stream);
 

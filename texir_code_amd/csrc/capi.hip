@@ -323,15 +323,13 @@ int texir_tex_gather_backward(float* d_tex, float* grad_rest, int32_t H, int32_t
     return TEXIR_OK;
 }
 
-int64_t texir_adam_tex_active_elems(int32_t H, int32_t W, int32_t C) { return adam_tex_active_elems(H, W, C); }
-
 int texir_adam_step_tex(float* param, const float* grad, const uint32_t* grad_mask, const float* grad_level1, float* exp_avg, float* exp_avg_sq,
-                        float* mip_level1, uint8_t* active, int32_t H, int32_t W, int32_t C, float lr, float beta1, float beta2, float eps, int32_t step,
+                        float* mip_level1, int32_t H, int32_t W, int32_t C, float lr, float beta1, float beta2, float eps, int32_t step,
                         float clamp_lo, float clamp_hi, void* stream)
 {
     if (!param || !grad_level1 || !exp_avg || !exp_avg_sq) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex: null argument");
     if (H < 2 || W < 2 || (H & 1) || (W & 1) || C < 1 || C > 4 || step < 1) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex: bad H/W/C/step");
-    HIP_TRY(launch_adam_tex(param, grad, grad_mask, grad_level1, exp_avg, exp_avg_sq, mip_level1, active, H, W, C, lr, beta1, beta2, eps, step, clamp_lo, clamp_hi, (hipStream_t)stream));
+    HIP_TRY(launch_adam_tex(param, grad, grad_mask, grad_level1, exp_avg, exp_avg_sq, mip_level1, H, W, C, lr, beta1, beta2, eps, step, clamp_lo, clamp_hi, (hipStream_t)stream));
     return TEXIR_OK;
 }
 

@@ -689,7 +689,6 @@ __global__ __launch_bounds__(256) void adam_tex_kernel(float* __restrict__ p, co
 template <int C>
 __global__ __launch_bounds__(256) void adam_tex_vec_kernel(float* __restrict__ p, const float* __restrict__ g, const uint32_t* __restrict__ l0_mask,
                                                            const float* __restrict__ g1, float* __restrict__ m, float* __restrict__ v, float* __restrict__ mip1,
-                                                           uint8_t* __restrict__ active, int force_all,
                                                            int H, int W, float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float lo, float hi)
 {
     constexpr int EPB = (1024 / (2 * C)) * (2 * C);
@@ -702,27 +701,8 @@ __global__ __launch_bounds__(256) void adam_tex_vec_kernel(float* __restrict__ p
     const bool act = j4 < n_here;
     const int h_base = e_base / 2, n_half = n_here / 2;              // this block's segment of the half-resolution row
     for (int by = blockIdx.y; by < Hh; by += gridDim.y) {
-        int nz = 0;
-        for (int k = threadIdx.x; k < n_half; k += 256) { const float x = g1[(size_t)by * Wh * C + h_base + k]; g1s[k] = x; nz |= x != 0.f; }
-        if (active) {
-            // Segments that have never received a gradient hold exp_avg = exp_avg_sq = 0 and a parameter inside its clamp range (the first
-            // step touches everything): their Adam update is exactly p - 0, so they are skipped -- no read, no write, identical bits.  A
-            // segment becomes (and stays) active with its first non-zero gradient.
-            if (g) {
-                if (!l0_mask) nz = 1;
-                else {
-                    const size_t t0 = (size_t)(2 * by) * W + e_base / C, nt = n_here / C;
-                    for (int r = 0; r < 2; r++)
-                        for (size_t w = (t0 + (size_t)r * W) >> 5, we = (t0 + (size_t)r * W + nt - 1) >> 5, k = w + threadIdx.x; k <= we; k += 256) nz |= l0_mask[k] != 0u;
-                }
-            }
-            uint8_t* flag = active + (size_t)by * gridDim.x + blockIdx.x;
-            const int ever = *flag;
-            const int now = __syncthreads_or(nz);
-            if (!(ever | now | force_all)) continue;              // (block-uniform)
-            if (now && !ever && threadIdx.x == 0) *flag = 1;
-        } else
-            __syncthreads();
+        for (int k = threadIdx.x; k < n_half; k += 256) g1s[k] = g1[(size_t)by * Wh * C + h_base + k];
+        __syncthreads();
         if (act) {
 #pragma unroll
             for (int r = 0; r < 2; r++) {
@@ -760,14 +740,7 @@ __global__ __launch_bounds__(256) void adam_tex_vec_kernel(float* __restrict__ p
     }
 }
 
-int64_t adam_tex_active_elems(int H, int W, int C)
-{
-    if ((W * C) % 4) return 0;                    // (the one-float-per-access fallback kernel does not skip)
-    const int epb = (1024 / (2 * C)) * (2 * C);
-    return (int64_t)(H >> 1) * ((W * C + epb - 1) / epb);
-}
-
-hipError_t launch_adam_tex(float* p, const float* g, const uint32_t* l0_mask, const float* g1, float* m, float* v, float* mip1, uint8_t* active, int H, int W, int C,
+hipError_t launch_adam_tex(float* p, const float* g, const uint32_t* l0_mask, const float* g1, float* m, float* v, float* mip1, int H, int W, int C,
                            float lr, float beta1, float beta2, float eps, int step, float lo, float hi, hipStream_t st)
 {
     double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -775,11 +748,11 @@ hipError_t launch_adam_tex(float* p, const float* g, const uint32_t* l0_mask, co
     float bc2_sqrt = (float)sqrt(bc2);
     if ((W * C) % 4 == 0 && !getenv("TEXIR_ADAM_SCALAR")) {
         const int epb = (1024 / (2 * C)) * (2 * C);
-        dim3 gridv((W * C + epb - 1) / epb, active ? (H >> 1) : ((H >> 1) > 2048 ? 2048 : (H >> 1)));     // (one row pair per block when flags are kept: flag index = by * gridDim.x + bx)
-        if (C == 1) hipLaunchKernelGGL(adam_tex_vec_kernel<1>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, active, step <= 1 ? 1 : 0, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
-        else if (C == 2) hipLaunchKernelGGL(adam_tex_vec_kernel<2>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, active, step <= 1 ? 1 : 0, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
-        else if (C == 3) hipLaunchKernelGGL(adam_tex_vec_kernel<3>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, active, step <= 1 ? 1 : 0, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
-        else hipLaunchKernelGGL(adam_tex_vec_kernel<4>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, active, step <= 1 ? 1 : 0, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+        dim3 gridv((W * C + epb - 1) / epb, (H >> 1) > 2048 ? 2048 : (H >> 1));
+        if (C == 1) hipLaunchKernelGGL(adam_tex_vec_kernel<1>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+        else if (C == 2) hipLaunchKernelGGL(adam_tex_vec_kernel<2>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+        else if (C == 3) hipLaunchKernelGGL(adam_tex_vec_kernel<3>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+        else hipLaunchKernelGGL(adam_tex_vec_kernel<4>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
         return hipGetLastError();
     }
     dim3 grid(((W >> 1) * C + 255) / 256, (H >> 1) > 4096 ? 4096 : (H >> 1));

@@ -13,12 +13,10 @@ class FusedAdam(torch.optim.Optimizer):
     read-modify-write of every texture per step).  Until step() has run, `p.grad` then lacks that term: code that reduces gradients
     across ranks in between must treat the pair (p.grad, p._texir_grad_l1), as dist_util.reduce_texture_grads does."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, fuse_mip_fold=False, skip_untouched=True):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, fuse_mip_fold=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._clamps = {}
         self.fuse_mip_fold = bool(fuse_mip_fold)
-        # with fuse_mip_fold: texture segments whose moments are still exactly zero (never a gradient) are not visited (bit-identical)
-        self.skip_untouched = bool(skip_untouched) and __import__("os").environ.get("TEXIR_ADAM_DENSE", "0") != "1"      # (env: A/B switch)
         for group in self.param_groups:
             for p in group["params"]:
                 p._texir_defer_fold = self.fuse_mip_fold and p.dim() == 3 and p.shape[0] % 2 == 0 and p.shape[1] % 2 == 0
@@ -86,14 +84,8 @@ class FusedAdam(torch.optim.Optimizer):
                     # level 1 of the next forward's mip stack is written on the way (texture._mips_for then builds levels 2.. only)
                     mips = getattr(p, "_texir_mips", None)
                     mip1 = mips[1] if (mips is not None and mips[1].numel() >= (H // 2) * (W // 2) * C and mips[1].device == p.device) else None
-                    # segments that never received a gradient are skipped exactly (kernel comment); the flags live with the state
-                    act = st.get("active")
-                    if act is None:
-                        # (only from the very first step on: moments restored from elsewhere come without flags -> dense steps)
-                        n_act = int(L.texir_adam_tex_active_elems(H, W, C)) if (self.skip_untouched and st["step"] == 1) else 0
-                        act = st["active"] = torch.zeros(n_act, device=p.device, dtype=torch.uint8) if n_act else False
                     _lib.check(L.texir_adam_step_tex(_lib.ptr(p), _lib.ptr(g), _lib.ptr(mask), _lib.ptr(g1), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]),
-                                                     _lib.ptr(mip1), _lib.ptr(act) if torch.is_tensor(act) else None, H, W, C, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                     _lib.ptr(mip1), H, W, C, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                                      int(st["step"]), lo, hi, _lib.stream_ptr()))
                     p._texir_mip1_version = (p.data_ptr(), p._version) if mip1 is not None else None
                     if not getattr(p, "_texir_l1_static", False):      # (hipGraph replay re-fills the same buffer: keep it)

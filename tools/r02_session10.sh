@@ -1,7 +1,7 @@
 #!/bin/bash
-# round-2 GPU session 9: Adam segment skipping (exactness + A/B), full suite, final profiles and bench lines
+# round-2 GPU session 10: full suite, final profiles and bench lines of the round
 R=${GRAFT_REPO_ROOT:-/root/repo}
-out=$R/gpurun_out/r02_s9
+out=$R/gpurun_out/r02_s10
 mkdir -p $out
 cd $R
 export TEXIR_SYNTH_CACHE=/tmp/texir_synth
@@ -12,11 +12,11 @@ abm() { label=$1; shift
   echo "$label material_step_ms,irt $v" | tee -a $out/abm.txt
 }
 abm default X=1
-abm adam_dense TEXIR_ADAM_DENSE=1
-abm default_again X=1
+
+
 bash tools/trace_mat_step.sh > $out/mat_step_trace.txt 2>&1
 tail -n 30 $out/mat_step_trace.txt | cut -c1-110
-bash tools/profile_round.sh r02_s9/prof c4 c2 > $out/profile_round.log 2>&1
+bash tools/profile_round.sh r02_s10/prof c4 c2 > $out/profile_round.log 2>&1
 tail -n 2 $out/profile_round.log | cut -c1-300
 cp $R/profiles/pmc_c4.json $R/profiles/pmc_c2.json $out/ 2>/dev/null
 cp $out/prof/c4_kernel_stats.csv $out/prof/bench_default_under_rocprof.json $out/ 2>/dev/null
