@@ -119,6 +119,30 @@ def test_irt_vs_oracle_various_N(room, N, mode, per_wave, monkeypatch):
     assert rel_l2(irr[v], ref[v]) < 1e-4
 
 
+def test_scalar_float_node_path_changes_nothing(room, tx, monkeypatch):
+    """wave-uniform node steps read the FLOAT form of the node through the scalar cache (TEXIR_UNIFORM_SLOAD = 2); a scene created with
+    TEXIR_UNIFORM_FLOAT=0 has no float nodes and every step takes the per-lane quantised path.  Both prune with conservative boxes, so the
+    closest hits -- and with them every irradiance bit -- must be the same."""
+    g, sc, _ = room
+    monkeypatch.setenv("TEXIR_UNIFORM_FLOAT", "0")
+    sc_q = tx.Scene(g["verts"], g["tris"], g["tri_uvs"], g["hdr"])
+    monkeypatch.delenv("TEXIR_UNIFORM_FLOAT")
+    assert sc_q.info()["node_bytes"] < sc.info()["node_bytes"]          # (the default scene carries both forms)
+    v = np.argwhere(g["valid"].reshape(-1) > 0)[:, 0]
+    ids = torch.from_numpy(v.astype(np.int32)).cuda()
+    args = (torch.from_numpy(g["pos"]), torch.from_numpy(g["nrm"]), torch.from_numpy(g["shift"]), 256, "uniform")
+    a = sc.irt_generate(*args, texel_ids=ids).cpu().numpy()
+    b = sc_q.irt_generate(*args, texel_ids=ids).cpu().numpy()
+    assert np.array_equal(a[v], b[v])
+    # single rays as well (incoherent: the scalar path is taken only by chance)
+    rng = np.random.default_rng(5)
+    o = np.repeat(g["pos"].reshape(-1, 3)[v[:4096]] + 1e-3 * g["nrm"].reshape(-1, 3)[v[:4096]], 4, 0).astype(np.float32)
+    d = rng.normal(size=o.shape).astype(np.float32)
+    ra = sc.trace_shade(torch.from_numpy(o), torch.from_numpy(d)).cpu().numpy()
+    rb = sc_q.trace_shade(torch.from_numpy(o), torch.from_numpy(d)).cpu().numpy()
+    assert np.array_equal(ra, rb)
+
+
 def test_irt_constant_radiance_closed_room(tx):
     """analytic KAT: closed room, constant radiance L  =>  E -> pi*L  (sum ndl*2pi/N -> pi)"""
     from texir_code_amd import synth

@@ -189,7 +189,7 @@ void emit4_fill(GpuNode4& g, const Box& nb, const Tmp* const* kids, int nk, cons
     g.lox = lo[0]; g.loy = lo[1]; g.loz = lo[2]; g.hix = hi[0]; g.hiy = hi[1]; g.hiz = hi[2];
 }
 
-#if TEXIR_NODE_F32
+#if TEXIR_BUILD_F32NODES
 static std::vector<GpuNode4F>* g_out4f = nullptr;
 
 static void emit4f_fill(GpuNode4F& g, const Tmp* const* kids, int nk, const int32_t* codes, int32_t dummy_leaf)
@@ -210,7 +210,7 @@ int32_t emit4(const Tmp* t, std::vector<GpuNode4>& out, int depth, int& max_dept
 {
     int32_t idx = (int32_t)out.size();
     out.emplace_back();
-#if TEXIR_NODE_F32
+#if TEXIR_BUILD_F32NODES
     g_out4f->emplace_back();
 #endif
     if (depth > max_depth) max_depth = depth;
@@ -227,7 +227,7 @@ int32_t emit4(const Tmp* t, std::vector<GpuNode4>& out, int depth, int& max_dept
     int32_t codes[4];
     for (int k = 0; k < nk; k++) codes[k] = kids[k]->count ? leaf_code(kids[k]) : emit4(kids[k], out, depth + 1, max_depth, dummy_leaf);
     emit4_fill(out[idx], t->box, kids, nk, codes, dummy_leaf);
-#if TEXIR_NODE_F32
+#if TEXIR_BUILD_F32NODES
     emit4f_fill((*g_out4f)[idx], kids, nk, codes, dummy_leaf);
 #endif
     return idx;
@@ -278,7 +278,7 @@ void build_bvh(const float* verts, int V, const int32_t* tris, int T, const floa
     out.nodes4.clear();
     out.nodes4.reserve((size_t)T / 2 + 16);
     int d4 = 0;
-#if TEXIR_NODE_F32
+#if TEXIR_BUILD_F32NODES
     out.nodes4f.clear();
     out.nodes4f.reserve((size_t)T / 2 + 16);
     g_out4f = &out.nodes4f;
@@ -288,10 +288,12 @@ void build_bvh(const float* verts, int V, const int32_t* tris, int T, const floa
     emit4(root.get(), out.nodes4, 1, d4, dummy_leaf);
     out.max_depth4 = d4;
     out.tris.resize((size_t)T + 1);
-    out.uvs.resize((size_t)T + 1);
     std::memset(&out.tris[T], 0, sizeof(GpuTri));
-    std::memset(&out.uvs[T], 0, sizeof(GpuTriUV));
     out.tris[T].prim = 0xFFFFFFFFu;
+#if !TEXIR_TRI64
+    out.uvs.resize((size_t)T + 1);
+    std::memset(&out.uvs[T], 0, sizeof(GpuTriUV));
+#endif
     for (int i = 0; i < T; i++) {
         int p = order[i];
         const float* a = verts + 3 * (size_t)tris[3 * (size_t)p];
@@ -303,10 +305,16 @@ void build_bvh(const float* verts, int V, const int32_t* tris, int T, const floa
 #else
         for (int k = 0; k < 3; k++) { g.v0[k] = a[k]; g.e1[k] = b[k] - a[k]; g.e2[k] = cc[k] - a[k]; }
 #endif
-        g.prim = (uint32_t)p; g.pad1 = g.pad2 = 0.f;
+        g.prim = (uint32_t)p;
+        const float* uv = tri_uvs + 6 * (size_t)p;
+#if TEXIR_TRI64
+        g.uv0x = uv[0]; g.uv0y = uv[1]; g.uv1x = uv[2]; g.uv1y = uv[3]; g.uv2x = uv[4]; g.uv2y = uv[5];
+#else
+        g.pad1 = g.pad2 = 0.f;
         GpuTriUV& u = out.uvs[i];
-        std::memcpy(u.uv, tri_uvs + 6 * (size_t)p, sizeof(float) * 6);
+        std::memcpy(u.uv, uv, sizeof(float) * 6);
         u.uv[6] = u.uv[7] = 0.f;
+#endif
     }
 }
 

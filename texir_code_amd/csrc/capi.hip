@@ -19,7 +19,7 @@ using namespace texir;
 struct texir_scene {
     int device = 0;
     SceneDev dev{};
-    void* d_nodes4 = nullptr;
+    void* d_nodes4 = nullptr; void* d_nodes4f = nullptr;
     void* d_nodes = nullptr; void* d_tris = nullptr; void* d_uvs = nullptr; float* d_tex = nullptr;
     float* d_tex_tiled = nullptr;        // retiled copy read by the hit shader (texture layouts 1, 2); d_tex stays the row-major master
     size_t tiled_bytes = 0;
@@ -62,7 +62,7 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
     if (!verts || !tris || !tri_uvs || !hdr_tex || !out) return fail(TEXIR_ERR_INVALID, "texir_scene_create: null argument");
     if (V <= 0 || T <= 0 || Ht <= 0 || Wt <= 0) return fail(TEXIR_ERR_INVALID, "texir_scene_create: empty mesh or texture");
     // the traversal addresses nodes and triangles with 32-bit byte offsets (64-byte nodes, 48-byte triangle records)
-    if ((uint64_t)(T + 1) * 48u >= (1ull << 32) || (TEXIR_NODE_F32 && (uint64_t)T * 64u >= (1ull << 32))) return fail(TEXIR_ERR_INVALID, "texir_scene_create: too many triangles (%d; limit 89 M)", (int)T);
+    if ((uint64_t)(T + 1) * sizeof(GpuTri) >= (1ull << 32) || (TEXIR_NODE_F32 && (uint64_t)T * 64u >= (1ull << 32))) return fail(TEXIR_ERR_INVALID, "texir_scene_create: too many triangles (%d; limit 67 M with 64-byte, 89 M with 48-byte triangles)", (int)T);
     for (int64_t i = 0; i < 3 * (int64_t)T; i++)
         if (tris[i] < 0 || tris[i] >= V) return fail(TEXIR_ERR_INVALID, "texir_scene_create: triangle index %d out of range", (int)tris[i]);
     HIP_TRY(hipSetDevice(device));
@@ -89,18 +89,25 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
 #else
         if ((e = hipMalloc(&s->d_nodes4, h.nodes4.size() * sizeof(GpuNode4))) != hipSuccess) return bail(e, "hipMalloc nodes4");
         if ((e = hipMemcpy(s->d_nodes4, h.nodes4.data(), h.nodes4.size() * sizeof(GpuNode4), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload nodes4");
+#if TEXIR_UNIFORM_SLOAD >= 2
+        // the float form of the same nodes, read by wave-uniform node steps through the scalar cache (TEXIR_UNIFORM_FLOAT=0: A/B switch)
+        if (!(getenv("TEXIR_UNIFORM_FLOAT") && atoi(getenv("TEXIR_UNIFORM_FLOAT")) == 0)) {
+            if ((e = hipMalloc(&s->d_nodes4f, h.nodes4f.size() * sizeof(GpuNode4F))) != hipSuccess) return bail(e, "hipMalloc nodes4f");
+            if ((e = hipMemcpy(s->d_nodes4f, h.nodes4f.data(), h.nodes4f.size() * sizeof(GpuNode4F), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload nodes4f");
+        }
+#endif
 #endif
     }
     if ((e = hipMalloc(&s->d_nodes, h.nodes.size() * sizeof(GpuNode))) != hipSuccess) return bail(e, "hipMalloc nodes");
     if ((e = hipMalloc(&s->d_tris, h.tris.size() * sizeof(GpuTri))) != hipSuccess) return bail(e, "hipMalloc tris");
-    if ((e = hipMalloc(&s->d_uvs, h.uvs.size() * sizeof(GpuTriUV))) != hipSuccess) return bail(e, "hipMalloc uvs");
+    if (!h.uvs.empty() && (e = hipMalloc(&s->d_uvs, h.uvs.size() * sizeof(GpuTriUV))) != hipSuccess) return bail(e, "hipMalloc uvs");
     if ((e = hipMalloc((void**)&s->d_tex, s->tex_bytes)) != hipSuccess) return bail(e, "hipMalloc texture");
     if ((e = hipMalloc((void**)&s->d_work, texir_scene::kWorkSlots * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc work counters");
     if ((e = hipMemcpy(s->d_nodes, h.nodes.data(), h.nodes.size() * sizeof(GpuNode), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload nodes");
     if ((e = hipMemcpy(s->d_tris, h.tris.data(), h.tris.size() * sizeof(GpuTri), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload tris");
-    if ((e = hipMemcpy(s->d_uvs, h.uvs.data(), h.uvs.size() * sizeof(GpuTriUV), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload uvs");
+    if (!h.uvs.empty() && (e = hipMemcpy(s->d_uvs, h.uvs.data(), h.uvs.size() * sizeof(GpuTriUV), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload uvs");
     if ((e = hipMemcpy(s->d_tex, hdr_tex, s->tex_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload texture");
-    s->dev.nodes4 = (const float4*)s->d_nodes4;
+    s->dev.nodes4 = (const float4*)s->d_nodes4; s->dev.nodes4f = (const float4*)s->d_nodes4f;
     s->dev.nodes = (const float4*)s->d_nodes; s->dev.tris = (const float4*)s->d_tris; s->dev.uvs = (const float4*)s->d_uvs;
     s->dev.tex = s->d_tex; s->dev.Ht = Ht; s->dev.Wt = Wt; s->dev.tex_layout = 0; s->dev.tiles_x = 0;
     // hit-shader texture layout: 2 (one 128-byte line per bilinear footprint) by default, TEXIR_TEX_LAYOUT=0|1|2 for A/B runs
@@ -123,6 +130,7 @@ int texir_scene_destroy(texir_scene* s)
     if (!s) return TEXIR_OK;
     (void)hipSetDevice(s->device);
     if (s->d_nodes4) (void)hipFree(s->d_nodes4);
+    if (s->d_nodes4f) (void)hipFree(s->d_nodes4f);
     if (s->d_nodes) (void)hipFree(s->d_nodes);
     if (s->d_tris) (void)hipFree(s->d_tris);
     if (s->d_uvs) (void)hipFree(s->d_uvs);
@@ -147,8 +155,8 @@ int texir_scene_info(const texir_scene* s, int64_t out[8])
 {
     if (!s || !out) return fail(TEXIR_ERR_INVALID, "texir_scene_info: null argument");
     out[0] = s->width == 4 ? s->n_nodes4 : s->n_nodes; out[1] = s->n_tris; out[2] = s->max_depth;
-    out[3] = s->width == 4 ? s->n_nodes4 * (int64_t)(TEXIR_NODE_F32 ? sizeof(GpuNode4F) : sizeof(GpuNode4)) : s->n_nodes * (int64_t)sizeof(GpuNode);
-    out[4] = s->n_tris * (int64_t)sizeof(GpuTri); out[5] = s->n_tris * (int64_t)sizeof(GpuTriUV); out[6] = (int64_t)(s->d_tex_tiled ? s->tiled_bytes : s->tex_bytes); out[7] = s->device;
+    out[3] = s->width == 4 ? s->n_nodes4 * (int64_t)(TEXIR_NODE_F32 ? sizeof(GpuNode4F) : sizeof(GpuNode4) + (s->d_nodes4f ? sizeof(GpuNode4F) : 0)) : s->n_nodes * (int64_t)sizeof(GpuNode);
+    out[4] = s->n_tris * (int64_t)sizeof(GpuTri); out[5] = s->d_uvs ? s->n_tris * (int64_t)sizeof(GpuTriUV) : 0; out[6] = (int64_t)(s->d_tex_tiled ? s->tiled_bytes : s->tex_bytes); out[7] = s->device;
     return TEXIR_OK;
 }
 

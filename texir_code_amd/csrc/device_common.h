@@ -16,14 +16,24 @@
 #ifndef TEXIR_FAST_DEQUANT
 #define TEXIR_FAST_DEQUANT 0
 #endif
+#ifndef TEXIR_USF_MIN_LANES
+#define TEXIR_USF_MIN_LANES 1
+#endif
+#ifndef TEXIR_PSORT3
+#define TEXIR_PSORT3 0
+#endif
+// TEXIR_UNIFORM_SLOAD (bvh_build.h): 1: wave-uniform node steps read their node through the scalar cache (s_load) instead of 64 x 64 bytes
+// through the vector L1; 2: ... and read the float form of the node when the rays' direction signs agree as well (see traverse)
 
 namespace texir {
 
 struct SceneDev {
     const float4* nodes4;  // GpuNode4 as 4 x 16 B (4-wide quantised tree; null when the scene was built binary-only)
+    const float4* nodes4f; // GpuNode4F (float child planes of the same tree, index for index) -- read through the scalar cache by wave-uniform
+                           // node steps (TEXIR_UNIFORM_SLOAD = 2); null otherwise
     const float4* nodes;   // GpuNode as 4 x float4
-    const float4* tris;    // GpuTri as 3 x float4
-    const float4* uvs;     // GpuTriUV as 2 x float4
+    const float4* tris;    // GpuTri as kTriQuads x float4
+    const float4* uvs;     // GpuTriUV as 2 x float4 (null when the triangle record carries the uvs: TEXIR_TRI64)
     const float* tex;      // [Ht,Wt,3] row-major (layout 0), or the retiled copy the hit shader reads (layouts 1, 2: see shade_hit)
     int Ht, Wt;
     int tex_layout;        // 0 row-major; 1 = 8x8-texel tiles of 12-byte texels; 2 = overlapping 3x3 tiles at stride 2, one 128-byte line each
@@ -102,13 +112,37 @@ __device__ __forceinline__ void sample_dir(int mode, float s0, float s1, float r
     for (int a = 0; a < 3; a++) L[a] = f.V[a] * sp + f.n[a] * ct + f.U[a] * cp;
 }
 
+// corner uvs of the triangle in leaf slot `slot`: a = (uv0, uv1), b = (uv2, -, -)
+__device__ __forceinline__ void tri_uvs(const SceneDev& sc, int slot, float4& a, float4& b)
+{
+#if TEXIR_TRI64
+    // the w components of the record's first three quads and its fourth quad (the line the intersection test has just read)
+    const char* const tp = reinterpret_cast<const char*>(sc.tris) + ((uint32_t)slot << 6);
+    const float4 q3 = *reinterpret_cast<const float4*>(tp + 48);
+    a.x = *reinterpret_cast<const float*>(tp + 12); a.y = *reinterpret_cast<const float*>(tp + 28); a.z = *reinterpret_cast<const float*>(tp + 44); a.w = q3.x;
+    b.x = q3.y; b.y = q3.z; b.z = b.w = 0.f;
+#else
+    a = sc.uvs[2 * (size_t)slot]; b = sc.uvs[2 * (size_t)slot + 1];
+#endif
+}
+// primitive id (row of the caller's index array) of the triangle in leaf slot `slot`
+__device__ __forceinline__ uint32_t tri_prim(const SceneDev& sc, int slot)
+{
+#if TEXIR_TRI64
+    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(sc.tris) + ((uint32_t)slot << 6) + 60);
+#else
+    return __float_as_uint(sc.tris[3 * (size_t)slot].w);
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------
 // hit shader: query_irf post-intersection math (tracer_o3d_irt.py:248-267)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void shade_hit(const SceneDev& sc, int tri_slot, float bu, float bv, float* rgb)
 {
     float u = fminf(fmaxf(bu, 0.f), 1.f), v = fminf(fmaxf(bv, 0.f), 1.f);      // :250 np.clip
-    float4 a = sc.uvs[2 * (size_t)tri_slot], b = sc.uvs[2 * (size_t)tri_slot + 1];
+    float4 a, b;
+    tri_uvs(sc, tri_slot, a, b);
     float w = 1.0f - u - v;
     // :260 (float64 in the reference; float32 here -- <=1e-7 in uv, far below a texel)
     float gx = a.x * w + a.z * u + b.x * v;
@@ -257,6 +291,13 @@ __device__ __forceinline__ void traverse(const SceneDev& sc, RayState& r, typena
     const float dx = r.dx, dy = r.dy, dz = r.dz, idx = r.idx, idy = r.idy, idz = r.idz, oodx = r.oodx, oody = r.oody, oodz = r.oodz;
     Hit h = r.h;
     int node = r.node;
+#if TEXIR_UNIFORM_SLOAD >= 2
+    // byte offsets of the NEAR plane array of each axis inside a 128-byte float node (far = offset ^ 16), wave-uniform when the rays' signs agree
+    const uint32_t lon = (idx < 0.f ? 16u : 0u) | ((idy < 0.f ? 48u : 32u) << 8) | ((idz < 0.f ? 80u : 64u) << 16);
+    const uint32_t son = (uint32_t)__builtin_amdgcn_readfirstlane((int)lon);
+    const bool signs_uniform = sc.nodes4f != nullptr && !__any(lon != son);
+    const uint32_t son0 = son & 255u, son1 = (son >> 8) & 255u, son2 = son >> 16;
+#endif
     (void)dx; (void)dy; (void)dz;       // (the watertight intersector of the 4-wide path reads the ray's shear rows instead)
     auto make = [](int code, float tn) -> Entry { if constexpr (CULL) return make_int2(code, __float_as_int(tn)); else return code; };
     // LDS part and private overflow are kept in separate, wave-uniformly guarded code paths: the overflow is almost never
@@ -304,6 +345,76 @@ __device__ __forceinline__ void traverse(const SceneDev& sc, RayState& r, typena
                     const float tn = fmaxf(fmaxf(nxt, nyt), fmaxf(nzt, 0.f)), tf = fminf(fminf(fxt, fyt), fminf(fzt, h.t));
                     key[k] = tn <= tf ? tn : __builtin_inff();
                 }
+#else
+#if TEXIR_UNIFORM_SLOAD
+                // The box tests of one node step, on node words that are either per-lane (vector loads) or wave-uniform (scalar loads):
+                float key[4]; int code[4];
+                auto box4 = [&](const auto& q0x, const auto& q0y, const auto& q0z, const auto& q0w, const auto& q1x, const auto& q1y, const auto& q1z, const auto& q1w,
+                                const auto& q2x, const auto& q2y, const auto& q2z, const auto& q2w) __attribute__((always_inline)) {
+                    const float sx = __uint_as_float(q0w) * idx, sy = __uint_as_float(q2z) * idy, sz = __uint_as_float(q2w) * idz;
+                    const float bx = __uint_as_float(q0x) * idx - oodx, by = __uint_as_float(q0y) * idy - oody, bz = __uint_as_float(q0z) * idz - oodz;
+                    const uint32_t nx_ = idx < 0.f ? q1w : q1x, fx_ = idx < 0.f ? q1x : q1w;
+                    const uint32_t ny_ = idy < 0.f ? q2x : q1y, fy_ = idy < 0.f ? q1y : q2x;
+                    const uint32_t nz_ = idz < 0.f ? q2y : q1z, fz_ = idz < 0.f ? q1z : q2y;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int sh = 8 * k;
+                        float nxt = (float)((nx_ >> sh) & 255u) * sx + bx, fxt = (float)((fx_ >> sh) & 255u) * sx + bx;
+                        float nyt = (float)((ny_ >> sh) & 255u) * sy + by, fyt = (float)((fy_ >> sh) & 255u) * sy + by;
+                        float nzt = (float)((nz_ >> sh) & 255u) * sz + bz, fzt = (float)((fz_ >> sh) & 255u) * sz + bz;
+                        float tn = fmaxf(fmaxf(nxt, nyt), fmaxf(nzt, 0.f));
+                        float tf = fminf(fminf(fxt, fyt), fminf(fzt, h.t));
+                        key[k] = tn <= tf ? tn : __builtin_inff();
+                    }
+                };
+                // Wave-uniform steps (the rays of a pass leave neighbouring points in nearly the same direction and walk the upper levels
+                // together: 45 % of the wave-level node steps on c4): a vector fetch costs the L1 64 lanes x 64 bytes whether or not the lanes
+                // agree (tools/tcp_node.hip: 60 clocks per wave fetch from 1 to 16 distinct nodes); the scalar path costs it nothing.
+                {
+                    const int n0 = __builtin_amdgcn_readfirstlane(node);
+#if TEXIR_UNIFORM_SLOAD >= 2
+                    // ... and when the wave's rays also share their direction signs (a pass is one ~2.5 degree direction cell: they do unless the
+                    // cell straddles an axis plane), the step reads the FLOAT planes of the node (GpuNode4F) through wave-uniform offsets that pick
+                    // the near / far plane arrays: no byte -> float conversion (24 per step), no sign select, no origin / cell-size set-up.
+                    if (signs_uniform && !__any(node != n0)
+#if TEXIR_USF_MIN_LANES > 1
+                        && __popcll(__ballot(1)) >= TEXIR_USF_MIN_LANES       // (few-lane tails sit deep in the tree: their nodes miss the small scalar cache)
+#endif
+                       ) {
+                        typedef float F4 __attribute__((ext_vector_type(4)));
+                        typedef int32_t I4 __attribute__((ext_vector_type(4)));
+                        const char __attribute__((address_space(4)))* const nb =
+                            (const char __attribute__((address_space(4)))*)(reinterpret_cast<const char*>(sc.nodes4f) + ((uint32_t)n0 << 7));
+                        auto ldf = [&](uint32_t off) { return *(const F4 __attribute__((address_space(4)))*)(nb + off); };
+                        const F4 pnx = ldf(son0), pfx = ldf(son0 ^ 16u), pny = ldf(son1), pfy = ldf(son1 ^ 16u), pnz = ldf(son2), pfz = ldf(son2 ^ 16u);
+                        const I4 ch = *(const I4 __attribute__((address_space(4)))*)(nb + 96u);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const float nxt = pnx[k] * idx - oodx, fxt = pfx[k] * idx - oodx, nyt = pny[k] * idy - oody, fyt = pfy[k] * idy - oody;
+                            const float nzt = pnz[k] * idz - oodz, fzt = pfz[k] * idz - oodz;
+                            const float tn = fmaxf(fmaxf(nxt, nyt), fmaxf(nzt, 0.f)), tf = fminf(fminf(fxt, fyt), fminf(fzt, h.t));
+                            key[k] = tn <= tf ? tn : __builtin_inff();
+                        }
+                        code[0] = ch.x; code[1] = ch.y; code[2] = ch.z; code[3] = ch.w;
+                    } else
+#else
+                    if (!__any(node != n0)) {
+                        typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+                        typedef const U4 __attribute__((address_space(4)))* ConstQ;
+                        ConstQ sp = (ConstQ)(reinterpret_cast<const char*>(sc.nodes4) + ((uint32_t)n0 << 6));
+                        const U4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+                        box4(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w);
+                        code[0] = (int)s3.x; code[1] = (int)s3.y; code[2] = (int)s3.z; code[3] = (int)s3.w;
+                    } else
+#endif
+                    {
+                        const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes4) + ((uint32_t)node << 6));
+                        const uint4 v0 = np[0], v1 = np[1], v2 = np[2], v3 = np[3];
+                        box4(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w);
+                        code[0] = (int)v3.x; code[1] = (int)v3.y; code[2] = (int)v3.z; code[3] = (int)v3.w;
+                    }
+                }
+                if (STATS) { n_nodes++; if (wave_iters && first_active()) wave_iters[0]++; }
 #else
 #if TEXIR_UNIFORM_BCAST
                 // Wave-uniform steps (the rays of a pass leave neighbouring points in nearly the same direction: they walk the upper
@@ -388,9 +499,15 @@ __device__ __forceinline__ void traverse(const SceneDev& sc, RayState& r, typena
                 }
 #endif
 #endif
+#endif
                 // sort the four (key, code) pairs ascending: 5-comparator network
 #define TEXIR_CSWAP(a, b) { bool s_ = key[b] < key[a]; float ka = s_ ? key[b] : key[a], kb = s_ ? key[a] : key[b]; int ca = s_ ? code[b] : code[a], cb = s_ ? code[a] : code[b]; key[a] = ka; key[b] = kb; code[a] = ca; code[b] = cb; }
+#if TEXIR_PSORT3
+                // (A/B) nearest child first, the other three pushed in slot order: 3 instead of 5 comparators (the culling pop keeps it exact)
+                TEXIR_CSWAP(0, 1) TEXIR_CSWAP(2, 3) TEXIR_CSWAP(0, 2)
+#else
                 TEXIR_CSWAP(0, 1) TEXIR_CSWAP(2, 3) TEXIR_CSWAP(0, 2) TEXIR_CSWAP(1, 3) TEXIR_CSWAP(1, 2)
+#endif
 #undef TEXIR_CSWAP
                 const float inf = __builtin_inff();
                 if (!__any(top + 3 * kBlock > lim)) {
@@ -442,7 +559,7 @@ __device__ __forceinline__ void traverse(const SceneDev& sc, RayState& r, typena
             if constexpr (!CULL) node = pop();           // (early: the LDS read overlaps the triangle loads)
             int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
             for (int i = first; i < first + cnt; i++) {
-                const float4* tp = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.tris) + (uint32_t)i * 48u);
+                const float4* tp = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.tris) + (uint32_t)i * (uint32_t)(16 * kTriQuads));
                 float4 v0 = tp[0], e1 = tp[1], e2 = tp[2];
                 if (STATS) { n_tris++; if (wave_iters && first_active()) wave_iters[1]++; }
 #if TEXIR_TRI_WATERTIGHT

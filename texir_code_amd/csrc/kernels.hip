@@ -283,7 +283,7 @@ __global__ __launch_bounds__(kBlock) void trace_shade_kernel(SceneDev sc, const 
         if (hit) shade_hit(sc, h.slot, h.u, h.v, L);
         rad[3 * r] = L[0]; rad[3 * r + 1] = L[1]; rad[3 * r + 2] = L[2];
         if (t_hit) t_hit[r] = h.t;
-        if (prim) prim[r] = h.slot >= 0 ? __float_as_uint(sc.tris[3 * (size_t)h.slot].w) : 0xFFFFFFFFu;
+        if (prim) prim[r] = h.slot >= 0 ? tri_prim(sc, h.slot) : 0xFFFFFFFFu;
         if (puv) { puv[2 * r] = h.u; puv[2 * r + 1] = h.v; }
     }
 }

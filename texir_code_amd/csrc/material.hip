@@ -53,12 +53,12 @@ __global__ __launch_bounds__(kBlock) void gbuffer_kernel(SceneDev sc, GbufArgs g
         float o_pos[3] = {1.f, 0.f, 0.f}, o_n[3] = {1.f, 0.f, 0.f}, o_uv[2] = {0.f, 0.f}, o_da[4] = {0.f, 0.f, 0.f, 0.f};   // bg (mat_nvdiffrast.py:125)
         float m = 0.f; int32_t tri = 0;
         if (h.slot >= 0) {
-            const float4* tp = sc.tris + 3 * (size_t)h.slot;
+            const float4* tp = sc.tris + kTriQuads * (size_t)h.slot;
             float4 v0 = tp[0], e1 = tp[1], e2 = tp[2];
 #if TEXIR_TRI_WATERTIGHT
             e1.x -= v0.x; e1.y -= v0.y; e1.z -= v0.z; e2.x -= v0.x; e2.y -= v0.y; e2.z -= v0.z;      // the record holds v1, v2
 #endif
-            m = 1.f; tri = (int32_t)__float_as_uint(v0.w) + 1;
+            m = 1.f; tri = (int32_t)tri_prim(sc, h.slot) + 1;
             const float u = h.u, v = h.v, w = 1.f - u - v;
             o_pos[0] = v0.x + u * e1.x + v * e2.x; o_pos[1] = v0.y + u * e1.y + v * e2.y; o_pos[2] = v0.z + u * e1.z + v * e2.z;
             if (g.cnrm) {
@@ -80,7 +80,8 @@ __global__ __launch_bounds__(kBlock) void gbuffer_kernel(SceneDev sc, GbufArgs g
                 float qx = by[k] * e1.z - bz[k] * e1.y, qy = bz[k] * e1.x - bx[k] * e1.z, qz = bx[k] * e1.y - by[k] * e1.x;
                 dv[k] = (dx * qx + dy * qy + dz * qz) * inv;
             }
-            float4 a = sc.uvs[2 * (size_t)h.slot], b = sc.uvs[2 * (size_t)h.slot + 1];
+            float4 a, b;
+            tri_uvs(sc, h.slot, a, b);
             float a1x = a.z - a.x, a1y = a.w - a.y, a2x = b.x - a.x, a2y = b.y - a.y;
             o_uv[0] = a.x * w + a.z * u + b.x * v; o_uv[1] = a.y * w + a.w * u + b.y * v;
             o_da[0] = a1x * du[0] + a2x * dv[0]; o_da[1] = a1x * du[1] + a2x * dv[1];        // du/dX, du/dY

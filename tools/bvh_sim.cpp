@@ -68,7 +68,7 @@ static uint32_t sample_index(uint32_t cell, int log2N)
 
 struct Ray { float o[3], d[3], id[3], ood[3]; float t; int slot; int node; std::vector<int> stk; std::vector<float> stk_t; };
 
-struct Counters { double rays = 0, nodes = 0, tris = 0, wnode = 0, wtri = 0, culled = 0, hits = 0, wcull = 0, maxsp = 0, wuni = 0, wdeep[4] = {0, 0, 0, 0}, lines = 0; };
+struct Counters { double rays = 0, nodes = 0, tris = 0, wnode = 0, wtri = 0, culled = 0, hits = 0, wcull = 0, maxsp = 0, wuni = 0, wuni0 = 0, wdeep[4] = {0, 0, 0, 0}, lines = 0; };
 
 static const int kSent = 0x7FFFFFFF;
 
@@ -77,8 +77,8 @@ int main(int argc, char** argv)
     if (argc < 2) { fprintf(stderr, "usage: bvh_sim <dir> [groups=64] [passes=64] [variant flags: cull cull8 nosort]\n"); return 1; }
     std::string dir = argv[1];
     int n_groups = argc > 2 ? atoi(argv[2]) : 64, n_pass = argc > 3 ? atoi(argv[3]) : 64;
-    bool cull = false, cull8 = false, nosort = false;
-    for (int i = 4; i < argc; i++) { if (!strcmp(argv[i], "cull")) cull = true; if (!strcmp(argv[i], "cull8")) cull = cull8 = true; if (!strcmp(argv[i], "nosort")) nosort = true; }
+    bool cull = false, cull8 = false, nosort = false, psort3 = false;
+    for (int i = 4; i < argc; i++) { if (!strcmp(argv[i], "cull")) cull = true; if (!strcmp(argv[i], "cull8")) cull = cull8 = true; if (!strcmp(argv[i], "nosort")) nosort = true; if (!strcmp(argv[i], "psort3")) psort3 = true; }
     auto verts = load<float>(dir + "/verts.f32"); auto tris = load<int32_t>(dir + "/tris.i32"); auto uvs = load<float>(dir + "/tri_uvs.f32");
     auto pos = load<float>(dir + "/pos.f32"); auto nrm = load<float>(dir + "/nrm.f32"); auto shift = load<float>(dir + "/shift.f32");
     auto ids = load<int32_t>(dir + "/ids.i32"); auto meta = load<int32_t>(dir + "/meta.i32");
@@ -207,6 +207,7 @@ int main(int argc, char** argv)
                     r.t = INFINITY; r.slot = -1; r.node = 0; r.stk.clear(); r.stk_t.clear();
                 }
                 c.rays += 64;
+                bool still_uni = true;      // no divergent node step yet in this pass
                 auto pop = [&](Ray& r) -> int {
                     for (;;) {
                         if (r.stk.empty()) return kSent;
@@ -226,6 +227,7 @@ int main(int argc, char** argv)
                             int first = -1; bool uni = true; size_t deep = 0; std::vector<int> ln;
                             for (auto& r : R) if (r.node >= 0 && r.node != kSent) { if (first < 0) first = r.node; else if (r.node != first) uni = false; if (r.stk.size() > deep) deep = r.stk.size(); ln.push_back(r.node >> 1); }
                             if (uni) c.wuni++;
+                            if (uni && still_uni) c.wuni0++; else still_uni = false;
                             if (deep + 3 > 8) c.wdeep[0]++; if (deep + 3 > 10) c.wdeep[1]++; if (deep + 3 > 11) c.wdeep[2]++; if (deep + 3 > 16) c.wdeep[3]++;
                             std::sort(ln.begin(), ln.end()); c.lines += (double)(std::unique(ln.begin(), ln.end()) - ln.begin());
                         }
@@ -248,7 +250,7 @@ int main(int argc, char** argv)
                             }
                             if (!nosort) {
 #define CS(a, b) if (key[b] < key[a]) { std::swap(key[a], key[b]); std::swap(code[a], code[b]); }
-                                CS(0, 1) CS(2, 3) CS(0, 2) CS(1, 3) CS(1, 2)
+                                CS(0, 1) CS(2, 3) CS(0, 2) if (!psort3) { CS(1, 3) CS(1, 2) }
 #undef CS
                             }
                             for (int k = 3; k >= 1; k--) if (key[k] < INFINITY) { r.stk.push_back(code[k]); r.stk_t.push_back(cull8 ? q8(key[k]) : key[k]); }
@@ -285,12 +287,12 @@ int main(int argc, char** argv)
             }
         }
 #pragma omp critical
-        { tot.rays += c.rays; tot.nodes += c.nodes; tot.tris += c.tris; tot.wnode += c.wnode; tot.wtri += c.wtri; tot.culled += c.culled; tot.hits += c.hits; tot.wuni += c.wuni; tot.lines += c.lines; for (int q = 0; q < 4; q++) tot.wdeep[q] += c.wdeep[q]; if (c.maxsp > tot.maxsp) tot.maxsp = c.maxsp; }
+        { tot.rays += c.rays; tot.nodes += c.nodes; tot.tris += c.tris; tot.wnode += c.wnode; tot.wtri += c.wtri; tot.culled += c.culled; tot.hits += c.hits; tot.wuni += c.wuni; tot.wuni0 += c.wuni0; tot.lines += c.lines; for (int q = 0; q < 4; q++) tot.wdeep[q] += c.wdeep[q]; if (c.maxsp > tot.maxsp) tot.maxsp = c.maxsp; }
     }
     double wr = tot.rays / 64.0;
     printf("per ray: %.2f node visits, %.2f tri tests, %.2f culled pops, hit %.4f, max stack %.0f\n", tot.nodes / tot.rays, tot.tris / tot.rays, tot.culled / tot.rays, tot.hits / tot.rays, tot.maxsp);
     printf("per pass: %.2f wave node steps (util %.3f), %.2f wave tri steps (util %.3f)\n", tot.wnode / wr, tot.nodes / (64.0 * tot.wnode), tot.wtri / wr, tot.tris / (64.0 * tot.wtri));
-    printf("wave node steps: %.3f uniform, %.2f distinct node lines per step; steps whose push could pass 8/10/11/16 entries: %.4f %.4f %.4f %.4f\n", tot.wuni / tot.wnode, tot.lines / tot.wnode,
+    printf("wave node steps: %.3f uniform (%.3f in the initial all-uniform run), %.2f distinct node lines per step; steps whose push could pass 8/10/11/16 entries: %.4f %.4f %.4f %.4f\n", tot.wuni / tot.wnode, tot.wuni0 / tot.wnode, tot.lines / tot.wnode,
            tot.wdeep[0] / tot.wnode, tot.wdeep[1] / tot.wnode, tot.wdeep[2] / tot.wnode, tot.wdeep[3] / tot.wnode);
     printf("VALU model (124/node step, 62/tri step): %.0f per pass\n", 124.0 * tot.wnode / wr + 62.0 * tot.wtri / wr);
     return 0;
