@@ -137,6 +137,7 @@ def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5):
                           % (2 * cube, 4 * cube, S))
     irrt = torch.flip(irr_tex.reshape(res, res, 3), dims=[0]).contiguous()          # file orientation
     model = MaterialModel.from_arrays(sc, sc0["hdr"], irrt, conf, albedo_res=tres, roughness_res=tres)
+    model.lean_outputs = True               # (as the runner sets it: the un-mipmapped roughness fetch only feeds the stage-1 loss)
     views = [cameras.cube_mvps(E) for E in cameras.grid_cameras(4)]
     sc0 = dict(sc0)
     if "patches" not in sc0:                 # (workload came from the array cache: the chart list is needed for the GT materials)

@@ -42,7 +42,7 @@ def _pixel_runner(g):
         def _gbuffer(self, mvp, view_id):
             return self._gb
 
-        def _fetch_materials(self, gb):
+        def _fetch_materials(self, gb, womipmap=True):
             return self.materials_a, self.materials_r, self.materials_r, self._irr
 
     class DS(torch.utils.data.Dataset):

@@ -252,8 +252,20 @@ __global__ __launch_bounds__(kLB) void loss_main_kernel(LossArgs a, LossWs ws)
 }
 
 // ---- pass 3: gradient through the (non-detached) class means (loss.py:283,290) ----------------------------------
-__global__ __launch_bounds__(kLB) void loss_meangrad_kernel(LossArgs a, LossWs ws)
+__device__ __forceinline__ void loss_final(const LossArgs& a, const LossWs& ws, float* out /* [2]: total, seg */)
 {
+    const double P = (double)a.P;
+    double direct, seg;
+    if (a.stage == 0) { direct = ws.acc[0] / (3.0 * P); seg = 20.0 * ws.acc[1] / ((double)a.C * P * 3.0); }
+    else if (a.stage == 1) { direct = ws.acc[0] / ((double)a.C * P * 3.0) * (double)a.hw; seg = ws.acc[1] / ((double)a.C * P); }
+    else { direct = ws.acc[0] / ((double)a.C * P * 3.0); seg = 0.2 * ws.acc[1] / ((double)a.R * (double)a.C * P); }
+    out[0] = (float)(direct + seg); out[1] = (float)seg;
+}
+
+// (`out`: the loss pair is written here as well -- it only needs loss_main_kernel's sums, complete before this launch starts: one launch less)
+__global__ __launch_bounds__(kLB) void loss_meangrad_kernel(LossArgs a, LossWs ws, float* out)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) loss_final(a, ws, out);
     const double P = (double)a.P;
     const float ks0 = (float)(20.0 / ((double)a.C * P * 3.0));
     const float ks2 = (float)(0.2 / ((double)a.R * (double)a.C * P));
@@ -274,12 +286,7 @@ __global__ __launch_bounds__(kLB) void loss_meangrad_kernel(LossArgs a, LossWs w
 __global__ void loss_final_kernel(LossArgs a, LossWs ws, float* out /* [2]: total, seg */)
 {
     if (threadIdx.x || blockIdx.x) return;
-    const double P = (double)a.P;
-    double direct, seg;
-    if (a.stage == 0) { direct = ws.acc[0] / (3.0 * P); seg = 20.0 * ws.acc[1] / ((double)a.C * P * 3.0); }
-    else if (a.stage == 1) { direct = ws.acc[0] / ((double)a.C * P * 3.0) * (double)a.hw; seg = ws.acc[1] / ((double)a.C * P); }
-    else { direct = ws.acc[0] / ((double)a.C * P * 3.0); seg = 0.2 * ws.acc[1] / ((double)a.R * (double)a.C * P); }
-    out[0] = (float)(direct + seg); out[1] = (float)seg;
+    loss_final(a, ws, out);
 }
 
 size_t loss_workspace_bytes(int64_t P, int C, int R)
@@ -326,8 +333,8 @@ hipError_t launch_loss(int stage, int l2, const float* gt, const float* rgb, con
         hipLaunchKernelGGL(loss_stats_kernel, dim3(grid), dim3(kLB), lds_stats, st, 2, rough, seg, hl, room, P, C, a.R, ws);
     }
     hipLaunchKernelGGL(loss_main_kernel, dim3(grid), dim3(kLB), sizeof(double) * rc * 3, st, a, ws);
-    if (stage != 1) hipLaunchKernelGGL(loss_meangrad_kernel, dim3(grid), dim3(kLB), 0, st, a, ws);
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, a, ws, out);
+    if (stage != 1) hipLaunchKernelGGL(loss_meangrad_kernel, dim3(grid), dim3(kLB), 0, st, a, ws, out);
+    else hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, a, ws, out);
     return hipGetLastError();
 }
 

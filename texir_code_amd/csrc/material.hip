@@ -528,6 +528,7 @@ hipError_t launch_mip_build(const float* tex, float* rest, int H, int W, int C, 
     else if (C == 2) launch_pyr_down_c<2>(src, rest, d, s_lvl, n_out, st);
     else if (C == 3) launch_pyr_down_c<3>(src, rest, d, s_lvl, n_out, st);
     else launch_pyr_down_c<4>(src, rest, d, s_lvl, n_out, st);
+    // (the levels above the pyramid: a last-block-finishes fusion was measured -- 16 384 same-address atomics cost 0.5 ms against this 5 us launch)
     const int lt = s_lvl + n_out + 1;
     if (lt < levels) hipLaunchKernelGGL(mip_down_tail_kernel, dim3(1), dim3(1024), 0, st, rest, d, lt);
     return hipGetLastError();

@@ -65,10 +65,13 @@ class _LossFn(torch.autograd.Function):
         # two 0-dim outputs (views of the kernel's result pair): the loss, and the segmentation term the reference returns as .item()
         loss, seg = out[0], out[1]
         ctx.mark_non_differentiable(seg)
+        ctx.set_materialize_grads(False)          # (no zero tensor filled per step for the non-differentiable output)
         return loss, seg
 
     @staticmethod
     def backward(ctx, g0, _g_seg=None):
+        if g0 is None:
+            return (None,) * 16
         d_rgb, d_alb, d_r = ctx.grads
         s_rgb, s_alb, s_r = ctx.shapes
         if ctx.unit_upstream:

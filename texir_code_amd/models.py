@@ -215,12 +215,13 @@ class MaterialModel(nn.Module):
             self._gb_cache[key] = gb
         return gb
 
-    def _fetch_materials(self, gb):
-        """the four dr.texture fetches of mat_nvdiffrast.py:131-139"""
+    def _fetch_materials(self, gb, womipmap=True):
+        """the four dr.texture fetches of mat_nvdiffrast.py:131-139 (womipmap=False leaves the un-mipmapped roughness out: only the
+        stage-1 loss reads it, train_material.py via loss.py:98-104)"""
         texc, texd = gb["uv"], gb["uv_da"]
         # (cache=gb: the view's fetch coordinates never change, so the backward is a gather over tap lists sorted once per view)
         albedo = tex_fetch(self.materials_a, texc, texd, "linear-mipmap-linear", self.max_mip_level, cache=gb)
-        roughness_womipmap = tex_fetch(self.materials_r, texc, texd, "linear", cache=gb)
+        roughness_womipmap = tex_fetch(self.materials_r, texc, texd, "linear", cache=gb) if womipmap else None
         roughness = tex_fetch(self.materials_r, texc, texd, "linear-mipmap-linear", self.max_mip_level, cache=gb)
         # the irradiance texture is frozen and the view's uvs are constant: fetch once per view
         irr = gb.get("_irr")
@@ -257,7 +258,8 @@ class MaterialModel(nn.Module):
             # per-view constants: the offset ray origins (mat_nvdiffrast.py:179,182) and the position the render reports
             gb["_points"] = pos + 1e-2 * nrm
             gb["_position_out"] = (gb["_points"] + 2e-2 * nrm).detach()
-        albedo, roughness_womipmap, roughness, irr = self._fetch_materials(gb)
+        # `lean_outputs` (set by the trainers' optimisation step): res["roughness_womipmap"] is None in the stages whose loss does not read it
+        albedo, roughness_womipmap, roughness, irr = self._fetch_materials(gb, womipmap=(stage == 1 or not getattr(self, "lean_outputs", False)))
         cam_position = cam_position.to(self.device)
         if stage == -1:
             # light-source-only radiance texture (mat_nvdiffrast.py:141-150)

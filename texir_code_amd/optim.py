@@ -22,6 +22,33 @@ class FusedAdam(torch.optim.Optimizer):
                 p._texir_defer_fold = self.fuse_mip_fold and p.dim() == 3 and p.shape[0] % 2 == 0 and p.shape[1] % 2 == 0
                 p._texir_grad_l1 = None
                 p._texir_l0_touched = False
+        self._make_grad_arena()
+
+    def _make_grad_arena(self):
+        """ONE buffer for the mip-level gradient stacks of all deferring texture parameters (per device), so that a step clears them with
+        a single fill (texture.py backward) instead of one per parameter.  A slot is sized for the full pyramid of its texture (levels
+        1 .. 1x1: one third of the texture); the backward uses the leading part its fetch's level count needs."""
+        by_dev = {}
+        for group in self.param_groups:
+            for p in group["params"]:
+                p._texir_arena = None
+                if p._texir_defer_fold and p.is_cuda and p.dtype == torch.float32:
+                    by_dev.setdefault(p.device, []).append(p)
+        for dev, ps in by_dev.items():
+            sizes = []
+            for p in ps:
+                H, W, C = p.shape
+                n, h, w = 0, H // 2, W // 2
+                while h >= 1 and w >= 1:
+                    n += h * w * C
+                    h, w = h // 2, w // 2
+                sizes.append((n + 63) // 64 * 64)
+            buf = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+            arena = {"buf": buf, "dirty": True, "params": ps, "clean": set()}
+            off = 0
+            for p, n in zip(ps, sizes):
+                p._texir_arena, p._texir_arena_span, p._texir_in_fwd = arena, (off, off + n), False
+                off += n
 
     def zero_grad(self, set_to_none=True):
         for group in self.param_groups:
@@ -30,6 +57,8 @@ class FusedAdam(torch.optim.Optimizer):
                 p._texir_l0_touched = False
                 p._texir_l0_mask = None
                 p._texir_l0_sparse = False
+                if getattr(p, "_texir_arena", None) is not None:
+                    p._texir_arena["dirty"] = True            # the next deferring backward clears the stacks (once for all parameters)
         super().zero_grad(set_to_none=set_to_none)
 
     def release(self):
@@ -38,6 +67,7 @@ class FusedAdam(torch.optim.Optimizer):
             for p in group["params"]:
                 p._texir_defer_fold = False
                 p._texir_grad_l1 = None
+                p._texir_arena = None
 
     def set_clamp(self, param, lo=-math.inf, hi=math.inf):
         """fuse `param.data.clamp_(lo, hi)` into every step of this parameter"""

@@ -80,6 +80,7 @@ class MatTrainRunner:
         self.model = get_class(self.conf.get_string("train.model_class"))(
             conf=self.conf, ids=self.train_dataset.ids, extrinsics=self.train_dataset.extrinsics_list, optim_cam=self.conf.get_bool("train.optim_cam"))
         self.model.cuda()
+        self.model.lean_outputs = True        # the step's only consumer of the forward dict is the loss: skip what it does not read (models.py forward)
         self.mat_loss = get_class(self.conf.get_string("train.irf_loss_class"))(**self.conf.get_config("render_loss"))
         self._new_optimizer()
         self.start_epoch = 0
@@ -198,7 +199,7 @@ class MatTrainRunner:
             P = gt_color.shape[0] * h * w
             pr = dist_util.pixel_range(P, rank, world)
             local = self.model(mvp[0] if mvp.dim() == 4 else mvp, vid0, cam[0] if cam.dim() == 2 else cam, stage, pixel_range=pr)
-            preds = {k: dist_util.gather_pixels(local[k].reshape(pr[1] - pr[0], -1), P).reshape(gt_color.shape[0], h, w, -1)
+            preds = {k: None if local[k] is None else dist_util.gather_pixels(local[k].reshape(pr[1] - pr[0], -1), P).reshape(gt_color.shape[0], h, w, -1)
                      for k in ("rgb", "albedo", "roughness", "roughness_womipmap", "empty_mask")}
         else:
             preds = self.model(mvp[0] if mvp.dim() == 4 else mvp, vid0, cam[0] if cam.dim() == 2 else cam, stage)
