@@ -44,10 +44,10 @@ class FusedAdam(torch.optim.Optimizer):
                     h, w = h // 2, w // 2
                 sizes.append((n + 63) // 64 * 64)
             buf = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
-            arena = {"buf": buf, "dirty": True, "params": ps, "clean": set()}
+            arena = {"buf": buf, "params": ps, "clean": set()}       # clean: ids of the parameters whose span is known to be zero
             off = 0
             for p, n in zip(ps, sizes):
-                p._texir_arena, p._texir_arena_span, p._texir_in_fwd = arena, (off, off + n), False
+                p._texir_arena, p._texir_arena_span = arena, (off, off + n)
                 off += n
 
     def zero_grad(self, set_to_none=True):
@@ -57,8 +57,6 @@ class FusedAdam(torch.optim.Optimizer):
                 p._texir_l0_touched = False
                 p._texir_l0_mask = None
                 p._texir_l0_sparse = False
-                if getattr(p, "_texir_arena", None) is not None:
-                    p._texir_arena["dirty"] = True            # the next deferring backward clears the stacks (once for all parameters)
         super().zero_grad(set_to_none=set_to_none)
 
     def release(self):

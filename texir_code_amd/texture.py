@@ -141,17 +141,12 @@ class _TexFetch(torch.autograd.Function):
                 # by all captured hipGraphs (they run one after the other on one stream): nothing is allocated per step or per graph
                 arena = getattr(owner, "_texir_arena", None)
                 if arena is not None and arena["buf"].device == d_out.device and owner._texir_arena_span[1] - owner._texir_arena_span[0] >= n_rest:
-                    # FusedAdam's arena: the stacks of all its texture parameters in one buffer.  The first deferring backward after a
-                    # zero_grad() clears, with ONE fill, the span of every parameter that was fetched since the last clear
+                    # FusedAdam's arena: the stacks of all its texture parameters in one buffer, cleared by ONE fill at the step's first
+                    # fetch (texture() below).  A backward pass whose forward did not clear it clears its own span here.
                     lo, hi = owner._texir_arena_span
                     g_rest = arena["buf"][lo:lo + n_rest]
-                    if arena["dirty"] or id(owner) not in arena["clean"]:
-                        ps = [q for q in arena["params"] if getattr(q, "_texir_in_fwd", False) or q is owner]
-                        arena["buf"][min(q._texir_arena_span[0] for q in ps):max(q._texir_arena_span[1] for q in ps)].zero_()
-                        for q in ps:
-                            q._texir_in_fwd = False
-                        arena["clean"] = set(id(q) for q in ps)
-                        arena["dirty"] = False
+                    if id(owner) not in arena["clean"]:
+                        arena["buf"][lo:hi].zero_()
                     arena["clean"].discard(id(owner))          # (this backward writes into it)
                 else:
                     g_rest = getattr(owner, "_texir_grest", None)
@@ -228,8 +223,13 @@ def texture(tex, uv, uv_da=None, filter_mode="linear", max_mip_level=13, cache=N
     levels = int(_lib.lib().texir_mip_levels(H, W, int(max_mip_level))) if mode == 1 else 1
     rest = _mips_for(owner, tex.detach(), levels) if levels > 1 else None
     taps = None
-    if tex.requires_grad and torch.is_grad_enabled() and getattr(owner, "_texir_arena", None) is not None and mode == 1:
-        owner._texir_in_fwd = True             # (its gradient stack is part of the next backward's single clear)
+    arena = getattr(owner, "_texir_arena", None)
+    if arena is not None and mode == 1 and tex.requires_grad and torch.is_grad_enabled() and id(owner) not in arena["clean"]:
+        # first deferring fetch of a step: clear the gradient stacks of every trainable parameter of the arena with one fill (in the forward:
+        # stream-ordered before every backward of the step, whichever parameter's comes first)
+        ps = [q for q in arena["params"] if q.requires_grad]
+        arena["buf"][min(q._texir_arena_span[0] for q in ps):max(q._texir_arena_span[1] for q in ps)].zero_()
+        arena["clean"] = set(id(q) for q in ps)
     if cache is not None and tex.requires_grad and torch.is_grad_enabled():
         taps = _tap_lists(cache, H, W, C, levels, mode, uvf, daf)
     out = _TexFetch.apply(tex, rest, uvf, daf, mode, levels, owner if isinstance(owner, torch.nn.Parameter) else None, taps)
