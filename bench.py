@@ -284,6 +284,10 @@ def roofline(workload, kernel, kern_ms, rays_this_rank, world, alg):
                                    "lane_utilisation": pmc.get("valu_lane_utilisation"), "insts_per_64_rays": round(valu / (rays_this_rank / 64.0), 1)},
                     "l1_tcp": None if l1 is None else {"accesses_per_launch": float(pmc["tcp_cache_accesses"]) * scale, "frac": round(l1, 4),
                                                         "note": "vector-L1 cache accesses / (256 TCPs x TCP clock x t); peak 1 access per clock per TCP"},
+                    "waves": {"wait_any_frac": pmc.get("sq_wait_any_frac"), "active_inst_any_frac": pmc.get("sq_active_inst_any_frac"),
+                              "note": "share of the resident waves' cycles spent waiting / issuing (SQ_WAIT_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES)"},
+                    "scalar_path": None if pmc.get("smem_insts") is None else {"smem_insts_per_launch": float(pmc["smem_insts"]) * scale,
+                                                                               "scalar_cache_hit_rate": pmc.get("scalar_cache_hit_rate")},
                     "profile": "profiles/pmc_%s.json (%s)" % (workload, pmc.get("source", ""))})
     if alg is not None:
         bpr, nbar, tbar, phit = alg

@@ -257,6 +257,52 @@ def test_graphed_material_step_equals_eager(golden, fuse):
     assert abs(res[1][2] - res[0][2]) < 1e-5 * max(1.0, abs(res[0][2]))
 
 
+def test_lean_outputs_and_shared_gradient_arena_change_nothing(golden):
+    """(i) `lean_outputs` drops the un-mipmapped roughness fetch where no loss reads it (stages 0 and 2) and nothing else; (ii) the
+    optimiser's gradient arena (one buffer, one clear per step for all texture parameters) gives the same bits as per-parameter stacks"""
+    from texir_code_amd import cameras, conf as C
+    from texir_code_amd.loss import RenderLoss
+    from texir_code_amd.models import MaterialModel
+    from texir_code_amd.optim import FusedAdam
+    from texir_code_amd.scene import Scene
+    from texir_code_amd.trainer.train_material import build_masks
+    g = golden("irt_room.npz")
+    cf = C.parse_string("train{ pano_img_res = [32,64]\n sample_light = [64,16]\n hdr_exposure = 0 }\nmodels{ render{ sample_type = [uniform, importance] } }")
+    mvp, cam = cameras.cube_mvps(cameras.grid_cameras(1)[0])
+    cam = cam.cuda()
+    out = {}
+    for mode in ("plain", "lean", "no_arena"):
+        torch.manual_seed(5)
+        sc = Scene(g["verts"], g["tris"], g["tri_uvs"], g["hdr"], device=0)
+        m = MaterialModel.from_arrays(sc, g["hdr"], torch.rand(64, 64, 3) * 2, cf, albedo_res=64, roughness_res=128)
+        m.lean_outputs = mode == "lean"
+        c = m.cube_res
+        gt = torch.rand(6, c, c, 3, device="cuda")
+        gmask = torch.ones(6, c, c, 1, device="cuda")
+        seg, fm, _ = build_masks(torch.randint(40, 49, (6, c, c, 1)).float().cuda(), torch.rand(6, c, c, 3, device="cuda") - 0.5)
+        room = torch.ones((1, 6, c, c, 1), device="cuda")
+        loss_fn = RenderLoss("L1", 1, lazy_item=True)
+        opt = FusedAdam([m.materials_a, m.materials_r], lr=3e-2, fuse_mip_fold=True)
+        arena = m.materials_a._texir_arena
+        assert arena is not None and arena is m.materials_r._texir_arena
+        (a0, a1), (r0, r1) = m.materials_a._texir_arena_span, m.materials_r._texir_arena_span
+        assert a1 <= r0 or r1 <= a0
+        if mode == "no_arena":
+            m.materials_a._texir_arena = m.materials_r._texir_arena = None
+        torch.manual_seed(9)
+        for it, stage in enumerate((2, 2, 1, 2)):
+            preds = m(mvp, "v", cam, stage)
+            assert (preds["roughness_womipmap"] is None) == (mode == "lean" and stage != 1)
+            loss = loss_fn(gt, preds, gmask, fm, seg, stage=stage, room_seg_mask=room if stage == 2 else None)[0]
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        out[mode] = (m.materials_a.detach().cpu().numpy().copy(), m.materials_r.detach().cpu().numpy().copy(), float(loss))
+    for mode in ("lean", "no_arena"):
+        assert np.array_equal(out[mode][0], out["plain"][0]) and np.array_equal(out[mode][1], out["plain"][1]), mode
+        assert out[mode][2] == out["plain"][2]
+
+
 def test_runner_with_hipgraph_matches_eager_runner(tmp_path, monkeypatch):
     """train.hipgraph = true must give the same optimisation trajectory as the default eager runner -- with several views, i.e. several
     captured graphs whose gradient buffers are distinct pool allocations (the optimiser must read the replayed graph's own)"""

@@ -40,6 +40,10 @@ if c.get("SQ_WAVE_CYCLES", 0):
     for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
         if k in c:
             res[k.lower() + "_frac"] = round(c[k] / c["SQ_WAVE_CYCLES"], 4)
+if c.get("SQC_DCACHE_REQ", 0):
+    # scalar path of the traversal (wave-uniform node steps fetch through the scalar cache)
+    res["smem_insts"] = c.get("SQ_INSTS_SMEM", 0.0)
+    res["scalar_cache_hit_rate"] = round(c.get("SQC_DCACHE_HITS", 0.0) / c["SQC_DCACHE_REQ"], 4)
 # rays of the profiled launch = valid texels x spp of the workload (every PMC pass runs `bench.py --workload <wl> --steps 1`)
 try:
     T, r_, tex_, spp_, style_ = bench.WORKLOADS[wl]

@@ -33,6 +33,7 @@ for wl in "${WLS[@]}"; do
   run $wl tccbusy TCC_BUSY_sum TCC_CYCLE_sum
   run $wl tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum
   run $wl tcpgate TCP_GATE_EN1_sum TCP_TOTAL_ACCESSES_sum
+  run $wl sqc SQ_INSTS_SMEM SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQ_INSTS_VALU_CVT
   python $R/tools/pmc_to_json.py $out/$wl $wl $R/gpurun_out/$tag/pmc_$wl.json
 done
 # kernel-trace stats of the default bench run (the headline), with the PMC json in place so that the line carries the measured bounds
