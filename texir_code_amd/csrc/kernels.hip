@@ -41,18 +41,23 @@ __device__ __forceinline__ void irt_stats_flush(unsigned long long* stats, int l
     }
 }
 
-// Occupancy: 7 waves/SIMD (<= 72 VGPRs; the compiler parks the per-texel frame in scratch across the traversal loop) with a
-// 16-entry LDS stack (16 KiB per block) measured best: 5 waves / 24 entries 13.85, 6 / 24 14.79, 7 / 16 15.11, 8 / 16 15.06 Grays/s (c4).
+// Occupancy.  Round 1 (4-byte stack entries): 5 waves / 24 entries 13.85, 6 / 24 14.79, 7 / 16 15.11, 8 / 16 15.06 Grays/s (c4).  Round 2, after the
+// scalar node path took the L1 off the critical path (8-byte entries): 6 waves / 12 entries 15.01, 7 / 11 15.82, 8 / 10 15.87 (c2: 16.30, 17.11, 17.40;
+// c4_scan: 4.98, 5.31, 5.54): 8 waves per SIMD = 64 VGPRs (the compiler parks the per-texel frame and the ray's shear rows in scratch across the
+// traversal loop) and a 10-entry LDS stack.
 #ifndef TEXIR_CULL
 #define TEXIR_CULL 1
 #endif
 constexpr bool kCull = TEXIR_CULL != 0;
 constexpr int kEstimatorCosine = 4;      // or-ed into the IrT kernels' `mode`: the cosine branch of diffuse_reflectance (mat_nvdiffrast.py:256-257)
 #ifndef TEXIR_GROUP_LSTK
-#define TEXIR_GROUP_LSTK (TEXIR_CULL ? 11 : 16)         // 8-byte entries with culling: 11 x 2 KiB = 22 KiB per block, 7 blocks = 154 of 160 KiB
+#define TEXIR_GROUP_LSTK (TEXIR_CULL ? 10 : 16)         // 8-byte entries with culling: 10 x 2 KiB = 20 KiB per block, 8 blocks = all 160 KiB of a CU
 #endif
 constexpr int kGroupLstk = TEXIR_GROUP_LSTK;
-constexpr int kGroupWaves = 7;
+#ifndef TEXIR_GROUP_WAVES
+#define TEXIR_GROUP_WAVES 8
+#endif
+constexpr int kGroupWaves = TEXIR_GROUP_WAVES;
 constexpr int kLstk = kCull ? kLdsStack / 2 : kLdsStack;   // the other tracing kernels: 24 KiB of stack per block either way
 
 // One texel per wave: the 64 lanes trace 64 samples of the texel per pass (any N, binary or 4-wide tree).  Kept as the
@@ -370,6 +375,10 @@ __device__ __forceinline__ SpecSample spec_sample(const Frame& f, float nx, floa
 #ifndef TEXIR_SPEC_WAVES
 #define TEXIR_SPEC_WAVES 0
 #endif
+#ifndef TEXIR_SPEC_LSTK
+#define TEXIR_SPEC_LSTK (TEXIR_SPEC_WAVES >= 7 && TEXIR_CULL ? (TEXIR_SPEC_WAVES >= 8 ? 10 : 11) : kLstk)
+#endif
+constexpr int kSpecLstk = TEXIR_SPEC_LSTK;
 template <bool BWD, int WIDTH>
 __global__
 #if TEXIR_SPEC_WAVES
@@ -428,7 +437,7 @@ void spec_kernel(SceneDev sc, const float* __restrict__ normal, const float* __r
                         const float* lp = Ls_ws + 3 * ((size_t)p * S + i);
                         L[0] = lp[0]; L[1] = lp[1]; L[2] = lp[2];
                     } else {
-                        Hit h = trace_closest<false, kLstk, WIDTH, kCull>(sc, ox, oy, oz, ss.l[0], ss.l[1], ss.l[2], cn, ct);
+                        Hit h = trace_closest<false, kSpecLstk, WIDTH, kCull>(sc, ox, oy, oz, ss.l[0], ss.l[1], ss.l[2], cn, ct);
                         if (h.slot >= 0 && h.t > 1e-4f) shade_hit(sc, h.slot, h.u, h.v, L);
                         if (Ls_ws) { float* lp = Ls_ws + 3 * ((size_t)p * S + i); lp[0] = L[0]; lp[1] = L[1]; lp[2] = L[2]; }
                     }
