@@ -451,6 +451,8 @@ def main():
             if rank == 0:
                 ex[w] = {"value": round(e["value"], 2), "unit": "Mrays/s", "ms_per_step": round(e["dt"] / args.steps * 1e3, 3), "workload": e["desc"],
                          "kernel": e["kernel"], "scene": e["sc"].info()}
+                if load_pmc(w, e["kernel"])[0] is not None:         # (measured bounds where tools/profile_round.sh has profiled this workload too)
+                    ex[w]["roofline"] = roofline(w, e["kernel"], e["kern_ms"], int(e["ids"].numel()) * e["spp"], world, None)
             del e
             torch.cuda.empty_cache()
         if rank == 0:

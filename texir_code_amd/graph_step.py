@@ -1,5 +1,5 @@
-"""hipGraph capture of the launch-bound part of a material-estimation step (forward + loss + backward is ~40 short kernels:
-mip builds, texture fetches, specular trace, three loss passes, scatter + folds).  The per-step GGX shifts still come from
+"""hipGraph capture of the launch-bound part of a material-estimation step (forward + loss + backward: 18 kernels in stage 2 --
+mip builds, texture fetches, specular trace, three loss passes, one gradient-arena fill, gathers + folds).  The per-step GGX shifts still come from
 the CPU generator exactly as the reference draws them (utils/sample_util.py:102) -- they are copied into a static device
 buffer the captured kernels read.  Optimiser step and gradient all-reduce stay outside the graph."""
 import torch

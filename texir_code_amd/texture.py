@@ -137,8 +137,9 @@ class _TexFetch(torch.autograd.Function):
         g_rest = None
         if levels > 1:
             if defer:
-                # the gradient stack of a deferring parameter lives in ONE buffer owned by the parameter, reused by every step and shared
-                # by all captured hipGraphs (they run one after the other on one stream): nothing is allocated per step or per graph
+                # the gradient stack of a deferring parameter lives in a persistent buffer -- its slot of the optimiser's arena, or, without
+                # one, a buffer owned by the parameter -- reused by every step and shared by all captured hipGraphs (they run one after the
+                # other on one stream): nothing is allocated per step or per graph
                 arena = getattr(owner, "_texir_arena", None)
                 if arena is not None and arena["buf"].device == d_out.device and owner._texir_arena_span[1] - owner._texir_arena_span[0] >= n_rest:
                     # FusedAdam's arena: the stacks of all its texture parameters in one buffer, cleared by ONE fill at the step's first

@@ -112,9 +112,9 @@ class MatTrainRunner:
             self._gs = GraphedMatStep(self.model, self.mat_loss, self.mat_optimizer, [self.model.materials_a, self.model.materials_r])
             self._gs_inputs = getattr(self, "_gs_inputs", {})
         if (vid0, stage) not in self._gs.graphs:
-            # every captured (view, stage) graph pins its own gradient buffers (~1.3 x the texture bytes); beyond the budget further views
-            # run the eager step (TEXIR_MAX_GRAPHS, default 96 ~ 43 GB at 4k textures; a new stage starts a fresh set)
-            if len(self._gs.graphs) >= int(os.environ.get("TEXIR_MAX_GRAPHS", "96")):
+            # a captured (view, stage) graph owns no gradient memory (the stacks live in the optimiser's arena, shared by all graphs); the cap
+            # on their number (TEXIR_MAX_GRAPHS, default 1024; beyond it further views run the eager step) is a safety valve only
+            if len(self._gs.graphs) >= int(os.environ.get("TEXIR_MAX_GRAPHS", "1024")):
                 return None
             if vid0 not in self._gs_inputs:
                 gt = gt_item["color"].float().cuda()
