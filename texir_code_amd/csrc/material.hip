@@ -484,10 +484,24 @@ __global__ __launch_bounds__(256) void tex_gather_kernel(float* __restrict__ lvl
         const int b = seg_start[s], e = b + seg_count[s];
         float acc[C];
         for (int c = 0; c < C; c++) acc[c] = 0.f;
-        for (int i = b; i < e; i++) {
-            const float wi = w[i];
-            const float* g = d_out + (int64_t)pix[i] * C;
-            for (int c = 0; c < C; c++) acc[c] = __builtin_fmaf(g[c], wi, acc[c]);
+        // (four taps' loads in flight at a time -- index, weight, then the gathered gradient; a short tail re-reads the last tap -- and the fused
+        // multiply-adds in list order, one per real tap: the chain of dependent loads per tap is what this kernel waits for, and the sum keeps its bits)
+        for (int i = b; i < e; i += 4) {
+            const int n = e - i;                                   // taps of this round: 4, or 1..3 in the last one
+            const int i1 = n > 1 ? i + 1 : i, i2 = n > 2 ? i + 2 : i, i3 = n > 3 ? i + 3 : i;
+            const int p0 = pix[i], p1 = pix[i1], p2 = pix[i2], p3 = pix[i3];
+            const float w0 = w[i], w1 = w[i1], w2 = w[i2], w3 = w[i3];
+            float v0[C], v1[C], v2[C], v3[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) { v0[c] = d_out[(int64_t)p0 * C + c]; v1[c] = d_out[(int64_t)p1 * C + c]; v2[c] = d_out[(int64_t)p2 * C + c]; v3[c] = d_out[(int64_t)p3 * C + c]; }
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                float a = __builtin_fmaf(v0[c], w0, acc[c]);
+                if (n > 1) a = __builtin_fmaf(v1[c], w1, a);
+                if (n > 2) a = __builtin_fmaf(v2[c], w2, a);
+                if (n > 3) a = __builtin_fmaf(v3[c], w3, a);
+                acc[c] = a;
+            }
         }
         float* o = key < n0 ? lvl0 + key * C : rest + (key - n0) * C;
         for (int c = 0; c < C; c++) o[c] = acc[c];
