@@ -199,7 +199,10 @@ TEXIR_API int texir_tex_fetch_backward_deferred(float* d_tex /*dev*/, float* gra
  * backward is texir_tex_gather_backward: one thread per touched texel adds its list in order (deterministic), followed by the
  * same folds as texir_tex_fetch_backward (defer_last_fold = 1: as texir_tex_fetch_backward_deferred).  d_tex / grad_rest zero on entry.
  * With defer_last_fold = 1, d_tex may be NULL when no listed tap samples level 0 (no key < H*W): the level-0 gradient is then
- * identically zero and texir_adam_step_tex(grad = NULL) never reads it. */
+ * identically zero and texir_adam_step_tex(grad = NULL) never reads it.
+ * defer_last_fold = 2 (levels >= 4, H and W divisible by 4): the folds stop at level 2 -- grad_rest then holds the raw level-1 gradient and the
+ * level-2 gradient with everything coarser folded in; texir_adam_step_tex(grad_level2 = ...) takes both remaining folds over and the
+ * read-modify-write of the level-1 stack (half the traffic of the folds) disappears. */
 TEXIR_API int texir_tex_taps(int32_t H, int32_t W, int32_t C, int32_t levels, const float* uv, const float* uv_da, int32_t filter_mode,
                        int64_t P, int64_t* keys /*dev [P*8]*/, float* weights /*dev [P*8]*/, void* stream);
 TEXIR_API int texir_tex_gather_backward(float* d_tex, float* grad_rest, int32_t H, int32_t W, int32_t C, int32_t levels,
@@ -222,6 +225,8 @@ TEXIR_API int texir_adam_step(float* param, const float* grad, float* exp_avg, f
 TEXIR_API int texir_adam_step_tex(float* param, const float* grad /*nullable: level-0 gradient identically zero*/,
                        const uint32_t* grad_mask /*nullable: 1 bit per texel (bit t&31 of word t>>5): grad is valid -- and read -- only where set*/,
                        const float* grad_level1,
+                       const float* grad_level2 /*nullable: [H/4,W/4,C] level-2 gradient NOT yet folded into grad_level1 (texir_tex_gather_backward with
+                                                  defer_last_fold = 2): the step also performs grad_level1 += 0.25 * grad_level2 on the fly, same fma*/,
                        float* exp_avg, float* exp_avg_sq, float* mip_level1 /*nullable: [H/2,W/2,C] <- 2x2 average of the updated texels*/,
                        int32_t H, int32_t W, int32_t C, float lr, float beta1, float beta2, float eps, int32_t step, float clamp_lo,
                        float clamp_hi, void* stream);

@@ -323,21 +323,23 @@ int texir_tex_gather_backward(float* d_tex, float* grad_rest, int32_t H, int32_t
     // optimiser step treats the level-0 gradient as identically zero)
     if ((!d_tex && !defer_last_fold) || !d_out || (n_seg > 0 && (!seg_key || !seg_start || !seg_count || !pix || !weights)) || (filter_mode == 1 && levels > 1 && !grad_rest))
         return fail(TEXIR_ERR_INVALID, "texir_tex_gather_backward: null argument");
-    if (filter_mode < 0 || filter_mode > 1 || n_seg < 0 || (defer_last_fold && (filter_mode != 1 || levels < 2)))
+    if (filter_mode < 0 || filter_mode > 1 || n_seg < 0 || defer_last_fold < 0 || defer_last_fold > 2 || (defer_last_fold && (filter_mode != 1 || levels < 2))
+        || (defer_last_fold == 2 && (levels < 4 || (H & 3) || (W & 3))))
         return fail(TEXIR_ERR_INVALID, "texir_tex_gather_backward: bad filter_mode/n_seg/defer_last_fold");
     if (int rc = check_tex("texir_tex_gather_backward", H, W, C, levels)) return rc;
     HIP_TRY(launch_tex_gather_bwd(d_tex, grad_rest, H, W, C, levels, (const long long*)seg_key, seg_start, seg_count, n_seg, pix, weights, d_out,
-                                  filter_mode, defer_last_fold ? 1 : 0, (hipStream_t)stream));
+                                  filter_mode, defer_last_fold, (hipStream_t)stream));
     return TEXIR_OK;
 }
 
-int texir_adam_step_tex(float* param, const float* grad, const uint32_t* grad_mask, const float* grad_level1, float* exp_avg, float* exp_avg_sq,
-                        float* mip_level1, int32_t H, int32_t W, int32_t C, float lr, float beta1, float beta2, float eps, int32_t step,
+int texir_adam_step_tex(float* param, const float* grad, const uint32_t* grad_mask, const float* grad_level1, const float* grad_level2, float* exp_avg,
+                        float* exp_avg_sq, float* mip_level1, int32_t H, int32_t W, int32_t C, float lr, float beta1, float beta2, float eps, int32_t step,
                         float clamp_lo, float clamp_hi, void* stream)
 {
     if (!param || !grad_level1 || !exp_avg || !exp_avg_sq) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex: null argument");
     if (H < 2 || W < 2 || (H & 1) || (W & 1) || C < 1 || C > 4 || step < 1) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex: bad H/W/C/step");
-    HIP_TRY(launch_adam_tex(param, grad, grad_mask, grad_level1, exp_avg, exp_avg_sq, mip_level1, H, W, C, lr, beta1, beta2, eps, step, clamp_lo, clamp_hi, (hipStream_t)stream));
+    if (grad_level2 && ((H & 3) || (W & 3))) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex: a level-2 gradient needs H and W divisible by 4");
+    HIP_TRY(launch_adam_tex(param, grad, grad_mask, grad_level1, grad_level2, exp_avg, exp_avg_sq, mip_level1, H, W, C, lr, beta1, beta2, eps, step, clamp_lo, clamp_hi, (hipStream_t)stream));
     return TEXIR_OK;
 }
 

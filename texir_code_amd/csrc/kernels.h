@@ -40,7 +40,7 @@ hipError_t launch_tex_taps(int H, int W, int C, int levels, const float* uv, con
 hipError_t launch_tex_gather_bwd(float* d_tex, float* grad_rest, int H, int W, int C, int levels, const long long* seg_key, const int* seg_start,
                                  const int* seg_count, int n_seg, const int* pix, const float* w, const float* d_out, int trilinear,
                                  int fold_to_level, hipStream_t st);
-hipError_t launch_adam_tex(float* p, const float* g /*nullable*/, const uint32_t* l0_mask /*nullable*/, const float* g1, float* m, float* v, float* mip1 /*nullable*/,
+hipError_t launch_adam_tex(float* p, const float* g /*nullable*/, const uint32_t* l0_mask /*nullable*/, const float* g1, const float* g2 /*nullable*/, float* m, float* v, float* mip1 /*nullable*/,
                            int H, int W, int C, float lr,
                            float beta1, float beta2, float eps, int step, float lo, float hi, hipStream_t st);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step,

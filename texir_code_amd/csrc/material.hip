@@ -601,14 +601,14 @@ hipError_t launch_tex_fetch_bwd(float* d_tex, float* grad_rest, int H, int W, in
 static void launch_folds(float* d_tex, float* grad_rest, const MipDesc& d, int H, int W, int C, int levels, int fold_to_level, hipStream_t st)
 {
     // one launch folds the whole stack into level `fold_to_level` (1: level 1 stays un-folded into level 0 -- texir_adam_step_tex adds
-    // 0.25 * level 1 while it reads the gradient)
+    // 0.25 * level 1 while it reads the gradient; 2: level 2 stays un-folded into level 1 as well, the optimiser step takes both folds over)
     const int f = fold_to_level;
     if (levels - 1 - f < 1) return;
     if (mip_per_level()) {
         int lt = tail_begin(d);
         if (lt < 2) lt = 2;
         // small levels: levels-1 .. lt folded down to level lt-1 inside one block
-        if (lt < levels) hipLaunchKernelGGL(mip_fold_tail_kernel, dim3(1), dim3(1024), 0, st, grad_rest, d, lt - 1);
+        if (lt < levels) hipLaunchKernelGGL(mip_fold_tail_kernel, dim3(1), dim3(1024), 0, st, grad_rest, d, lt - 1 > f ? lt - 1 : f);
         for (int l = (lt < levels ? lt : levels) - 1; l >= 1 + fold_to_level; l--) {
             float* fine_l = l == 1 ? d_tex : grad_rest + d.off[l - 1];
             launch_fold(fine_l, grad_rest + d.off[l], H >> (l - 1), W >> (l - 1), C, st);
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 //     (same expression as the mip build), which removes the build's pass over the whole level-0 texture.
 template <int C>
 __global__ __launch_bounds__(256) void adam_tex_kernel(float* __restrict__ p, const float* __restrict__ g, const uint32_t* __restrict__ l0_mask,
-                                                       const float* __restrict__ g1, float* __restrict__ m, float* __restrict__ v, float* __restrict__ mip1,
+                                                       const float* __restrict__ g1, const float* __restrict__ g2, float* __restrict__ m, float* __restrict__ v, float* __restrict__ mip1,
                                                        int H, int W, float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float lo, float hi)
 {
     // one thread per (2x2 block column, channel): t = bx * C + ch.  Its level-1 element and its g1 element sit at index t of the
@@ -674,7 +674,8 @@ __global__ __launch_bounds__(256) void adam_tex_kernel(float* __restrict__ p, co
     const int bx = t / C, ch = t - bx * C;
     const int e0 = bx * 2 * C + ch;
     for (int by = blockIdx.y; by < Hh; by += gridDim.y) {
-        const float g1c = g1[(size_t)by * Wh * C + t];
+        float g1c = g1[(size_t)by * Wh * C + t];
+        if (g2) g1c = __builtin_fmaf(0.25f, g2[((size_t)(by >> 1) * (Wh >> 1) + (bx >> 1)) * C + ch], g1c);      // the fold level 2 -> level 1, taken over as well
         float acc = 0.f;
 #pragma unroll
         for (int r = 0; r < 2; r++) {
@@ -704,7 +705,7 @@ __global__ __launch_bounds__(256) void adam_tex_kernel(float* __restrict__ p, co
 // Needs W*C % 4 == 0 (16-byte aligned rows); launch_adam_tex falls back to adam_tex_kernel otherwise.  Identical bits.
 template <int C>
 __global__ __launch_bounds__(256) void adam_tex_vec_kernel(float* __restrict__ p, const float* __restrict__ g, const uint32_t* __restrict__ l0_mask,
-                                                           const float* __restrict__ g1, float* __restrict__ m, float* __restrict__ v, float* __restrict__ mip1,
+                                                           const float* __restrict__ g1, const float* __restrict__ g2, float* __restrict__ m, float* __restrict__ v, float* __restrict__ mip1,
                                                            int H, int W, float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float lo, float hi)
 {
     constexpr int EPB = (1024 / (2 * C)) * (2 * C);
@@ -717,7 +718,14 @@ __global__ __launch_bounds__(256) void adam_tex_vec_kernel(float* __restrict__ p
     const bool act = j4 < n_here;
     const int h_base = e_base / 2, n_half = n_here / 2;              // this block's segment of the half-resolution row
     for (int by = blockIdx.y; by < Hh; by += gridDim.y) {
-        for (int k = threadIdx.x; k < n_half; k += 256) g1s[k] = g1[(size_t)by * Wh * C + h_base + k];
+        for (int k = threadIdx.x; k < n_half; k += 256) {
+            float x = g1[(size_t)by * Wh * C + h_base + k];
+            if (g2) {                                               // the fold level 2 -> level 1, taken over as well (same fma as mip_pyr_fold_kernel's)
+                const int txh = (h_base + k) / C, ch = (h_base + k) - txh * C;
+                x = __builtin_fmaf(0.25f, g2[((size_t)(by >> 1) * (Wh >> 1) + (txh >> 1)) * C + ch], x);
+            }
+            g1s[k] = x;
+        }
         __syncthreads();
         if (act) {
 #pragma unroll
@@ -756,7 +764,7 @@ __global__ __launch_bounds__(256) void adam_tex_vec_kernel(float* __restrict__ p
     }
 }
 
-hipError_t launch_adam_tex(float* p, const float* g, const uint32_t* l0_mask, const float* g1, float* m, float* v, float* mip1, int H, int W, int C,
+hipError_t launch_adam_tex(float* p, const float* g, const uint32_t* l0_mask, const float* g1, const float* g2, float* m, float* v, float* mip1, int H, int W, int C,
                            float lr, float beta1, float beta2, float eps, int step, float lo, float hi, hipStream_t st)
 {
     double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -765,17 +773,17 @@ hipError_t launch_adam_tex(float* p, const float* g, const uint32_t* l0_mask, co
     if ((W * C) % 4 == 0 && !getenv("TEXIR_ADAM_SCALAR")) {
         const int epb = (1024 / (2 * C)) * (2 * C);
         dim3 gridv((W * C + epb - 1) / epb, (H >> 1) > 2048 ? 2048 : (H >> 1));
-        if (C == 1) hipLaunchKernelGGL(adam_tex_vec_kernel<1>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
-        else if (C == 2) hipLaunchKernelGGL(adam_tex_vec_kernel<2>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
-        else if (C == 3) hipLaunchKernelGGL(adam_tex_vec_kernel<3>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
-        else hipLaunchKernelGGL(adam_tex_vec_kernel<4>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+        if (C == 1) hipLaunchKernelGGL(adam_tex_vec_kernel<1>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+        else if (C == 2) hipLaunchKernelGGL(adam_tex_vec_kernel<2>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+        else if (C == 3) hipLaunchKernelGGL(adam_tex_vec_kernel<3>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+        else hipLaunchKernelGGL(adam_tex_vec_kernel<4>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
         return hipGetLastError();
     }
     dim3 grid(((W >> 1) * C + 255) / 256, (H >> 1) > 4096 ? 4096 : (H >> 1));
-    if (C == 1) hipLaunchKernelGGL(adam_tex_kernel<1>, grid, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
-    else if (C == 2) hipLaunchKernelGGL(adam_tex_kernel<2>, grid, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
-    else if (C == 3) hipLaunchKernelGGL(adam_tex_kernel<3>, grid, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
-    else hipLaunchKernelGGL(adam_tex_kernel<4>, grid, dim3(256), 0, st, p, g, l0_mask, g1, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+    if (C == 1) hipLaunchKernelGGL(adam_tex_kernel<1>, grid, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+    else if (C == 2) hipLaunchKernelGGL(adam_tex_kernel<2>, grid, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+    else if (C == 3) hipLaunchKernelGGL(adam_tex_kernel<3>, grid, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+    else hipLaunchKernelGGL(adam_tex_kernel<4>, grid, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
     return hipGetLastError();
 }
 

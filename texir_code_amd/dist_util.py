@@ -40,9 +40,11 @@ def reduce_texture_grads(params):
                          for p in params], device=params[0].device)
     dist.all_reduce(need, op=dist.ReduceOp.MAX)
     for p, n in zip(params, need.tolist()):
-        g1 = getattr(p, "_texir_grad_l1", None)
+        g1, g2 = getattr(p, "_texir_grad_l1", None), getattr(p, "_texir_grad_l2", None)
         if g1 is not None:
             dist.all_reduce(g1)
+        if g2 is not None:                     # (the fold level 2 -> 1 is left to the optimiser step as well: both parts are linear in the ranks' sums)
+            dist.all_reduce(g2)
         if n > 0:
             if p.grad is None:                 # this rank's pixels touched no level-0 texel (the tensor was never made), another rank's did
                 p.grad = torch.zeros_like(p)

@@ -69,7 +69,8 @@ class GraphedMatStep:
         # during this capture (a level-0 gradient, when the view samples level 0) is remembered per graph and re-attached to the
         # parameters before every optimiser step.
         self.grads[(key, stage)] = [(p.grad, getattr(p, "_texir_grad_l1", None), getattr(p, "_texir_l0_touched", True),
-                                     getattr(p, "_texir_l0_mask", None), getattr(p, "_texir_l0_sparse", False)) for p in self.params]
+                                     getattr(p, "_texir_l0_mask", None), getattr(p, "_texir_l0_sparse", False), getattr(p, "_texir_grad_l2", None))
+                                    for p in self.params]
         self.graphs[(key, stage)] = g
         self.losses[(key, stage)] = loss.detach()      # keep no autograd graph of the captured region alive
         self.outs[(key, stage)] = self._last_out
@@ -111,9 +112,10 @@ class GraphedMatStep:
             if getattr(p, "_texir_mips", None) is not None and getattr(p, "_texir_mip1_version", None) != (p.data_ptr(), p._version):
                 refresh_mips(p)
         self.graphs[(key, stage)].replay()
-        for p, (g, g1, l0, mask, sparse) in zip(self.params, self.grads[(key, stage)]):
+        for p, (g, g1, l0, mask, sparse, g2) in zip(self.params, self.grads[(key, stage)]):
             p.grad = g
             p._texir_grad_l1 = g1
+            p._texir_grad_l2 = g2
             p._texir_l0_touched = l0
             p._texir_l0_mask = mask
             p._texir_l0_sparse = sparse

@@ -1,6 +1,7 @@
 """torch.optim.Adam-compatible optimiser whose step is one fused HIP kernel per parameter, optionally fused with the
 clamp the material trainer applies after every step (trainer/train_material.py:448-458,592-593)."""
 import math
+import os
 
 import torch
 
@@ -20,7 +21,8 @@ class FusedAdam(torch.optim.Optimizer):
         for group in self.param_groups:
             for p in group["params"]:
                 p._texir_defer_fold = self.fuse_mip_fold and p.dim() == 3 and p.shape[0] % 2 == 0 and p.shape[1] % 2 == 0
-                p._texir_grad_l1 = None
+                p._texir_defer_levels = int(os.environ.get("TEXIR_DEFER_LEVELS", "2"))      # folds left to the step: level 1 -> 0, and (2) level 2 -> 1 as well
+                p._texir_grad_l1 = p._texir_grad_l2 = None
                 p._texir_l0_touched = False
         self._make_grad_arena()
 
@@ -53,7 +55,7 @@ class FusedAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=True):
         for group in self.param_groups:
             for p in group["params"]:
-                p._texir_grad_l1 = None
+                p._texir_grad_l1 = p._texir_grad_l2 = None
                 p._texir_l0_touched = False
                 p._texir_l0_mask = None
                 p._texir_l0_sparse = False
@@ -64,7 +66,7 @@ class FusedAdam(torch.optim.Optimizer):
         for group in self.param_groups:
             for p in group["params"]:
                 p._texir_defer_fold = False
-                p._texir_grad_l1 = None
+                p._texir_grad_l1 = p._texir_grad_l2 = None
                 p._texir_arena = None
 
     def set_clamp(self, param, lo=-math.inf, hi=math.inf):
@@ -112,12 +114,13 @@ class FusedAdam(torch.optim.Optimizer):
                     # level 1 of the next forward's mip stack is written on the way (texture._mips_for then builds levels 2.. only)
                     mips = getattr(p, "_texir_mips", None)
                     mip1 = mips[1] if (mips is not None and mips[1].numel() >= (H // 2) * (W // 2) * C and mips[1].device == p.device) else None
-                    _lib.check(L.texir_adam_step_tex(_lib.ptr(p), _lib.ptr(g), _lib.ptr(mask), _lib.ptr(g1), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]),
+                    _lib.check(L.texir_adam_step_tex(_lib.ptr(p), _lib.ptr(g), _lib.ptr(mask), _lib.ptr(g1), _lib.ptr(getattr(p, "_texir_grad_l2", None)),
+                                                     _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]),
                                                      _lib.ptr(mip1), H, W, C, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                                      int(st["step"]), lo, hi, _lib.stream_ptr()))
                     p._texir_mip1_version = (p.data_ptr(), p._version) if mip1 is not None else None
                     if not getattr(p, "_texir_l1_static", False):      # (hipGraph replay re-fills the same buffer: keep it)
-                        p._texir_grad_l1 = None
+                        p._texir_grad_l1 = p._texir_grad_l2 = None
                 else:
                     p._texir_mip1_version = None                       # the texture changes behind the mip stack's back
                     _lib.check(L.texir_adam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]), p.numel(),

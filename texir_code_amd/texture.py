@@ -133,6 +133,11 @@ class _TexFetch(torch.autograd.Function):
         # parameter per backward pass defers; a further one folds completely and autograd adds its d_tex as usual.
         defer = (mode == 1 and levels > 1 and owner is not None and getattr(owner, "_texir_defer_fold", False)
                  and getattr(owner, "_texir_grad_l1", None) is None)
+        # FusedAdam can take the last TWO folds over (level 2 -> 1 -> 0): the folds then stop at level 2 and the read-modify-write of the
+        # level-1 stack disappears.  Gather path only (cached tap lists); needs a level above 2 and H, W divisible by 4.
+        defer_levels = 0
+        if defer:
+            defer_levels = 2 if (ctx.taps is not None and levels >= 4 and H % 4 == 0 and W % 4 == 0 and getattr(owner, "_texir_defer_levels", 1) >= 2) else 1
         n_rest = int(L.texir_mip_elems(H, W, C, levels))
         g_rest = None
         if levels > 1:
@@ -183,7 +188,7 @@ class _TexFetch(torch.autograd.Function):
             seg_key, starts, counts, pix, wts = ctx.taps[:5]
             _lib.check(L.texir_tex_gather_backward(_lib.ptr(d_tex), _lib.ptr(g_rest), H, W, C, levels, _lib.ptr(seg_key), _lib.ptr(starts),
                                                    _lib.ptr(counts), seg_key.numel(), _lib.ptr(pix), _lib.ptr(wts), _lib.ptr(d_out), mode,
-                                                   1 if defer else 0, _lib.stream_ptr()))
+                                                   defer_levels, _lib.stream_ptr()))
         elif defer:
             _lib.check(L.texir_tex_fetch_backward_deferred(_lib.ptr(d_tex), _lib.ptr(g_rest), H, W, C, levels, _lib.ptr(uv), _lib.ptr(uv_da),
                                                            uv.shape[0], _lib.ptr(d_out), _lib.stream_ptr()))
@@ -191,7 +196,9 @@ class _TexFetch(torch.autograd.Function):
             _lib.check(L.texir_tex_fetch_backward(_lib.ptr(d_tex), _lib.ptr(g_rest), H, W, C, levels, _lib.ptr(uv), _lib.ptr(uv_da), mode, uv.shape[0],
                                                   _lib.ptr(d_out), _lib.stream_ptr()))
         if defer:
-            owner._texir_grad_l1 = g_rest[:(H // 2) * (W // 2) * C]
+            n1 = (H // 2) * (W // 2) * C
+            owner._texir_grad_l1 = g_rest[:n1]
+            owner._texir_grad_l2 = g_rest[n1:n1 + (H // 4) * (W // 4) * C] if defer_levels == 2 else None
         if owner is not None:
             # does the level-0 gradient of this parameter hold anything at all after this backward pass?  A deferred fetch none of whose
             # pixels samples level 0 leaves d_tex all zero (the multi-GPU reduction can then skip it); any other fetch of the parameter
