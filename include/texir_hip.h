@@ -85,6 +85,8 @@ TEXIR_API int texir_generate_dir(const float* normals /*dev*/, const float* roug
  *   pos,nrm [Nt,3] dev (pos already offset by +1e-2*n, :110), shift [Nt,2] dev
  *   texel_ids [n_ids] i32 dev: the texels to compute (NULL => all Nt, n_ids ignored).  Seam texels
  *     (index texture all-zero, :137-139,176-178) are simply not listed; irr must be zero-initialised by the caller.
+ *     texel_ids == NULL means ALL Nt texels whatever n_ids says: a caller whose list can be empty (a rank's shard of a short list) must skip the call
+ *     -- an empty device array has no address to pass (the Python wrapper does, scene.Scene.irt_generate).
  *   irr [Nt,3] dev: only listed texels are written.  A texel's value has a fixed summation order per kernel form, so for lists of
  *     >= 32768 texels (the 64-texels-per-wave form; shorter lists use the one-texel-per-wave form, which differs in the last bits) the texture does
  *     not depend on the order or sharding of texel_ids nor on the launch configuration.

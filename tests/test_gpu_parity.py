@@ -143,6 +143,38 @@ def test_scalar_float_node_path_changes_nothing(room, tx, monkeypatch):
     assert np.array_equal(ra, rb)
 
 
+def test_empty_inputs_are_noops(room, tx):
+    """zero texels / rays / pixels / taps: every entry point returns an empty (or untouched) result instead of launching a 0-block grid or
+    raising (the reference's tensors of length 0 flow through torch the same way)"""
+    from texir_code_amd.scene import generate_dir, spec_render
+    from texir_code_amd.texture import texture
+    g, sc, _ = room
+    pos, nrm, shift = torch.from_numpy(g["pos"]), torch.from_numpy(g["nrm"]), torch.from_numpy(g["shift"])
+    none = torch.zeros(0, dtype=torch.int32, device="cuda")
+    out = torch.full((pos.reshape(-1, 3).shape[0], 3), 7.0, device="cuda")
+    irr = sc.irt_generate(pos, nrm, shift, 64, "uniform", texel_ids=none, out=out)
+    assert irr.shape == out.shape and bool((irr == 7.0).all())                   # nothing listed, nothing written
+    z3 = torch.zeros(0, 3, device="cuda")
+    assert sc.trace_shade(z3, z3).shape == (0, 3)
+    rad, t, pid, uv = sc.trace_shade(z3, z3, return_hits=True)
+    assert rad.shape == (0, 3) and t.numel() == 0 and pid.numel() == 0 and uv.numel() == 0
+    assert generate_dir(z3, 16, torch.zeros(0, 2), "cosine").shape == (0, 16, 3)
+    rgb = spec_render(sc, z3, z3, torch.zeros(0, device="cuda"), z3, z3, torch.zeros(3, device="cuda"), torch.zeros(0, 2, device="cuda"), 16)
+    assert rgb.shape == (0, 3)
+    tex = torch.rand(16, 16, 3, device="cuda", requires_grad=True)
+    o = texture(tex, torch.zeros(0, 2, device="cuda"), torch.zeros(0, 4, device="cuda"), "linear-mipmap-linear", 4)
+    assert o.shape == (0, 3)
+    o.sum().backward()
+    assert tex.grad is not None and float(tex.grad.abs().sum()) == 0.0
+    # ragged: a texel list that is not a multiple of the 64-texel wave, shorter than one wave, and one texel
+    v = np.argwhere(g["valid"].reshape(-1) > 0)[:, 0]
+    ref = sc.irt_generate(pos, nrm, shift, 64, "uniform", texel_ids=torch.from_numpy(v.astype(np.int32)).cuda()).cpu().numpy()
+    for n in (1, 63, 65, 130):
+        ids = torch.from_numpy(v[:n].astype(np.int32)).cuda()
+        part = sc.irt_generate(pos, nrm, shift, 64, "uniform", texel_ids=ids).cpu().numpy()
+        assert np.array_equal(part[v[:n]], ref[v[:n]]), n                        # the estimator is per texel: list length and wave packing do not matter
+
+
 def test_irt_constant_radiance_closed_room(tx):
     """analytic KAT: closed room, constant radiance L  =>  E -> pi*L  (sum ndl*2pi/N -> pi)"""
     from texir_code_amd import synth

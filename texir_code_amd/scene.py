@@ -103,8 +103,9 @@ class Scene:
             t = torch.empty(R, device=self.device, dtype=torch.float32)
             pid = torch.empty(R, device=self.device, dtype=torch.int32)
             uv = torch.empty((R, 2), device=self.device, dtype=torch.float32)
-        _lib.check(_lib.lib().texir_trace_shade(self.h, _lib.ptr(org), _lib.ptr(dir), R, float(t_min), _lib.ptr(rad), _lib.ptr(t),
-                                                _lib.ptr(pid), _lib.ptr(uv), _lib.stream_ptr()))
+        if R > 0:                                   # (zero rays: empty results; an empty tensor has no pointer to hand to the library)
+            _lib.check(_lib.lib().texir_trace_shade(self.h, _lib.ptr(org), _lib.ptr(dir), R, float(t_min), _lib.ptr(rad), _lib.ptr(t),
+                                                    _lib.ptr(pid), _lib.ptr(uv), _lib.stream_ptr()))
         return (rad, t, pid, uv) if return_hits else rad
 
     # -- TracerO3d.forward hot loop (tracer_o3d_irt.py:156-178) -------------------------------------------
@@ -121,6 +122,10 @@ class Scene:
             ids = texel_ids.to(device=self.device, dtype=torch.int32).contiguous()
             n_ids = ids.numel()
         st = torch.zeros(8, device=self.device, dtype=torch.int64) if stats else None
+        if Nt == 0 or (texel_ids is not None and n_ids == 0):
+            # nothing to do.  (An EMPTY id list must not reach the library: its null data pointer would read as "no list = all texels" --
+            # the case of a rank whose shard of a small texel list is empty, dist_util.shard_block_cyclic)
+            return (out, st) if stats else out
         _lib.check(_lib.lib().texir_irt_generate(self.h, _lib.ptr(pos), _lib.ptr(nrm), _lib.ptr(shift), _lib.ptr(ids), n_ids, Nt,
                                                  int(n_samples), MODES[mode], _lib.ptr(out), _lib.ptr(st), _lib.stream_ptr()))
         return (out, st) if stats else out
@@ -134,6 +139,8 @@ def generate_dir(normals, num_sample_dir, shift, mode="uniform", roughness=None)
     shift = _dev_f32(shift, dev).reshape(b, 2)
     r = None if roughness is None else roughness.to(torch.float32).contiguous().reshape(b)
     L = torch.empty((b, num_sample_dir, 3), device=dev, dtype=torch.float32)
+    if b == 0:
+        return L
     _lib.check(_lib.lib().texir_generate_dir(_lib.ptr(normals), _lib.ptr(r), _lib.ptr(shift), b, int(num_sample_dir), MODES[mode],
                                              _lib.ptr(L), _lib.stream_ptr()))
     return L
@@ -148,9 +155,10 @@ class _SpecRender(torch.autograd.Function):
         rgb = torch.empty((P, 3), device=normal.device, dtype=torch.float32)
         # lighting given: specular_reflectance on the caller's radiance (no tracing); else traced and kept for the backward
         Ls = torch.empty((P, S, 3), device=normal.device, dtype=torch.float32) if lighting is None else lighting
-        _lib.check(_lib.lib().texir_spec_forward(None if scene is None else scene.h, _lib.ptr(normal), _lib.ptr(albedo), _lib.ptr(rough), _lib.ptr(points),
-                                                 _lib.ptr(irr), _lib.ptr(cam), _lib.ptr(shift), P, S, float(clamp_eps), 0 if lighting is None else 1,
-                                                 _lib.ptr(rgb), _lib.ptr(Ls), _lib.stream_ptr()))
+        if P > 0:
+            _lib.check(_lib.lib().texir_spec_forward(None if scene is None else scene.h, _lib.ptr(normal), _lib.ptr(albedo), _lib.ptr(rough), _lib.ptr(points),
+                                                     _lib.ptr(irr), _lib.ptr(cam), _lib.ptr(shift), P, S, float(clamp_eps), 0 if lighting is None else 1,
+                                                     _lib.ptr(rgb), _lib.ptr(Ls), _lib.stream_ptr()))
         ctx.save_for_backward(normal, rough, points, irr, cam, shift, Ls)
         ctx.S, ctx.clamp_eps = S, float(clamp_eps)
         return rgb
@@ -163,9 +171,10 @@ class _SpecRender(torch.autograd.Function):
         need_a, need_r = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
         d_a = torch.empty((P, 3), device=normal.device, dtype=torch.float32) if need_a else None
         d_r = torch.empty((P,), device=normal.device, dtype=torch.float32) if need_r else None
-        _lib.check(_lib.lib().texir_spec_backward(_lib.ptr(normal), _lib.ptr(rough), _lib.ptr(points), _lib.ptr(irr), _lib.ptr(cam),
-                                                  _lib.ptr(shift), _lib.ptr(Ls), _lib.ptr(d_rgb), P, ctx.S, ctx.clamp_eps, _lib.ptr(d_a), _lib.ptr(d_r),
-                                                  _lib.stream_ptr()))
+        if P > 0:
+            _lib.check(_lib.lib().texir_spec_backward(_lib.ptr(normal), _lib.ptr(rough), _lib.ptr(points), _lib.ptr(irr), _lib.ptr(cam),
+                                                      _lib.ptr(shift), _lib.ptr(Ls), _lib.ptr(d_rgb), P, ctx.S, ctx.clamp_eps, _lib.ptr(d_a), _lib.ptr(d_r),
+                                                      _lib.stream_ptr()))
         return None, None, d_a, d_r, None, None, None, None, None, None, None
 
 
@@ -188,6 +197,8 @@ def diffuse_irradiance(scene, points, normals, shift, num_samples, sample_type="
     P = points.reshape(-1, 3).shape[0]
     f = lambda t, s: t.to(device=dev, dtype=torch.float32).reshape(*s).contiguous()
     out = torch.empty((P, 3), device=dev, dtype=torch.float32)
+    if P == 0:
+        return out
     _lib.check(_lib.lib().texir_diffuse_irradiance(scene.h, _lib.ptr(f(points, (P, 3))), _lib.ptr(f(normals, (P, 3))), _lib.ptr(f(shift, (P, 2))), P,
                                                    int(num_samples), MODES[sample_type], _lib.ptr(out), _lib.stream_ptr()))
     return out

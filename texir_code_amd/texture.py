@@ -111,8 +111,9 @@ class _TexFetch(torch.autograd.Function):
         P = uv.shape[0]
         t0 = tex.detach()
         out = torch.empty((P, C), device=tex.device, dtype=torch.float32)
-        _lib.check(L.texir_tex_fetch_forward(_lib.ptr(t0), _lib.ptr(rest), H, W, C, levels, _lib.ptr(uv), _lib.ptr(uv_da), mode, P, _lib.ptr(out),
-                                             _lib.stream_ptr()))
+        if P > 0:                                    # (zero fetch coordinates: an empty result, and a zero gradient in the backward)
+            _lib.check(L.texir_tex_fetch_forward(_lib.ptr(t0), _lib.ptr(rest), H, W, C, levels, _lib.ptr(uv), _lib.ptr(uv_da), mode, P, _lib.ptr(out),
+                                                 _lib.stream_ptr()))
         ctx.save_for_backward(uv, uv_da)
         ctx.meta = (H, W, C, levels, mode)
         ctx.owner = owner
@@ -125,6 +126,8 @@ class _TexFetch(torch.autograd.Function):
         H, W, C, levels, mode = ctx.meta
         if not ctx.needs_input_grad[0]:
             return None, None, None, None, None, None, None, None
+        if uv.shape[0] == 0:
+            return torch.zeros((H, W, C), device=d_out.device, dtype=torch.float32), None, None, None, None, None, None, None
         L = _lib.lib()
         d_out = d_out.contiguous()
         owner = ctx.owner
@@ -238,7 +241,7 @@ def texture(tex, uv, uv_da=None, filter_mode="linear", max_mip_level=13, cache=N
         ps = [q for q in arena["params"] if q.requires_grad]
         arena["buf"][min(q._texir_arena_span[0] for q in ps):max(q._texir_arena_span[1] for q in ps)].zero_()
         arena["clean"] = set(id(q) for q in ps)
-    if cache is not None and tex.requires_grad and torch.is_grad_enabled():
+    if cache is not None and tex.requires_grad and torch.is_grad_enabled() and uvf.shape[0] > 0:
         taps = _tap_lists(cache, H, W, C, levels, mode, uvf, daf)
     out = _TexFetch.apply(tex, rest, uvf, daf, mode, levels, owner if isinstance(owner, torch.nn.Parameter) else None, taps)
     return out.reshape(*lead, C)
