@@ -28,7 +28,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     def _make_grad_arena(self):
         """ONE buffer for the mip-level gradient stacks of all deferring texture parameters (per device), so that a step clears them with
-        a single fill (texture.py backward) instead of one per parameter.  A slot is sized for the full pyramid of its texture (levels
+        a single fill (at the step's first trainable fetch, texture.texture) instead of one per parameter.  A slot is sized for the full pyramid of its texture (levels
         1 .. 1x1: one third of the texture); the backward uses the leading part its fetch's level count needs."""
         by_dev = {}
         for group in self.param_groups:
