@@ -19,8 +19,9 @@ dominant kernel (rocprofv3 --pmc, committed under profiles/pmc_<workload>.json t
 -- a profile of other sources is refused) divided by the kernel time measured live with HIP events:
   * memory: fabric-side bytes (L2 <-> Infinity Cache/HBM read requests x 128 B + writes) / time / 8 TB/s,
   * VALU issue: SQ_INSTS_VALU / (1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction x time),
-  * vector L1: TCP_TOTAL_CACHE_ACCESSES / (the 256 TCPs' clocks over the same time) -- a TCP serves one access per clock.
-`bound` names the largest ("hbm" | "valu" | "l1"; `achieved` / `peak` / `traffic` stay the fabric-side GB/s figures).  SURVEY.md 8(d)'s algorithmic bytes (canonical BVH2 visit counts x 32/36 B) are reported under
+  * vector L1: TCP_TOTAL_CACHE_ACCESSES / (the 256 TCPs' clocks over the same time) -- a TCP serves one access per clock (self-calibrated).
+The top-level `bound` / `achieved` / `peak` / `frac` / `traffic` are always the memory side (frac = achieved / peak); `binding` names the
+tightest of the three, `limits` carries each one's numerator, denominator and fraction.  SURVEY.md 8(d)'s algorithmic bytes (canonical BVH2 visit counts x 32/36 B) are reported under
 `algorithmic` -- they are served by L1/L2 hits of a 4x more compact tree and exceed the HBM peak, so they bound nothing.
 `cpu_baseline` = the CPU oracle (a port of the reference algorithm; Open3D/Embree is not installable here) timed
 on this box's host cores on a bounded sample of the same workload.
@@ -123,22 +124,21 @@ def cpu_leg(sc0, pos, nrm, valid, shift, spp, budget_s=15.0, timed=True):
             "sample": "%d random valid texels x %d spp (%.1f s) of the same workload, canonical BVH2 oracle, OpenMP" % (n, spp, dt)}, c
 
 
-def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5):
-    """material-estimation step latency (BASELINE.json: "material-step ms at 4k tex"): stage-2 (joint) optimiser step =
-    4 texture fetches (4k albedo x3 / 4k roughness x1 / irradiance, mip stacks rebuilt) + GGX-importance specular trace
-    (P = 6*128^2 pixels x 16 spp) + fused RenderLoss/SegLoss + backward + (gradient all-reduce) + fused Adam over 67.1 M texels."""
-    from texir_code_amd import cameras, conf as C, dist_util, synth
+def mat_setup(sc, sc0, irr_tex, res, dev, cube=128, S=16, tres=4096, n_views=16, fuse=True):
+    """the material-step problem of BASELINE.json ("material-step ms at 4k tex") on a synthetic scene: MaterialModel with tres^2 albedo /
+    roughness textures, per-view data (ground truth rendered from the synthetic GT materials, segmentation / highlight masks built as the
+    trainer builds them), the fused loss and optimiser.  Shared by mat_leg, tools/run_c5.py and the 4k-texture tests."""
+    from texir_code_amd import cameras, conf as C, synth
     from texir_code_amd.loss import RenderLoss
     from texir_code_amd.models import MaterialModel
     from texir_code_amd.optim import FusedAdam
     from texir_code_amd.trainer.train_material import build_masks
-    cube, S, tres = 128, 16, 4096
     conf = C.parse_string("train{ pano_img_res = [%d,%d]\n sample_light = [2048,%d]\n hdr_exposure = 0 }\nmodels{ render{ sample_type = [uniform, importance] } }"
                           % (2 * cube, 4 * cube, S))
     irrt = torch.flip(irr_tex.reshape(res, res, 3), dims=[0]).contiguous()          # file orientation
     model = MaterialModel.from_arrays(sc, sc0["hdr"], irrt, conf, albedo_res=tres, roughness_res=tres)
     model.lean_outputs = True               # (as the runner sets it: the un-mipmapped roughness fetch only feeds the stage-1 loss)
-    views = [cameras.cube_mvps(E) for E in cameras.grid_cameras(4)]
+    views = [cameras.cube_mvps(E) for E in cameras.grid_cameras(4)][:n_views]
     sc0 = dict(sc0)
     if "patches" not in sc0:                 # (workload came from the array cache: the chart list is needed for the GT materials)
         sc0["patches"] = synth.make_scene(sc0["T"], seed=666, tex_res=8, style=sc0.get("style", "room"))["patches"]
@@ -160,9 +160,19 @@ def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5):
         model.materials_a.copy_(a0)
         model.materials_r.copy_(r0)
     loss_fn = RenderLoss("L1", 1, lazy_item=True, unit_upstream=True)       # (as the runner's hipGraph path sets it)
-    opt = FusedAdam([model.materials_a, model.materials_r], lr=3e-2, fuse_mip_fold=True)
+    opt = FusedAdam([model.materials_a, model.materials_r], lr=3e-2, fuse_mip_fold=fuse)
     opt.set_clamp(model.materials_r, 1e-2, 0.8)
     opt.set_clamp(model.materials_a, 0.0, float("inf"))
+    return model, views, data, loss_fn, opt
+
+
+def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5):
+    """material-estimation step latency (BASELINE.json: "material-step ms at 4k tex"): stage-2 (joint) optimiser step =
+    4 texture fetches (4k albedo x3 / 4k roughness x1 / irradiance, mip stacks rebuilt) + GGX-importance specular trace
+    (P = 6*128^2 pixels x 16 spp) + fused RenderLoss/SegLoss + backward + (gradient all-reduce) + fused Adam over 67.1 M texels."""
+    from texir_code_amd import dist_util
+    cube, S, tres = 128, 16, 4096
+    model, views, data, loss_fn, opt = mat_setup(sc, sc0, irr_tex, res, dev, cube, S, tres)
     if world > 1:
         import torch.distributed as dist
 
@@ -276,14 +286,21 @@ def roofline(workload, kernel, kern_ms, rays_this_rank, world, alg):
         fr = {"hbm": mem_frac, "valu": valu_frac}
         if l1 is not None:
             fr["l1"] = l1
-        bound = max(fr, key=fr.get)
-        out.update({"bound": bound, "achieved": round(traffic / t / 1e9, 1), "frac": round(fr[bound], 4),
-                    "traffic": traffic, "memory": {"fabric_bytes_per_launch": traffic, "gbs": round(traffic / t / 1e9, 1), "frac_of_8TBs": round(mem_frac, 4),
-                                                   "bytes_per_ray": round(traffic / rays_this_rank, 1), "l2_hit_rate": pmc.get("l2_hit_rate")},
-                    "valu_issue": {"insts_per_launch": valu, "peak_insts_per_s": SIMDS * CLOCK_HZ / 2.0, "frac": round(valu_frac, 4),
-                                   "lane_utilisation": pmc.get("valu_lane_utilisation"), "insts_per_64_rays": round(valu / (rays_this_rank / 64.0), 1)},
-                    "l1_tcp": None if l1 is None else {"accesses_per_launch": float(pmc["tcp_cache_accesses"]) * scale, "frac": round(l1, 4),
-                                                        "note": "vector-L1 cache accesses / (256 TCPs x TCP clock x t); peak 1 access per clock per TCP"},
+        # The top-level triple is ALWAYS the memory side (achieved / peak = frac, recomputable from the line itself); which of the three
+        # measured limits is the tightest is named under `binding`, each limit with its own numerator and denominator under `limits`.
+        out.update({"bound": "hbm", "achieved": round(traffic / t / 1e9, 1), "frac": round(mem_frac, 4), "traffic": traffic,
+                    "binding": max(fr, key=fr.get),
+                    "limits": {
+                        "hbm": {"frac": round(mem_frac, 4), "achieved": round(traffic / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "fabric_bytes_per_launch": traffic, "bytes_per_ray": round(traffic / rays_this_rank, 1), "l2_hit_rate": pmc.get("l2_hit_rate"),
+                                "note": "L2 <-> Infinity Cache / HBM: TCC_EA0_RDREQ x request size + WRITE_SIZE (MI355X_MICROARCH.md HBM section), / kernel time / 8 TB/s"},
+                        "valu": {"frac": round(valu_frac, 4), "achieved": round(valu / t / 1e9, 2), "peak": round(SIMDS * CLOCK_HZ / 2.0 / 1e9, 2), "unit": "G wave-instructions/s",
+                                 "insts_per_launch": valu, "insts_per_64_rays": round(valu / (rays_this_rank / 64.0), 1), "lane_utilisation": pmc.get("valu_lane_utilisation"),
+                                 "note": "SQ_INSTS_VALU / t against 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction"},
+                        "l1": None if l1 is None else {"frac": round(l1, 4), "achieved": round(float(pmc["tcp_cache_accesses"]) * scale / t / 1e9, 2),
+                                                       "peak": round(tcp_hz / 1e9, 2), "unit": "G cache accesses/s", "accesses_per_launch": float(pmc["tcp_cache_accesses"]) * scale,
+                                                       "note": "vector-L1 (TCP) tag lookups; the peak -- one access per clock per TCP, 256 TCPs at the clock TCP_GATE_EN1 reports -- is "
+                                                               "SELF-CALIBRATED (tools/tcp_rate.hip on this hardware, profiles/r02/tcp_rate.txt), not a documented figure"}},
                     "waves": {"wait_any_frac": pmc.get("sq_wait_any_frac"), "active_inst_any_frac": pmc.get("sq_active_inst_any_frac"),
                               "note": "share of the resident waves' cycles spent waiting / issuing (SQ_WAIT_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES)"},
                     "scalar_path": None if pmc.get("smem_insts") is None else {"smem_insts_per_launch": float(pmc["smem_insts"]) * scale,
@@ -324,7 +341,8 @@ def main():
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-mat", action="store_true")
-    ap.add_argument("--extra", default="", help="comma-separated extra workloads timed after the headline (IrT only), reported under extra_workloads")
+    ap.add_argument("--extra", default=None, help="comma-separated extra workloads timed after the headline (IrT only), reported under extra_workloads; "
+                    "default: c4_scan (the hostile sibling) next to the c4 headline, nothing otherwise; `none` switches it off")
     args = ap.parse_args()
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
@@ -357,6 +375,15 @@ def main():
             dist.init_process_group(backend)
 
     from texir_code_amd import scene as S, dist_util
+
+    # N > 1: rank 0 generates the synthetic scene + texel G-buffers once, the other ranks load them (8 ranks each building the 1 M-triangle
+    # scene and the 4096^2 G-buffer would cost 8x the host RAM and time before the first barrier).  Every rank derives the same directory
+    # from the rendezvous port; rank 0 removes it at the end if this run created it.
+    made_cache = None
+    if world > 1 and not os.environ.get("TEXIR_SYNTH_CACHE"):
+        import tempfile
+        made_cache = os.path.join(tempfile.gettempdir(), "texir_synth_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getuid()))
+        os.environ["TEXIR_SYNTH_CACHE"] = made_cache
 
     def barrier():
         if world > 1:
@@ -401,14 +428,31 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        ranks = None
         if world > 1:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
+            # per-rank kernel time (load imbalance of the block-cyclic shards shows here) and a check of the assembly: rank 0 re-traces a 1 %
+            # sample of the texel blocks -- its own and the other ranks' -- alone and compares with the all-reduced texture, bit for bit
+            km = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(km, torch.tensor([kern_ms], device=dev, dtype=torch.float64))
+            km = [float(x.item()) for x in km]
+            ok = None
+            if rank == 0:
+                nb = (int(ids_all.numel()) + BLOCK - 1) // BLOCK
+                pick = torch.arange(0, nb, 100)
+                sample = torch.cat([ids_all[int(b) * BLOCK:(int(b) + 1) * BLOCK] for b in pick]).to(dev)
+                alone = torch.zeros_like(irr)
+                sc.irt_generate(d_pos, d_nrm, d_shift, spp, "uniform", texel_ids=sample, out=alone)
+                ok = bool(torch.equal(alone[sample.long()], irr[sample.long()]))
+                del alone
+            ranks = {"kernel_ms_min": round(min(km), 3), "kernel_ms_max": round(max(km), 3), "kernel_ms": [round(x, 3) for x in km],
+                     "assembled_ok": ok, "assembled_check": "rank 0 alone re-traced every 100th %d-texel block of the list; bit-equal to the all-reduced texture" % BLOCK}
         T, _, tex_res, _, style = WORKLOADS[name]
         n_valid = int(ids_all.numel())
         return {"sc": sc, "sc0": sc0, "pos": pos, "nrm": nrm, "valid": valid, "shift": shift, "res": res, "spp": spp, "irr": irr, "ids": ids,
-                "dt": dt, "kern_ms": kern_ms, "n_valid": n_valid, "build_s": build_s, "kernel": sc.irt_kernel_name(int(ids.numel()), spp),
+                "dt": dt, "kern_ms": kern_ms, "ranks": ranks, "n_valid": n_valid, "build_s": build_s, "kernel": sc.irt_kernel_name(int(ids.numel()), spp),
                 "value": n_valid * spp * steps / dt / 1e6,
                 "desc": "%s: IrT %d spp, %dx%d texels (%d valid), %d-tri synthetic %s mesh, %dx%d RGB32F radiance texture"
                         % (name, spp, res, res, n_valid, T, "indoor" if style == "room" else "scan-like (rotated clutter, slats, openings)", tex_res, tex_res)}
@@ -432,6 +476,9 @@ def main():
         }
         if mat is not None:
             out["material_step"] = mat
+        if r["ranks"] is not None:
+            out["ranks"] = r["ranks"]
+            out["assembled_ok"] = r["ranks"]["assembled_ok"]
         rays_this_rank = int(r["ids"].numel()) * r["spp"]
         alg = cpu = None
         if not args.no_cpu:
@@ -441,7 +488,9 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
     # further workloads (IrT only), never the headline
-    extras = [w for w in args.extra.split(",") if w]
+    if args.extra is None:
+        args.extra = "c4_scan" if args.workload == "c4" else ""
+    extras = [w for w in args.extra.split(",") if w and w != "none"]
     if extras:
         del r
         torch.cuda.empty_cache()
@@ -460,6 +509,10 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
+        if rank == 0 and made_cache:
+            import shutil
+            shutil.rmtree(made_cache, ignore_errors=True)
         dist.destroy_process_group()
 
 

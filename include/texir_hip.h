@@ -233,6 +233,19 @@ TEXIR_API int texir_adam_step_tex(float* param, const float* grad /*nullable: le
                        int32_t H, int32_t W, int32_t C, float lr, float beta1, float beta2, float eps, int32_t step, float clamp_lo,
                        float clamp_hi, void* stream);
 
+/* The same two steps for launches that must not depend on host arguments that change every step (a captured hipGraph of the whole
+ * optimisation step, trainer/train_material.py:408-458 -- forward, loss, backward AND optimizer.step()): the step count, learning rate
+ * and betas of up to 64 parameters live in device memory (`state` [n][4] doubles: step count, lr, beta1, beta2).  texir_adam_tick
+ * advances the step count of the records selected by `mask` (bit i = record i) and writes hyper[i] = (lr / (1 - beta1^step),
+ * sqrt(1 - beta2^step)) in double precision, the expressions of torch.optim.Adam's single-tensor path; the *_dev steps read their
+ * record's pair instead of taking (lr, step).  A learning-rate scheduler writes state[i][1] between steps. */
+TEXIR_API int texir_adam_tick(double* state /*dev [n][4]*/, float* hyper /*dev [n][2]*/, int32_t n_records, uint64_t mask, void* stream);
+TEXIR_API int texir_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper /*dev [2]*/,
+                       float beta1, float beta2, float eps, float clamp_lo, float clamp_hi, void* stream);
+TEXIR_API int texir_adam_step_tex_dev(float* param, const float* grad, const uint32_t* grad_mask, const float* grad_level1, const float* grad_level2,
+                       float* exp_avg, float* exp_avg_sq, float* mip_level1, int32_t H, int32_t W, int32_t C, const float* hyper /*dev [2]*/,
+                       float beta1, float beta2, float eps, float clamp_lo, float clamp_hi, void* stream);
+
 /* ---- host-side codec loops of the file formats around the path (both take HOST pointers) ----------------------------
  * PNG scanline un-filtering (filters 0-4, PNG spec 9.2) of zlib-inflated IDAT data: raw [H][stride+1] -> out [H][stride]; replaces the
  * decode half of cv2.imread("0.png", -1) (models/tracer_o3d_irt.py:91, datasets/dataset.py:489-492). */

@@ -22,6 +22,15 @@ def golden():
     return load
 
 
+@pytest.fixture(scope="session")
+def tx():
+    """the product's scene module (GPU tests)"""
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from texir_code_amd import scene as S
+    return S
+
+
 def rel_l2(a, b):
     import numpy as np
     a = np.asarray(a, np.float64)

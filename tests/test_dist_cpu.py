@@ -48,3 +48,37 @@ def test_shard_world1_identity():
     from texir_code_amd import dist_util
     ids = torch.arange(10)
     assert dist_util.shard_block_cyclic(ids, 0, 1) is ids
+
+
+def _grad_worker(rank, world, port):
+    """reduce_texture_grads when the ranks hold DIFFERENT parts of the gradient: rank 0 parked level-1 and level-2 stacks and
+    sampled no level-0 texel, rank 1's pixel shard was empty (nothing at all); a second parameter has a dense gradient on rank 1 only"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from texir_code_amd import dist_util
+    H = W = 8
+    p, q = torch.nn.Parameter(torch.zeros(H, W, 3)), torch.nn.Parameter(torch.zeros(H, W, 1))
+    for t in (p, q):
+        t._texir_grad_l1 = t._texir_grad_l2 = None
+        t._texir_l0_touched = False
+        t._texir_arena = None
+    n1, n2 = (H // 2) * (W // 2) * 3, (H // 4) * (W // 4) * 3
+    if rank == 0:
+        p._texir_grad_l1, p._texir_grad_l2 = torch.full((n1,), 2.0), torch.full((n2,), 3.0)
+    else:
+        q.grad = torch.full((H, W, 1), 5.0)
+        q._texir_l0_touched = True
+        # rank 1's slot of a gradient arena: the zeros it contributes for p come from there
+        buf = torch.full((n1 + n2 + 7,), 9.0)
+        p._texir_arena, p._texir_arena_span = {"buf": buf, "params": [p], "clean": {id(p)}}, (0, n1 + n2 + 7)
+    dist_util.reduce_texture_grads([p, q])
+    assert p.grad is None                                                  # no rank sampled level 0 of p: the 4 * H * W * C bytes are never reduced
+    assert torch.equal(p._texir_grad_l1, torch.full((n1,), 2.0)) and torch.equal(p._texir_grad_l2, torch.full((n2,), 3.0))
+    assert torch.equal(q.grad, torch.full((H, W, 1), 5.0)) and q._texir_grad_l1 is None
+    if rank == 1:
+        assert id(p) not in p._texir_arena["clean"]                        # (the slot holds the reduced stacks now)
+    dist.destroy_process_group()
+
+
+def test_reduce_texture_grads_with_uneven_parts_world2():
+    mp.spawn(_grad_worker, args=(2, _free_port()), nprocs=2, join=True)

@@ -71,6 +71,8 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    # rank 0 re-traced a sample of both ranks' texel blocks alone: the all-reduced texture must hold exactly those values
+    assert d["assembled_ok"] is True and len(d["ranks"]["kernel_ms"]) == 2 and d["ranks"]["kernel_ms_max"] >= d["ranks"]["kernel_ms_min"] > 0
 
 
 @pytest.fixture(scope="module")

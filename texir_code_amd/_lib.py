@@ -61,6 +61,9 @@ def lib():
         sig["texir_tex_taps"] = [i32, i32, i32, i32, vp, vp, i32, i64, vp, vp, vp]
         sig["texir_tex_gather_backward"] = [vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp]
         sig["texir_adam_step_tex"] = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, i32, f32, f32, vp]
+        sig["texir_adam_tick"] = [vp, vp, i32, C.c_uint64, vp]
+        sig["texir_adam_step_dev"] = [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, vp]
+        sig["texir_adam_step_tex_dev"] = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, f32, f32, f32, f32, f32, vp]
         L.texir_mip_levels.argtypes = [i32, i32, i32]
         L.texir_mip_levels.restype = i32
         L.texir_mip_elems.argtypes = [i32, i32, i32, i32]

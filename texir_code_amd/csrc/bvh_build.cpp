@@ -151,11 +151,12 @@ struct Quant { uint8_t lo[3], hi[3]; };
 // behind a shared edge or vertex that lies exactly on the box's face (flat, axis-aligned geometry: every ray that hits it).
 // slack = 2^-19 * M is 8x that bound and ~1/50 of a leaf-level cell: it moves a quantised plane by one cell only when the true
 // plane happens to sit within `slack` of a cell boundary (a few percent of the planes) -- no measurable extra node visits.
-static float g_slack = 0.f;         // set per build (build_bvh), read by emit4_fill
+// (the slack and the output vectors travel in Emit4Ctx: texir_scene_create may run on several host threads at once)
+struct Emit4Ctx { float slack; std::vector<GpuNode4>* out; std::vector<GpuNode4F>* out4f; int32_t dummy_leaf; int max_depth; };
 
-void emit4_fill(GpuNode4& g, const Box& nb, const Tmp* const* kids, int nk, const int32_t* codes, int32_t dummy_leaf)
+void emit4_fill(GpuNode4& g, const Box& nb, const Tmp* const* kids, int nk, const int32_t* codes, int32_t dummy_leaf, float slack_f)
 {
-    const double slack = (double)g_slack;
+    const double slack = (double)slack_f;
     float scale[3];
     for (int a = 0; a < 3; a++) {
         const double ext = (double)nb.mx[a] - (double)nb.mn[a] + 2.0 * slack;
@@ -189,31 +190,25 @@ void emit4_fill(GpuNode4& g, const Box& nb, const Tmp* const* kids, int nk, cons
     g.lox = lo[0]; g.loy = lo[1]; g.loz = lo[2]; g.hix = hi[0]; g.hiy = hi[1]; g.hiz = hi[2];
 }
 
-#if TEXIR_BUILD_F32NODES
-static std::vector<GpuNode4F>* g_out4f = nullptr;
-
-static void emit4f_fill(GpuNode4F& g, const Tmp* const* kids, int nk, const int32_t* codes, int32_t dummy_leaf)
+static void emit4f_fill(GpuNode4F& g, const Tmp* const* kids, int nk, const int32_t* codes, int32_t dummy_leaf, float slack)
 {
     for (int k = 0; k < 4; k++) {
         for (int a = 0; a < 3; a++) {
             // unused slot: inverted box.  Used slot: the child's box widened by the absolute slack, rounded outwards
-            g.plane[2 * a][k] = k < nk ? std::nextafter((float)((double)kids[k]->box.mn[a] - (double)g_slack), -FLT_MAX) : 1e30f;
-            g.plane[2 * a + 1][k] = k < nk ? std::nextafter((float)((double)kids[k]->box.mx[a] + (double)g_slack), FLT_MAX) : -1e30f;
+            g.plane[2 * a][k] = k < nk ? std::nextafter((float)((double)kids[k]->box.mn[a] - (double)slack), -FLT_MAX) : 1e30f;
+            g.plane[2 * a + 1][k] = k < nk ? std::nextafter((float)((double)kids[k]->box.mx[a] + (double)slack), FLT_MAX) : -1e30f;
         }
         g.c[k] = k < nk ? codes[k] : dummy_leaf;
         g.pad[k] = 0;
     }
 }
-#endif
 
-int32_t emit4(const Tmp* t, std::vector<GpuNode4>& out, int depth, int& max_depth, int32_t dummy_leaf)
+int32_t emit4(const Tmp* t, Emit4Ctx& cx, int depth)
 {
-    int32_t idx = (int32_t)out.size();
-    out.emplace_back();
-#if TEXIR_BUILD_F32NODES
-    g_out4f->emplace_back();
-#endif
-    if (depth > max_depth) max_depth = depth;
+    const int32_t idx = (int32_t)cx.out->size();
+    cx.out->emplace_back();
+    cx.out4f->emplace_back();
+    if (depth > cx.max_depth) cx.max_depth = depth;
     const Tmp* kids[4]; int nk = 0;
     if (t->count) { kids[nk++] = t; }                      // degenerate root leaf
     else { kids[nk++] = t->l.get(); kids[nk++] = t->r.get(); }
@@ -225,11 +220,9 @@ int32_t emit4(const Tmp* t, std::vector<GpuNode4>& out, int depth, int& max_dept
         kids[best] = o->l.get(); kids[nk++] = o->r.get();
     }
     int32_t codes[4];
-    for (int k = 0; k < nk; k++) codes[k] = kids[k]->count ? leaf_code(kids[k]) : emit4(kids[k], out, depth + 1, max_depth, dummy_leaf);
-    emit4_fill(out[idx], t->box, kids, nk, codes, dummy_leaf);
-#if TEXIR_BUILD_F32NODES
-    emit4f_fill((*g_out4f)[idx], kids, nk, codes, dummy_leaf);
-#endif
+    for (int k = 0; k < nk; k++) codes[k] = kids[k]->count ? leaf_code(kids[k]) : emit4(kids[k], cx, depth + 1);
+    emit4_fill((*cx.out)[idx], t->box, kids, nk, codes, cx.dummy_leaf, cx.slack);
+    emit4f_fill((*cx.out4f)[idx], kids, nk, codes, cx.dummy_leaf, cx.slack);
     return idx;
 }
 
@@ -246,12 +239,13 @@ void build_bvh(const float* verts, int V, const int32_t* tris, int T, const floa
         for (int a = 0; a < 3; a++) cen[3 * (size_t)p + a] = 0.5f * (tb[p].mn[a] + tb[p].mx[a]);
         order[p] = p;
     }
+    float slack = 0.f;
     {   // absolute box slack of this scene (see emit4_fill); TEXIR_BOX_SLACK_LOG2 overrides the exponent for A/B runs (99 = none)
         float M = 0.f;
         for (int64_t i = 0; i < 3 * (int64_t)V; i++) M = std::max(M, std::fabs(verts[i]));
         const char* e = getenv("TEXIR_BOX_SLACK_LOG2");
         const int l2 = e ? atoi(e) : -19;
-        g_slack = l2 == 99 ? 0.f : std::ldexp(M, l2);
+        slack = l2 == 99 ? 0.f : std::ldexp(M, l2);
     }
     Ctx c{&tb, &cen, &order};
     unsigned hw = std::max(1u, std::thread::hardware_concurrency());
@@ -277,23 +271,17 @@ void build_bvh(const float* verts, int V, const int32_t* tris, int T, const floa
     }
     out.nodes4.clear();
     out.nodes4.reserve((size_t)T / 2 + 16);
-    int d4 = 0;
-#if TEXIR_BUILD_F32NODES
     out.nodes4f.clear();
     out.nodes4f.reserve((size_t)T / 2 + 16);
-    g_out4f = &out.nodes4f;
-#endif
     // slot T holds a degenerate (all-zero) triangle: the target of unused child slots
-    const int32_t dummy_leaf = ~(int32_t)(((uint32_t)T << 3) | 0u);
-    emit4(root.get(), out.nodes4, 1, d4, dummy_leaf);
-    out.max_depth4 = d4;
+    Emit4Ctx cx{slack, &out.nodes4, &out.nodes4f, ~(int32_t)(((uint32_t)T << 3) | 0u), 0};
+    emit4(root.get(), cx, 1);
+    out.max_depth4 = cx.max_depth;
     out.tris.resize((size_t)T + 1);
     std::memset(&out.tris[T], 0, sizeof(GpuTri));
     out.tris[T].prim = 0xFFFFFFFFu;
-#if !TEXIR_TRI64
     out.uvs.resize((size_t)T + 1);
     std::memset(&out.uvs[T], 0, sizeof(GpuTriUV));
-#endif
     for (int i = 0; i < T; i++) {
         int p = order[i];
         const float* a = verts + 3 * (size_t)tris[3 * (size_t)p];
@@ -307,14 +295,10 @@ void build_bvh(const float* verts, int V, const int32_t* tris, int T, const floa
 #endif
         g.prim = (uint32_t)p;
         const float* uv = tri_uvs + 6 * (size_t)p;
-#if TEXIR_TRI64
-        g.uv0x = uv[0]; g.uv0y = uv[1]; g.uv1x = uv[2]; g.uv1y = uv[3]; g.uv2x = uv[4]; g.uv2y = uv[5];
-#else
         g.pad1 = g.pad2 = 0.f;
         GpuTriUV& u = out.uvs[i];
         std::memcpy(u.uv, uv, sizeof(float) * 6);
         u.uv[6] = u.uv[7] = 0.f;
-#endif
     }
 }
 

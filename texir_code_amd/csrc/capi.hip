@@ -62,7 +62,7 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
     if (!verts || !tris || !tri_uvs || !hdr_tex || !out) return fail(TEXIR_ERR_INVALID, "texir_scene_create: null argument");
     if (V <= 0 || T <= 0 || Ht <= 0 || Wt <= 0) return fail(TEXIR_ERR_INVALID, "texir_scene_create: empty mesh or texture");
     // the traversal addresses nodes and triangles with 32-bit byte offsets (64-byte nodes, 48-byte triangle records)
-    if ((uint64_t)(T + 1) * sizeof(GpuTri) >= (1ull << 32) || (TEXIR_NODE_F32 && (uint64_t)T * 64u >= (1ull << 32))) return fail(TEXIR_ERR_INVALID, "texir_scene_create: too many triangles (%d; limit 67 M with 64-byte, 89 M with 48-byte triangles)", (int)T);
+    if ((uint64_t)(T + 1) * sizeof(GpuTri) >= (1ull << 32)) return fail(TEXIR_ERR_INVALID, "texir_scene_create: too many triangles (%d; limit 89 M)", (int)T);
     for (int64_t i = 0; i < 3 * (int64_t)T; i++)
         if (tris[i] < 0 || tris[i] >= V) return fail(TEXIR_ERR_INVALID, "texir_scene_create: triangle index %d out of range", (int)tris[i]);
     HIP_TRY(hipSetDevice(device));
@@ -83,26 +83,19 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
     s->width = (want_w == 4 && 3 * h.max_depth4 + 2 <= kStackCap) ? 4 : 2;
     if (s->width == 4) {
         s->n_nodes4 = (int64_t)h.nodes4.size(); s->max_depth = h.max_depth4;
-#if TEXIR_NODE_F32
-        if ((e = hipMalloc(&s->d_nodes4, h.nodes4f.size() * sizeof(GpuNode4F))) != hipSuccess) return bail(e, "hipMalloc nodes4");
-        if ((e = hipMemcpy(s->d_nodes4, h.nodes4f.data(), h.nodes4f.size() * sizeof(GpuNode4F), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload nodes4");
-#else
         if ((e = hipMalloc(&s->d_nodes4, h.nodes4.size() * sizeof(GpuNode4))) != hipSuccess) return bail(e, "hipMalloc nodes4");
         if ((e = hipMemcpy(s->d_nodes4, h.nodes4.data(), h.nodes4.size() * sizeof(GpuNode4), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload nodes4");
-#if TEXIR_UNIFORM_SLOAD >= 2
         // the float form of the same nodes, read by wave-uniform node steps through the scalar cache (TEXIR_UNIFORM_FLOAT=0: A/B switch)
         if (!(getenv("TEXIR_UNIFORM_FLOAT") && atoi(getenv("TEXIR_UNIFORM_FLOAT")) == 0)) {
             if ((e = hipMalloc(&s->d_nodes4f, h.nodes4f.size() * sizeof(GpuNode4F))) != hipSuccess) return bail(e, "hipMalloc nodes4f");
             if ((e = hipMemcpy(s->d_nodes4f, h.nodes4f.data(), h.nodes4f.size() * sizeof(GpuNode4F), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload nodes4f");
         }
-#endif
-#endif
     }
     if ((e = hipMalloc(&s->d_nodes, h.nodes.size() * sizeof(GpuNode))) != hipSuccess) return bail(e, "hipMalloc nodes");
     if ((e = hipMalloc(&s->d_tris, h.tris.size() * sizeof(GpuTri))) != hipSuccess) return bail(e, "hipMalloc tris");
     if (!h.uvs.empty() && (e = hipMalloc(&s->d_uvs, h.uvs.size() * sizeof(GpuTriUV))) != hipSuccess) return bail(e, "hipMalloc uvs");
     if ((e = hipMalloc((void**)&s->d_tex, s->tex_bytes)) != hipSuccess) return bail(e, "hipMalloc texture");
-    if ((e = hipMalloc((void**)&s->d_work, texir_scene::kWorkSlots * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc work counters");
+    if ((e = hipMalloc((void**)&s->d_work, texir_scene::kWorkSlots * 8 * kWorkStride * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc work counters");
     if ((e = hipMemcpy(s->d_nodes, h.nodes.data(), h.nodes.size() * sizeof(GpuNode), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload nodes");
     if ((e = hipMemcpy(s->d_tris, h.tris.data(), h.tris.size() * sizeof(GpuTri), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload tris");
     if (!h.uvs.empty() && (e = hipMemcpy(s->d_uvs, h.uvs.data(), h.uvs.size() * sizeof(GpuTriUV), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload uvs");
@@ -155,7 +148,7 @@ int texir_scene_info(const texir_scene* s, int64_t out[8])
 {
     if (!s || !out) return fail(TEXIR_ERR_INVALID, "texir_scene_info: null argument");
     out[0] = s->width == 4 ? s->n_nodes4 : s->n_nodes; out[1] = s->n_tris; out[2] = s->max_depth;
-    out[3] = s->width == 4 ? s->n_nodes4 * (int64_t)(TEXIR_NODE_F32 ? sizeof(GpuNode4F) : sizeof(GpuNode4) + (s->d_nodes4f ? sizeof(GpuNode4F) : 0)) : s->n_nodes * (int64_t)sizeof(GpuNode);
+    out[3] = s->width == 4 ? s->n_nodes4 * (int64_t)(sizeof(GpuNode4) + (s->d_nodes4f ? sizeof(GpuNode4F) : 0)) : s->n_nodes * (int64_t)sizeof(GpuNode);
     out[4] = s->n_tris * (int64_t)sizeof(GpuTri); out[5] = s->d_uvs ? s->n_tris * (int64_t)sizeof(GpuTriUV) : 0; out[6] = (int64_t)(s->d_tex_tiled ? s->tiled_bytes : s->tex_bytes); out[7] = s->device;
     return TEXIR_OK;
 }
@@ -187,7 +180,7 @@ int texir_irt_generate(const texir_scene* s, const float* pos, const float* nrm,
     if (N <= 0 || Nt < 0 || n_ids < 0) return fail(TEXIR_ERR_INVALID, "texir_irt_generate: bad sizes N=%d Nt=%lld n_ids=%lld", N, (long long)Nt, (long long)n_ids);
     if (Nt >= (1ll << 31)) return fail(TEXIR_ERR_INVALID, "texir_irt_generate: Nt too large");
     int64_t n = texel_ids ? n_ids : Nt;
-    unsigned long long* work = s->d_work + (s->work_next.fetch_add(1) % texir_scene::kWorkSlots);
+    unsigned long long* work = s->d_work + (size_t)(s->work_next.fetch_add(1) % texir_scene::kWorkSlots) * 8 * kWorkStride;
     HIP_TRY(launch_irt(s->dev, pos, nrm, shift, texel_ids, n, N, mode, irr, (unsigned long long*)stats, work, (hipStream_t)stream));
     return TEXIR_OK;
 }
@@ -226,7 +219,7 @@ int texir_diffuse_irradiance(const texir_scene* s, const float* pos, const float
     if (!s || !pos || !nrm || !shift || !irr) return fail(TEXIR_ERR_INVALID, "texir_diffuse_irradiance: null argument");
     if (sample_type < 0 || sample_type > 1) return fail(TEXIR_ERR_INVALID, "texir_diffuse_irradiance: sample_type must be uniform(0) or cosine(1)");
     if (N <= 0 || P < 0 || P >= (1ll << 31)) return fail(TEXIR_ERR_INVALID, "texir_diffuse_irradiance: bad sizes N=%d P=%lld", N, (long long)P);
-    unsigned long long* work = s->d_work + (s->work_next.fetch_add(1) % texir_scene::kWorkSlots);
+    unsigned long long* work = s->d_work + (size_t)(s->work_next.fetch_add(1) % texir_scene::kWorkSlots) * 8 * kWorkStride;
     // uniform: (2 pi / N) sum L n.l -- the IrT estimator; cosine: (pi / N) sum L over cosine-distributed directions
     const int mode = sample_type == 1 ? (1 | 4) : 0;
     HIP_TRY(launch_irt(s->dev, pos, nrm, shift, nullptr, P, N, mode, irr, nullptr, work, (hipStream_t)stream));
@@ -339,7 +332,7 @@ int texir_adam_step_tex(float* param, const float* grad, const uint32_t* grad_ma
     if (!param || !grad_level1 || !exp_avg || !exp_avg_sq) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex: null argument");
     if (H < 2 || W < 2 || (H & 1) || (W & 1) || C < 1 || C > 4 || step < 1) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex: bad H/W/C/step");
     if (grad_level2 && ((H & 3) || (W & 3))) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex: a level-2 gradient needs H and W divisible by 4");
-    HIP_TRY(launch_adam_tex(param, grad, grad_mask, grad_level1, grad_level2, exp_avg, exp_avg_sq, mip_level1, H, W, C, lr, beta1, beta2, eps, step, clamp_lo, clamp_hi, (hipStream_t)stream));
+    HIP_TRY(launch_adam_tex(param, grad, grad_mask, grad_level1, grad_level2, exp_avg, exp_avg_sq, mip_level1, H, W, C, lr, beta1, beta2, eps, step, clamp_lo, clamp_hi, nullptr, (hipStream_t)stream));
     return TEXIR_OK;
 }
 
@@ -348,7 +341,36 @@ int texir_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
 {
     if (!param || !grad || !exp_avg || !exp_avg_sq) return fail(TEXIR_ERR_INVALID, "texir_adam_step: null argument");
     if (n < 0 || step < 1) return fail(TEXIR_ERR_INVALID, "texir_adam_step: bad n/step");
-    HIP_TRY(launch_adam(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, clamp_lo, clamp_hi, (hipStream_t)stream));
+    HIP_TRY(launch_adam(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, clamp_lo, clamp_hi, nullptr, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
+int texir_adam_tick(double* state, float* hyper, int32_t n_records, uint64_t mask, void* stream)
+{
+    if (!state || !hyper) return fail(TEXIR_ERR_INVALID, "texir_adam_tick: null argument");
+    if (n_records < 0 || n_records > 64) return fail(TEXIR_ERR_INVALID, "texir_adam_tick: 0..64 records per call (got %d)", n_records);
+    HIP_TRY(launch_adam_tick(state, hyper, n_records, (unsigned long long)mask, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
+int texir_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper, float beta1, float beta2,
+                        float eps, float clamp_lo, float clamp_hi, void* stream)
+{
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper) return fail(TEXIR_ERR_INVALID, "texir_adam_step_dev: null argument");
+    if (n < 0) return fail(TEXIR_ERR_INVALID, "texir_adam_step_dev: bad n");
+    HIP_TRY(launch_adam(param, grad, exp_avg, exp_avg_sq, n, 0.f, beta1, beta2, eps, 1, clamp_lo, clamp_hi, hyper, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
+int texir_adam_step_tex_dev(float* param, const float* grad, const uint32_t* grad_mask, const float* grad_level1, const float* grad_level2, float* exp_avg,
+                            float* exp_avg_sq, float* mip_level1, int32_t H, int32_t W, int32_t C, const float* hyper, float beta1, float beta2, float eps,
+                            float clamp_lo, float clamp_hi, void* stream)
+{
+    if (!param || !grad_level1 || !exp_avg || !exp_avg_sq || !hyper) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex_dev: null argument");
+    if (H < 2 || W < 2 || (H & 1) || (W & 1) || C < 1 || C > 4) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex_dev: bad H/W/C");
+    if (grad_level2 && ((H & 3) || (W & 3))) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex_dev: a level-2 gradient needs H and W divisible by 4");
+    HIP_TRY(launch_adam_tex(param, grad, grad_mask, grad_level1, grad_level2, exp_avg, exp_avg_sq, mip_level1, H, W, C, 0.f, beta1, beta2, eps, 1, clamp_lo, clamp_hi, hyper,
+                            (hipStream_t)stream));
     return TEXIR_OK;
 }
 

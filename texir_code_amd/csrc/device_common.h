@@ -7,33 +7,15 @@
 
 #include "bvh_build.h"
 
-// 1: byte -> float conversions of the node step rewritten in full-rate operations (see traverse).  Measured -10 % (c4 13.7 vs 15.2
-// Grays/s, profiles/r02): kept as a documented experiment, off.
-// 1: wave-uniform node steps fetch the node once and broadcast it through LDS (A/B flag, see traverse)
-#ifndef TEXIR_UNIFORM_BCAST
-#define TEXIR_UNIFORM_BCAST 0
-#endif
-#ifndef TEXIR_FAST_DEQUANT
-#define TEXIR_FAST_DEQUANT 0
-#endif
-#ifndef TEXIR_USF_MIN_LANES
-#define TEXIR_USF_MIN_LANES 1
-#endif
-#ifndef TEXIR_PSORT3
-#define TEXIR_PSORT3 0
-#endif
-// TEXIR_UNIFORM_SLOAD (bvh_build.h): 1: wave-uniform node steps read their node through the scalar cache (s_load) instead of 64 x 64 bytes
-// through the vector L1; 2: ... and read the float form of the node when the rays' direction signs agree as well (see traverse)
-
 namespace texir {
 
 struct SceneDev {
     const float4* nodes4;  // GpuNode4 as 4 x 16 B (4-wide quantised tree; null when the scene was built binary-only)
     const float4* nodes4f; // GpuNode4F (float child planes of the same tree, index for index) -- read through the scalar cache by wave-uniform
-                           // node steps (TEXIR_UNIFORM_SLOAD = 2); null otherwise
+                           // node steps; null = every node step per lane (TEXIR_UNIFORM_FLOAT=0)
     const float4* nodes;   // GpuNode as 4 x float4
     const float4* tris;    // GpuTri as kTriQuads x float4
-    const float4* uvs;     // GpuTriUV as 2 x float4 (null when the triangle record carries the uvs: TEXIR_TRI64)
+    const float4* uvs;     // GpuTriUV as 2 x float4
     const float* tex;      // [Ht,Wt,3] row-major (layout 0), or the retiled copy the hit shader reads (layouts 1, 2: see shade_hit)
     int Ht, Wt;
     int tex_layout;        // 0 row-major; 1 = 8x8-texel tiles of 12-byte texels; 2 = overlapping 3x3 tiles at stride 2, one 128-byte line each
@@ -115,25 +97,10 @@ __device__ __forceinline__ void sample_dir(int mode, float s0, float s1, float r
 // corner uvs of the triangle in leaf slot `slot`: a = (uv0, uv1), b = (uv2, -, -)
 __device__ __forceinline__ void tri_uvs(const SceneDev& sc, int slot, float4& a, float4& b)
 {
-#if TEXIR_TRI64
-    // the w components of the record's first three quads and its fourth quad (the line the intersection test has just read)
-    const char* const tp = reinterpret_cast<const char*>(sc.tris) + ((uint32_t)slot << 6);
-    const float4 q3 = *reinterpret_cast<const float4*>(tp + 48);
-    a.x = *reinterpret_cast<const float*>(tp + 12); a.y = *reinterpret_cast<const float*>(tp + 28); a.z = *reinterpret_cast<const float*>(tp + 44); a.w = q3.x;
-    b.x = q3.y; b.y = q3.z; b.z = b.w = 0.f;
-#else
     a = sc.uvs[2 * (size_t)slot]; b = sc.uvs[2 * (size_t)slot + 1];
-#endif
 }
 // primitive id (row of the caller's index array) of the triangle in leaf slot `slot`
-__device__ __forceinline__ uint32_t tri_prim(const SceneDev& sc, int slot)
-{
-#if TEXIR_TRI64
-    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(sc.tris) + ((uint32_t)slot << 6) + 60);
-#else
-    return __float_as_uint(sc.tris[3 * (size_t)slot].w);
-#endif
-}
+__device__ __forceinline__ uint32_t tri_prim(const SceneDev& sc, int slot) { return __float_as_uint(sc.tris[3 * (size_t)slot].w); }
 
 // ------------------------------------------------------------------------------------------------
 // hit shader: query_irf post-intersection math (tracer_o3d_irt.py:248-267)
@@ -204,41 +171,57 @@ __device__ __forceinline__ float edge2_exact(float bx, float by, float cx, float
 #pragma clang fp contract(fast)
 
 // ------------------------------------------------------------------------------------------------
-// closest-hit traversal, one ray per lane.  Stack: kLdsStack entries per lane in LDS laid out
-// [entry][thread] (conflict-free ds_read/write_b32), deeper entries in a private overflow array.
+// closest-hit traversal, one ray per lane.  Stack: LSTK entries per lane in LDS laid out
+// [entry][thread] (conflict-free ds_read/write), deeper entries in a private overflow array.
 // Returns hit triangle slot (leaf order) or -1; t in units of |dir| (Embree semantics: t > 0).
 // ------------------------------------------------------------------------------------------------
 struct Hit { float t, u, v; int slot; };
 
-// Per-lane traversal state.  A ray is started with ray_begin() and advanced with traverse(); node == kSentinel <=> finished.
-struct RayState {
-    float dx, dy, dz, idx, idy, idz, oodx, oody, oodz;
-#if TEXIR_TRI_WATERTIGHT
-    float mx[3], my[3], mz[3];       // rows of the ray-space shear: x' = A . mx, y' = A . my, z' = A . mz (A = vertex - origin)
+// TEXIR_SCHED (A/B switch; 1 = default).  How the wave shares its issue slots between lanes that hold an inner node and lanes
+// that hold a leaf:
+//   0: "while-while" -- node steps until NO lane holds an inner node, then leaf steps until NO lane holds a leaf.  One lane on a
+//      long run of inner nodes keeps 63 lanes waiting at their leaves: on cluttered scenes the wave executes 2.8x the node steps of
+//      its average ray (c4_scan: 55 wave-level node steps per pass for 19.7 per ray, of which only 30 are the slowest lane's).
+//   1: per step, ballot + population count of both kinds of lanes and the body with more lanes waiting runs; node lanes count
+//      kSchedNodeWeight-fold (a leaf step -- 1 or 2 watertight triangle tests and the culling pop -- costs ~1.5 node steps, and leaf lanes
+//      are worth batching).  Every lane still performs exactly the same node visits, triangle tests and stack operations in the same
+//      order (the schedule only decides WHEN a lane's next step issues), so hits are identical bit for bit.
+//      CPU replay of the kernel's schedule (tools/bvh_sim.cpp): c4_scan 55.3 -> 36.8 (weight 1) / 40.6 (weight 2) wave-level node
+//      steps per pass, c4 19.5 -> 17.6 / 17.8.  Measured (gpurun_out/r03_s1, r03_s2; Grays/s, while-while = 1): weight 1: c4_scan 1.26-1.28,
+//      c4 0.97-1.00 (the leaf batches get smaller: wave-level triangle steps 5.2 -> 7.1); weight 2: c4_scan 1.23, c4 1.00; weight 3: 1.19, 1.00.
+#ifndef TEXIR_SCHED
+#define TEXIR_SCHED 1
 #endif
-#if TEXIR_NODE_F32
-    uint32_t offn[3];                // byte offset of the NEAR plane array of each axis inside a 128-byte float node (far = offset ^ 16)
+#ifndef TEXIR_SCHED_NODE_WEIGHT
+#define TEXIR_SCHED_NODE_WEIGHT 2
 #endif
-    Hit h;
-    int node, sp;
-};
+constexpr int kSchedNodeWeight = TEXIR_SCHED_NODE_WEIGHT;
 
-__device__ __forceinline__ void ray_begin(RayState& r, float ox, float oy, float oz, float dx, float dy, float dz)
+// CULL: a stack entry also carries the child's entry distance, and an entry whose distance is not below the closest hit found
+// since it was pushed is dropped when it is popped (it cannot contain a closer hit: same result, bit for bit) instead of
+// costing a node fetch + a full node step that finds all four children behind the hit.  Entries are 8 bytes then (one
+// ds_write_b64 / ds_read_b64, conflict-free in the [entry][thread] layout), so a kernel keeps LSTK * 2 KiB of LDS per block.
+template <bool CULL> struct StackEntry { typedef int type; };
+template <> struct StackEntry<true> { typedef int2 type; };
+
+// closest hit of one ray per lane, run to completion (all lanes of the wave enter and leave together).  One instance per kernel: it
+// owns the LDS part of the stacks.  STATS: n_nodes / n_tris count this lane's node fetches and triangle tests; wave_iters[0/1] (if
+// given) count, on the first active lane, how many times the wave executed the node-step and the triangle-test bodies.
+template <bool STATS, int LSTK = kLdsStack, int WIDTH = 2, bool CULL = false>
+__device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float oy, float oz, float dx, float dy, float dz,
+                                             uint32_t& n_nodes, uint32_t& n_tris, uint32_t* wave_iters = nullptr)
 {
+    typedef typename StackEntry<CULL>::type Entry;
     const float ooeps = 8.271806e-25f;  // 2^-80
-    r.dx = dx; r.dy = dy; r.dz = dz;
-    r.idx = __builtin_amdgcn_rcpf(fabsf(dx) > ooeps ? dx : copysignf(ooeps, dx));
-    r.idy = __builtin_amdgcn_rcpf(fabsf(dy) > ooeps ? dy : copysignf(ooeps, dy));
-    r.idz = __builtin_amdgcn_rcpf(fabsf(dz) > ooeps ? dz : copysignf(ooeps, dz));
-    r.oodx = ox * r.idx; r.oody = oy * r.idy; r.oodz = oz * r.idz;
-    r.h.t = __builtin_inff(); r.h.u = 0.f; r.h.v = 0.f; r.h.slot = -1;
-    r.node = 0; r.sp = 0;
-#if TEXIR_NODE_F32
-    r.offn[0] = r.idx < 0.f ? 16u : 0u; r.offn[1] = r.idy < 0.f ? 48u : 32u; r.offn[2] = r.idz < 0.f ? 80u : 64u;
-#endif
+    const float idx = __builtin_amdgcn_rcpf(fabsf(dx) > ooeps ? dx : copysignf(ooeps, dx));
+    const float idy = __builtin_amdgcn_rcpf(fabsf(dy) > ooeps ? dy : copysignf(ooeps, dy));
+    const float idz = __builtin_amdgcn_rcpf(fabsf(dz) > ooeps ? dz : copysignf(ooeps, dz));
+    const float oodx = ox * idx, oody = oy * idy, oodz = oz * idz;
 #if TEXIR_TRI_WATERTIGHT
+    // rows of the ray-space shear: x' = A . mx, y' = A . my, z' = A . mz (A = vertex - origin).  kz = dominant axis of the direction,
+    // (kx, ky) the other two in an order that keeps the winding; the shear maps d to (0, 0, 1)
+    float mx[3], my[3], mz[3];
     {
-        // kz = dominant axis of the direction, (kx, ky) the other two in an order that keeps the winding; the shear maps d to (0, 0, 1)
         const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
         const int kz = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
         const float dkz = kz == 0 ? dx : (kz == 1 ? dy : dz);
@@ -249,56 +232,28 @@ __device__ __forceinline__ void ray_begin(RayState& r, float ox, float oy, float
         const float Sz = __builtin_amdgcn_rcpf(dkz), Sx = dkx * Sz, Sy = dky * Sz;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            r.mx[c] = c == kx ? 1.f : (c == kz ? -Sx : 0.f);
-            r.my[c] = c == ky ? 1.f : (c == kz ? -Sy : 0.f);
-            r.mz[c] = c == kz ? Sz : 0.f;
+            mx[c] = c == kx ? 1.f : (c == kz ? -Sx : 0.f);
+            my[c] = c == ky ? 1.f : (c == kz ? -Sy : 0.f);
+            mz[c] = c == kz ? Sz : 0.f;
         }
     }
 #endif
-}
-
-struct NeverLeave { static constexpr bool never = true; __device__ bool operator()(int) const { return false; } };
-
-// Advances the rays of a wave in whole while-while rounds (node steps until every lane is at a leaf, then triangle steps
-// until every lane is back at a node) until all lanes have finished, or until leave(node) -- evaluated once per round with
-// the lane's current node -- is true (it must be wave-uniform and define `static constexpr bool never = false`; a persistent
-// kernel can use it to hand finished lanes their next ray -- measured slower than lock-step passes).  One instance per kernel (it owns the LDS part of the stacks); `ovf` is the caller's private overflow.
-//
-// CULL: a stack entry also carries the child's entry distance, and an entry whose distance is not below the closest hit found
-// since it was pushed is dropped when it is popped (it cannot contain a closer hit: same result, bit for bit) instead of
-// costing a node fetch + a full node step that finds all four children behind the hit.  Entries are 8 bytes then (one
-// ds_write_b64 / ds_read_b64, conflict-free in the [entry][thread] layout), so a kernel keeps LSTK * 2 KiB of LDS per block.
-template <bool CULL> struct StackEntry { typedef int type; };
-template <> struct StackEntry<true> { typedef int2 type; };
-
-template <bool STATS, int LSTK, int WIDTH, bool CULL, typename Leave>
-__device__ __forceinline__ void traverse(const SceneDev& sc, RayState& r, typename StackEntry<CULL>::type (&ovf)[kStackCap - LSTK], float ox, float oy, float oz,
-                                         uint32_t& n_nodes, uint32_t& n_tris, uint32_t* wave_iters, Leave leave)
-{
-    typedef typename StackEntry<CULL>::type Entry;
-    // STATS: n_nodes / n_tris count this lane's node fetches and triangle tests; wave_iters[0/1] (if given) count, on the first
-    // active lane, how many times the wave executed the node-step and the triangle-step bodies (for lane-utilisation figures)
+    Hit h;
+    h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f; h.slot = -1;
+    int node = 0;
     auto first_active = [&]() -> bool { unsigned long long m = __ballot(1); return (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1; };
     // the traversal stack: LSTK entries per lane in LDS ([entry][thread]), deeper ones private.  The stack pointer is kept as
     // the LDS address of the next free entry (push = ds_write + one add, no index scaling in the node step).
     __shared__ Entry lds_all[LSTK * kBlock];
-#if TEXIR_UNIFORM_BCAST
-    __shared__ float4 bcast_all[4 * (kBlock / 64)];          // 64 bytes per wave: the node of a wave-uniform step
-#endif
+    Entry ovf[kStackCap - LSTK];
     Entry* const base = lds_all + threadIdx.x;
     Entry* const lim = base + LSTK * kBlock;
-    Entry* top = base + r.sp * kBlock;
-    const float dx = r.dx, dy = r.dy, dz = r.dz, idx = r.idx, idy = r.idy, idz = r.idz, oodx = r.oodx, oody = r.oody, oodz = r.oodz;
-    Hit h = r.h;
-    int node = r.node;
-#if TEXIR_UNIFORM_SLOAD >= 2
+    Entry* top = base;
     // byte offsets of the NEAR plane array of each axis inside a 128-byte float node (far = offset ^ 16), wave-uniform when the rays' signs agree
     const uint32_t lon = (idx < 0.f ? 16u : 0u) | ((idy < 0.f ? 48u : 32u) << 8) | ((idz < 0.f ? 80u : 64u) << 16);
     const uint32_t son = (uint32_t)__builtin_amdgcn_readfirstlane((int)lon);
-    const bool signs_uniform = sc.nodes4f != nullptr && !__any(lon != son);
+    const bool signs_uniform = WIDTH == 4 && sc.nodes4f != nullptr && !__any(lon != son);
     const uint32_t son0 = son & 255u, son1 = (son >> 8) & 255u, son2 = son >> 16;
-#endif
-    (void)dx; (void)dy; (void)dz;       // (the watertight intersector of the 4-wide path reads the ray's shear rows instead)
     auto make = [](int code, float tn) -> Entry { if constexpr (CULL) return make_int2(code, __float_as_int(tn)); else return code; };
     // LDS part and private overflow are kept in separate, wave-uniformly guarded code paths: the overflow is almost never
     // touched (depth > LSTK), and hipcc must not merge the two address spaces into one flat access
@@ -318,300 +273,174 @@ __device__ __forceinline__ void traverse(const SceneDev& sc, RayState& r, typena
             else return v;
         }
     };
-    for (;;) {
-        // run-to-completion callers: plain per-lane loop.  Resumable callers: wave-uniform loop control -- finished lanes stay in
-        // the loop, masked off by the inner loops, so that leave() sees them
-        if (Leave::never ? node == kSentinel : (!__any(node != kSentinel) || leave(node))) break;
-        if (WIDTH == 4) {
-            while (node >= 0 && node != kSentinel) {
-#if TEXIR_NODE_F32
-                // full-float child boxes: the six plane arrays are fetched through per-ray offsets (near = the lo array if the direction
-                // component is positive, else the hi array), so the step has neither conversions nor selects: 24 fma + min/max
-                // (uniform base + ONE 32-bit byte offset per load: saddr-form loads, one full-rate add each)
-                const char* const nbase = reinterpret_cast<const char*>(sc.nodes4);
-                const uint32_t no = (uint32_t)node << 7;
-                auto ld = [&](uint32_t off) { return *reinterpret_cast<const float4*>(nbase + (no + off)); };
-                const float4 pnx = ld(r.offn[0]), pfx = ld(r.offn[0] ^ 16u), pny = ld(r.offn[1]), pfy = ld(r.offn[1] ^ 16u);
-                const float4 pnz = ld(r.offn[2]), pfz = ld(r.offn[2] ^ 16u);
-                const int4 ch = *reinterpret_cast<const int4*>(nbase + (no + 96u));
-                if (STATS) { n_nodes++; if (wave_iters && first_active()) wave_iters[0]++; }
-                float key[4]; int code[4] = {ch.x, ch.y, ch.z, ch.w};
-                const float nxa[4] = {pnx.x, pnx.y, pnx.z, pnx.w}, fxa[4] = {pfx.x, pfx.y, pfx.z, pfx.w}, nya[4] = {pny.x, pny.y, pny.z, pny.w};
-                const float fya[4] = {pfy.x, pfy.y, pfy.z, pfy.w}, nza[4] = {pnz.x, pnz.y, pnz.z, pnz.w}, fza[4] = {pfz.x, pfz.y, pfz.z, pfz.w};
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const float nxt = nxa[k] * idx - oodx, fxt = fxa[k] * idx - oodx, nyt = nya[k] * idy - oody, fyt = fya[k] * idy - oody;
-                    const float nzt = nza[k] * idz - oodz, fzt = fza[k] * idz - oodz;
-                    const float tn = fmaxf(fmaxf(nxt, nyt), fmaxf(nzt, 0.f)), tf = fminf(fminf(fxt, fyt), fminf(fzt, h.t));
-                    key[k] = tn <= tf ? tn : __builtin_inff();
-                }
-#else
-#if TEXIR_UNIFORM_SLOAD
-                // The box tests of one node step, on node words that are either per-lane (vector loads) or wave-uniform (scalar loads):
-                float key[4]; int code[4];
-                auto box4 = [&](const auto& q0x, const auto& q0y, const auto& q0z, const auto& q0w, const auto& q1x, const auto& q1y, const auto& q1z, const auto& q1w,
-                                const auto& q2x, const auto& q2y, const auto& q2z, const auto& q2w) __attribute__((always_inline)) {
-                    const float sx = __uint_as_float(q0w) * idx, sy = __uint_as_float(q2z) * idy, sz = __uint_as_float(q2w) * idz;
-                    const float bx = __uint_as_float(q0x) * idx - oodx, by = __uint_as_float(q0y) * idy - oody, bz = __uint_as_float(q0z) * idz - oodz;
-                    const uint32_t nx_ = idx < 0.f ? q1w : q1x, fx_ = idx < 0.f ? q1x : q1w;
-                    const uint32_t ny_ = idy < 0.f ? q2x : q1y, fy_ = idy < 0.f ? q1y : q2x;
-                    const uint32_t nz_ = idz < 0.f ? q2y : q1z, fz_ = idz < 0.f ? q1z : q2y;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int sh = 8 * k;
-                        float nxt = (float)((nx_ >> sh) & 255u) * sx + bx, fxt = (float)((fx_ >> sh) & 255u) * sx + bx;
-                        float nyt = (float)((ny_ >> sh) & 255u) * sy + by, fyt = (float)((fy_ >> sh) & 255u) * sy + by;
-                        float nzt = (float)((nz_ >> sh) & 255u) * sz + bz, fzt = (float)((fz_ >> sh) & 255u) * sz + bz;
-                        float tn = fmaxf(fmaxf(nxt, nyt), fmaxf(nzt, 0.f));
-                        float tf = fminf(fminf(fxt, fyt), fminf(fzt, h.t));
-                        key[k] = tn <= tf ? tn : __builtin_inff();
-                    }
-                };
-                // Wave-uniform steps (the rays of a pass leave neighbouring points in nearly the same direction and walk the upper levels
-                // together: 45 % of the wave-level node steps on c4): a vector fetch costs the L1 64 lanes x 64 bytes whether or not the lanes
-                // agree (tools/tcp_node.hip: 60 clocks per wave fetch from 1 to 16 distinct nodes); the scalar path costs it nothing.
-                {
-                    const int n0 = __builtin_amdgcn_readfirstlane(node);
-#if TEXIR_UNIFORM_SLOAD >= 2
-                    // ... and when the wave's rays also share their direction signs (a pass is one ~2.5 degree direction cell: they do unless the
-                    // cell straddles an axis plane), the step reads the FLOAT planes of the node (GpuNode4F) through wave-uniform offsets that pick
-                    // the near / far plane arrays: no byte -> float conversion (24 per step), no sign select, no origin / cell-size set-up.
-                    if (signs_uniform && !__any(node != n0)
-#if TEXIR_USF_MIN_LANES > 1
-                        && __popcll(__ballot(1)) >= TEXIR_USF_MIN_LANES       // (few-lane tails sit deep in the tree: their nodes miss the small scalar cache)
-#endif
-                       ) {
-                        typedef float F4 __attribute__((ext_vector_type(4)));
-                        typedef int32_t I4 __attribute__((ext_vector_type(4)));
-                        const char __attribute__((address_space(4)))* const nb =
-                            (const char __attribute__((address_space(4)))*)(reinterpret_cast<const char*>(sc.nodes4f) + ((uint32_t)n0 << 7));
-                        auto ldf = [&](uint32_t off) { return *(const F4 __attribute__((address_space(4)))*)(nb + off); };
-                        const F4 pnx = ldf(son0), pfx = ldf(son0 ^ 16u), pny = ldf(son1), pfy = ldf(son1 ^ 16u), pnz = ldf(son2), pfz = ldf(son2 ^ 16u);
-                        const I4 ch = *(const I4 __attribute__((address_space(4)))*)(nb + 96u);
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const float nxt = pnx[k] * idx - oodx, fxt = pfx[k] * idx - oodx, nyt = pny[k] * idy - oody, fyt = pfy[k] * idy - oody;
-                            const float nzt = pnz[k] * idz - oodz, fzt = pfz[k] * idz - oodz;
-                            const float tn = fmaxf(fmaxf(nxt, nyt), fmaxf(nzt, 0.f)), tf = fminf(fminf(fxt, fyt), fminf(fzt, h.t));
-                            key[k] = tn <= tf ? tn : __builtin_inff();
-                        }
-                        code[0] = ch.x; code[1] = ch.y; code[2] = ch.z; code[3] = ch.w;
-                    } else
-#else
-                    if (!__any(node != n0)) {
-                        typedef uint32_t U4 __attribute__((ext_vector_type(4)));
-                        typedef const U4 __attribute__((address_space(4)))* ConstQ;
-                        ConstQ sp = (ConstQ)(reinterpret_cast<const char*>(sc.nodes4) + ((uint32_t)n0 << 6));
-                        const U4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
-                        box4(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w);
-                        code[0] = (int)s3.x; code[1] = (int)s3.y; code[2] = (int)s3.z; code[3] = (int)s3.w;
-                    } else
-#endif
-                    {
-                        const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes4) + ((uint32_t)node << 6));
-                        const uint4 v0 = np[0], v1 = np[1], v2 = np[2], v3 = np[3];
-                        box4(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w);
-                        code[0] = (int)v3.x; code[1] = (int)v3.y; code[2] = (int)v3.z; code[3] = (int)v3.w;
-                    }
-                }
-                if (STATS) { n_nodes++; if (wave_iters && first_active()) wave_iters[0]++; }
-#else
-#if TEXIR_UNIFORM_BCAST
-                // Wave-uniform steps (the rays of a pass leave neighbouring points in nearly the same direction: they walk the upper
-                // levels together): when every participating lane holds the SAME node, one lane fetches its 64 bytes and the wave reads them
-                // back as an LDS broadcast -- 4 lane-loads instead of 4 x (participating lanes) through the L1.
-                float4 q0; uint4 q1, q2; int4 ch;
-                {
-                    const int n0 = __builtin_amdgcn_readfirstlane(node);
-                    const unsigned long long act = __ballot(1);
-                    if (!__any(node != n0) && __popcll(act) >= 8) {
-                        float4* const slot = bcast_all + 4 * (threadIdx.x >> 6);
-                        if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) {
-                            const float4* npu = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.nodes4) + ((uint32_t)n0 << 6));
-                            slot[0] = npu[0]; slot[1] = npu[1]; slot[2] = npu[2]; slot[3] = npu[3];
-                        }
-                        // (LDS operations of one wave execute in order: the reads below see the write above)
-                        q0 = slot[0];
-                        q1 = *reinterpret_cast<const uint4*>(slot + 1);
-                        q2 = *reinterpret_cast<const uint4*>(slot + 2);
-                        ch = *reinterpret_cast<const int4*>(slot + 3);
-                    } else {
-                        const float4* np = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.nodes4) + ((uint32_t)node << 6));
-                        q0 = np[0];
-                        q1 = *reinterpret_cast<const uint4*>(np + 1);
-                        q2 = *reinterpret_cast<const uint4*>(np + 2);
-                        ch = *reinterpret_cast<const int4*>(np + 3);
-                    }
-                }
-#else
-                // (uniform base + 32-bit byte offset: one VALU op of address arithmetic, saddr-form loads)
-                const float4* np = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.nodes4) + ((uint32_t)node << 6));
-                const float4 q0 = np[0];
-                const uint4 q1 = *reinterpret_cast<const uint4*>(np + 1);
-                const uint4 q2 = *reinterpret_cast<const uint4*>(np + 2);
-                const int4 ch = *reinterpret_cast<const int4*>(np + 3);
-#endif
-                if (STATS) { n_nodes++; if (wave_iters && first_active()) wave_iters[0]++; }
-                // cell size folded into the reciprocal direction; origin folded into the offset
-                const float sx = q0.w * idx, sy = __uint_as_float(q2.z) * idy, sz = __uint_as_float(q2.w) * idz;
-                const float bx = q0.x * idx - oodx, by = q0.y * idy - oody, bz = q0.z * idz - oodz;
-                float key[4]; int code[4] = {ch.x, ch.y, ch.z, ch.w};
-                // the ray's direction signs decide once per node (for all four children at a time: the bytes stay packed) which of
-                // the lo/hi planes is the entry and which the exit plane -- no per-child min/max of the two slab distances
-#if TEXIR_FAST_DEQUANT
-                // EXPERIMENT (off, -10 %).  gfx950 issues fma / mul / add / sub / and / or / xor / lshr at full rate but cvt, min/max, cmp and
-                // cndmask at ~0.6 of it; a stream that alternates the two classes overlaps them almost completely (tools/issue_rate.hip).  If
-                // this loop were bound by the slower class alone, trading each v_cvt_f32_ubyte for ~3 full-rate operations would pay: it does
-                // not -- the classes share issue, and the instruction count decides.
-                //   byte | 0x4B000000 is the float 2^23 + byte, minus 2^23 gives the byte exactly (bytes 1 / 2 are taken in place, as 256 x
-                //   byte, against a cell size divided by 256); x ^ ((x ^ y) & m) selects with a per-ray mask instead of v_cndmask.
-                // (the instructions are pinned with inline asm: left to itself hipcc re-fuses them into v_bfe_u32 / v_lshl_or_b32 / v_or_b32_sdwa /
-                // v_bitop3_b32 -- all on the slow unit)
-                const uint32_t nx_ = idx < 0.f ? q1.w : q1.x, fx_ = idx < 0.f ? q1.x : q1.w;
-                const uint32_t ny_ = idy < 0.f ? q2.x : q1.y, fy_ = idy < 0.f ? q1.y : q2.x;
-                const uint32_t nz_ = idz < 0.f ? q2.y : q1.z, fz_ = idz < 0.f ? q1.z : q2.y;
-                const float sx8 = sx * 0.00390625f, sy8 = sy * 0.00390625f, sz8 = sz * 0.00390625f;
-                auto unbias = [](uint32_t a) { float f; asm("v_or_b32 %0, 0x4b000000, %1\n\tv_add_f32 %0, 0xcb000000, %0" : "=v"(f) : "v"(a)); return f; };
-                auto b0 = [&](uint32_t p) { uint32_t a; asm("v_and_b32 %0, 0xff, %1" : "=v"(a) : "v"(p)); return unbias(a); };                             // byte 0
-                auto b1 = [&](uint32_t p) { uint32_t a; asm("v_and_b32 %0, 0xff00, %1" : "=v"(a) : "v"(p)); return unbias(a); };                           // 256 x byte 1
-                auto b2 = [&](uint32_t p) { uint32_t a; asm("v_lshrrev_b32 %0, 8, %1\n\tv_and_b32 %0, 0xff00, %0" : "=v"(a) : "v"(p)); return unbias(a); };  // 256 x byte 2
-                auto b3 = [&](uint32_t p) { uint32_t a; asm("v_lshrrev_b32 %0, 24, %1" : "=v"(a) : "v"(p)); return unbias(a); };                           // byte 3
-#define TEXIR_CHILD(k, B, SX, SY, SZ) { \
-                    const float nxt = B(nx_) * SX + bx, fxt = B(fx_) * SX + bx, nyt = B(ny_) * SY + by, fyt = B(fy_) * SY + by, nzt = B(nz_) * SZ + bz, fzt = B(fz_) * SZ + bz; \
-                    const float tn = fmaxf(fmaxf(nxt, nyt), fmaxf(nzt, 0.f)), tf = fminf(fminf(fxt, fyt), fminf(fzt, h.t)); \
-                    key[k] = tn <= tf ? tn : __builtin_inff(); }
-                TEXIR_CHILD(0, b0, sx, sy, sz) TEXIR_CHILD(1, b1, sx8, sy8, sz8) TEXIR_CHILD(2, b2, sx8, sy8, sz8) TEXIR_CHILD(3, b3, sx, sy, sz)
-#undef TEXIR_CHILD
-#else
-                const uint32_t nx_ = idx < 0.f ? q1.w : q1.x, fx_ = idx < 0.f ? q1.x : q1.w;
-                const uint32_t ny_ = idy < 0.f ? q2.x : q1.y, fy_ = idy < 0.f ? q1.y : q2.x;
-                const uint32_t nz_ = idz < 0.f ? q2.y : q1.z, fz_ = idz < 0.f ? q1.z : q2.y;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int sh = 8 * k;
-                    float nxt = (float)((nx_ >> sh) & 255u) * sx + bx, fxt = (float)((fx_ >> sh) & 255u) * sx + bx;
-                    float nyt = (float)((ny_ >> sh) & 255u) * sy + by, fyt = (float)((fy_ >> sh) & 255u) * sy + by;
-                    float nzt = (float)((nz_ >> sh) & 255u) * sz + bz, fzt = (float)((fz_ >> sh) & 255u) * sz + bz;
-                    float tn = fmaxf(fmaxf(nxt, nyt), fmaxf(nzt, 0.f));
-                    float tf = fminf(fminf(fxt, fyt), fminf(fzt, h.t));
-                    // (unused slots: inverted box, and if ever entered they lead to a degenerate dummy triangle -- no test needed here)
-                    key[k] = tn <= tf ? tn : __builtin_inff();
-                }
-#endif
-#endif
-#endif
-                // sort the four (key, code) pairs ascending: 5-comparator network
-#define TEXIR_CSWAP(a, b) { bool s_ = key[b] < key[a]; float ka = s_ ? key[b] : key[a], kb = s_ ? key[a] : key[b]; int ca = s_ ? code[b] : code[a], cb = s_ ? code[a] : code[b]; key[a] = ka; key[b] = kb; code[a] = ca; code[b] = cb; }
-#if TEXIR_PSORT3
-                // (A/B) nearest child first, the other three pushed in slot order: 3 instead of 5 comparators (the culling pop keeps it exact)
-                TEXIR_CSWAP(0, 1) TEXIR_CSWAP(2, 3) TEXIR_CSWAP(0, 2)
-#else
-                TEXIR_CSWAP(0, 1) TEXIR_CSWAP(2, 3) TEXIR_CSWAP(0, 2) TEXIR_CSWAP(1, 3) TEXIR_CSWAP(1, 2)
-#endif
-#undef TEXIR_CSWAP
-                const float inf = __builtin_inff();
-                if (!__any(top + 3 * kBlock > lim)) {
-                    // common case (one wave-uniform test per node): the whole update stays inside the LDS part of the stack
-                    if (key[3] < inf) { *top = make(code[3], key[3]); top += kBlock; }
-                    if (key[2] < inf) { *top = make(code[2], key[2]); top += kBlock; }
-                    if (key[1] < inf) { *top = make(code[1], key[1]); top += kBlock; }
-                    if (key[0] < inf) node = code[0];
-                    else if constexpr (CULL) {
-                        node = kSentinel;
-                        while (top != base) { top -= kBlock; const Entry e = *top; if (__int_as_float(e.y) < h.t) { node = e.x; break; } }
-                    }
-                    else if (top != base) { top -= kBlock; node = *reinterpret_cast<const int*>(top); }
-                    else node = kSentinel;
-                } else {
-                    if (key[3] < inf) push(code[3], key[3]);
-                    if (key[2] < inf) push(code[2], key[2]);
-                    if (key[1] < inf) push(code[1], key[1]);
-                    node = key[0] < inf ? code[0] : pop();
-                }
-            }
-        } else {
-        while (node >= 0 && node != kSentinel) {
-                const float4* np = sc.nodes + 4 * (size_t)node;
-                float4 n0 = np[0], n1 = np[1], n2 = np[2];
-                int2 ch = *reinterpret_cast<const int2*>(np + 3);
-                if (STATS) n_nodes++;
-                float c0lox = n0.x * idx - oodx, c0hix = n0.y * idx - oodx, c0loy = n0.z * idy - oody, c0hiy = n0.w * idy - oody;
-                float c0loz = n2.x * idz - oodz, c0hiz = n2.y * idz - oodz;
-                float c1lox = n1.x * idx - oodx, c1hix = n1.y * idx - oodx, c1loy = n1.z * idy - oody, c1hiy = n1.w * idy - oody;
-                float c1loz = n2.z * idz - oodz, c1hiz = n2.w * idz - oodz;
-                float t0n = fmaxf(fmaxf(fminf(c0lox, c0hix), fminf(c0loy, c0hiy)), fmaxf(fminf(c0loz, c0hiz), 0.f));
-                float t0f = fminf(fminf(fmaxf(c0lox, c0hix), fmaxf(c0loy, c0hiy)), fminf(fmaxf(c0loz, c0hiz), h.t));
-                float t1n = fmaxf(fmaxf(fminf(c1lox, c1hix), fminf(c1loy, c1hiy)), fmaxf(fminf(c1loz, c1hiz), 0.f));
-                float t1f = fminf(fminf(fmaxf(c1lox, c1hix), fmaxf(c1loy, c1hiy)), fminf(fmaxf(c1loz, c1hiz), h.t));
-                bool h0 = t0n <= t0f, h1 = t1n <= t1f;
-                if (h0 && h1) {
-                    bool swp = t1n < t0n;
-                    int nearc = swp ? ch.y : ch.x, farc = swp ? ch.x : ch.y;
-                    push(farc, swp ? t0n : t1n);
-                    node = nearc;
-                } else if (h0) node = ch.x;
-                else if (h1) node = ch.y;
-                else node = pop();
-            }
-}
-        while (node < 0) {
-            const uint32_t code = ~(uint32_t)node;
-            if constexpr (!CULL) node = pop();           // (early: the LDS read overlaps the triangle loads)
-            int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
-            for (int i = first; i < first + cnt; i++) {
-                const float4* tp = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.tris) + (uint32_t)i * (uint32_t)(16 * kTriQuads));
-                float4 v0 = tp[0], e1 = tp[1], e2 = tp[2];
-                if (STATS) { n_tris++; if (wave_iters && first_active()) wave_iters[1]++; }
-#if TEXIR_TRI_WATERTIGHT
-                // (tp[1], tp[2] hold the vertices v1, v2 here, not edges.)  Shear the three vertices into ray space ...
-                const float a0 = v0.x - ox, a1 = v0.y - oy, a2 = v0.z - oz;
-                const float b0 = e1.x - ox, b1 = e1.y - oy, b2 = e1.z - oz;
-                const float c0 = e2.x - ox, c1 = e2.y - oy, c2 = e2.z - oz;
-                const float Ax = __builtin_fmaf(a2, r.mx[2], __builtin_fmaf(a1, r.mx[1], a0 * r.mx[0])), Ay = __builtin_fmaf(a2, r.my[2], __builtin_fmaf(a1, r.my[1], a0 * r.my[0]));
-                const float Bx = __builtin_fmaf(b2, r.mx[2], __builtin_fmaf(b1, r.mx[1], b0 * r.mx[0])), By = __builtin_fmaf(b2, r.my[2], __builtin_fmaf(b1, r.my[1], b0 * r.my[0]));
-                const float Cx = __builtin_fmaf(c2, r.mx[2], __builtin_fmaf(c1, r.mx[1], c0 * r.mx[0])), Cy = __builtin_fmaf(c2, r.my[2], __builtin_fmaf(c1, r.my[1], c0 * r.my[0]));
-                // ... 2D edge functions with exact signs (device_common.h edge2_exact): U, V, W = unnormalised weights of v0, v1, v2
-                const float U = edge2_exact(Bx, By, Cx, Cy), V = edge2_exact(Cx, Cy, Ax, Ay), W = edge2_exact(Ax, Ay, Bx, By);
-                const float mn = fminf(fminf(U, V), W), mx = fmaxf(fmaxf(U, V), W);
-                const float det = U + V + W;
-                const float Az = __builtin_fmaf(a2, r.mz[2], __builtin_fmaf(a1, r.mz[1], a0 * r.mz[0]));
-                const float Bz = __builtin_fmaf(b2, r.mz[2], __builtin_fmaf(b1, r.mz[1], b0 * r.mz[0]));
-                const float Cz = __builtin_fmaf(c2, r.mz[2], __builtin_fmaf(c1, r.mz[1], c0 * r.mz[0]));
-                const float inv = __builtin_amdgcn_rcpf(det);
-                const float t = (U * Az + V * Bz + W * Cz) * inv;
-                const float u = V * inv, v = W * inv;
-                // inside <=> no two of the signs differ (zeros -- the origin exactly on an edge or vertex -- count as inside for BOTH neighbours)
-                const bool ok = !((mn < 0.f) & (mx > 0.f)) & (det != 0.f) & (t > 0.f) & (t < h.t);
-#else
-                // Moeller-Trumbore, same operation order as the oracle
-                float px = dy * e2.z - dz * e2.y, py = dz * e2.x - dx * e2.z, pz = dx * e2.y - dy * e2.x;
-                float det = e1.x * px + e1.y * py + e1.z * pz;
-                float inv = __builtin_amdgcn_rcpf(det);
-                float tx = ox - v0.x, ty = oy - v0.y, tz = oz - v0.z;
-                float u = (tx * px + ty * py + tz * pz) * inv;
-                float qx = ty * e1.z - tz * e1.y, qy = tz * e1.x - tx * e1.z, qz = tx * e1.y - ty * e1.x;
-                float v = (dx * qx + dy * qy + dz * qz) * inv;
-                float t = (e2.x * qx + e2.y * qy + e2.z * qz) * inv;
-                bool ok = (det != 0.f) & (u >= 0.f) & (u <= 1.f) & (v >= 0.f) & (u + v <= 1.f) & (t > 0.f) & (t < h.t);
-#endif
-                if (ok) { h.t = t; h.u = u; h.v = v; h.slot = i; }
-            }
-            if constexpr (CULL) node = pop();            // after the tests: the pop drops what this leaf's hit has just put out of reach
-        }
-    }
-    r.h = h; r.sp = (int)(top - base) / kBlock; r.node = node;
-}
 
-// closest hit of one ray per lane, run to completion
-template <bool STATS, int LSTK = kLdsStack, int WIDTH = 2, bool CULL = false>
-__device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float oy, float oz, float dx, float dy, float dz,
-                                             uint32_t& n_nodes, uint32_t& n_tris, uint32_t* wave_iters = nullptr)
-{
-    RayState r;
-    ray_begin(r, ox, oy, oz, dx, dy, dz);
-    typename StackEntry<CULL>::type ovf[kStackCap - LSTK];
-    traverse<STATS, LSTK, WIDTH, CULL>(sc, r, ovf, ox, oy, oz, n_nodes, n_tris, wave_iters, NeverLeave());
-    return r.h;
+    // ---- one node step of the 4-wide tree: four box tests, sort, push the far children, descend into the nearest ----
+    auto node_step4 = [&]() __attribute__((always_inline)) {
+        float key[4]; int code[4];
+        // The box tests on per-lane node words (vector loads of the 64-byte quantised node): the ray's direction signs decide once
+        // per node (for all four children at a time: the bytes stay packed) which of the lo/hi planes is the entry and which the exit
+        // plane; the cell size is folded into the reciprocal direction, the node origin into the offset.
+        auto box4 = [&](uint32_t q0x, uint32_t q0y, uint32_t q0z, uint32_t q0w, uint32_t q1x, uint32_t q1y, uint32_t q1z, uint32_t q1w,
+                        uint32_t q2x, uint32_t q2y, uint32_t q2z, uint32_t q2w) __attribute__((always_inline)) {
+            const float sx = __uint_as_float(q0w) * idx, sy = __uint_as_float(q2z) * idy, sz = __uint_as_float(q2w) * idz;
+            const float bx = __uint_as_float(q0x) * idx - oodx, by = __uint_as_float(q0y) * idy - oody, bz = __uint_as_float(q0z) * idz - oodz;
+            const uint32_t nx_ = idx < 0.f ? q1w : q1x, fx_ = idx < 0.f ? q1x : q1w;
+            const uint32_t ny_ = idy < 0.f ? q2x : q1y, fy_ = idy < 0.f ? q1y : q2x;
+            const uint32_t nz_ = idz < 0.f ? q2y : q1z, fz_ = idz < 0.f ? q1z : q2y;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int sh = 8 * k;
+                float nxt = (float)((nx_ >> sh) & 255u) * sx + bx, fxt = (float)((fx_ >> sh) & 255u) * sx + bx;
+                float nyt = (float)((ny_ >> sh) & 255u) * sy + by, fyt = (float)((fy_ >> sh) & 255u) * sy + by;
+                float nzt = (float)((nz_ >> sh) & 255u) * sz + bz, fzt = (float)((fz_ >> sh) & 255u) * sz + bz;
+                float tn = fmaxf(fmaxf(nxt, nyt), fmaxf(nzt, 0.f));
+                float tf = fminf(fminf(fxt, fyt), fminf(fzt, h.t));
+                // (unused slots: inverted box, and if ever entered they lead to a degenerate dummy triangle -- no test needed here)
+                key[k] = tn <= tf ? tn : __builtin_inff();
+            }
+        };
+        // Wave-uniform steps (the rays of a pass leave neighbouring points in nearly the same direction and walk the upper levels
+        // together: 45 % of the wave-level node steps on c4): a vector fetch costs the L1 64 lanes x 64 bytes whether or not the lanes
+        // agree (tools/tcp_node.hip: 60 clocks per wave fetch from 1 to 16 distinct nodes); the scalar path costs it nothing.  When the
+        // wave's rays also share their direction signs (a pass is one ~2.5 degree direction cell: they do unless the cell straddles an
+        // axis plane), the step reads the FLOAT planes of the node (GpuNode4F) through wave-uniform offsets that pick the near / far
+        // plane arrays: no byte -> float conversion (24 per step), no sign select, no origin / cell-size set-up.
+        const int n0 = __builtin_amdgcn_readfirstlane(node);
+        if (signs_uniform && !__any(node != n0)) {
+            typedef float F4 __attribute__((ext_vector_type(4)));
+            typedef int32_t I4 __attribute__((ext_vector_type(4)));
+            const char __attribute__((address_space(4)))* const nb =
+                (const char __attribute__((address_space(4)))*)(reinterpret_cast<const char*>(sc.nodes4f) + ((uint32_t)n0 << 7));
+            auto ldf = [&](uint32_t off) { return *(const F4 __attribute__((address_space(4)))*)(nb + off); };
+            const F4 pnx = ldf(son0), pfx = ldf(son0 ^ 16u), pny = ldf(son1), pfy = ldf(son1 ^ 16u), pnz = ldf(son2), pfz = ldf(son2 ^ 16u);
+            const I4 ch = *(const I4 __attribute__((address_space(4)))*)(nb + 96u);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float nxt = pnx[k] * idx - oodx, fxt = pfx[k] * idx - oodx, nyt = pny[k] * idy - oody, fyt = pfy[k] * idy - oody;
+                const float nzt = pnz[k] * idz - oodz, fzt = pfz[k] * idz - oodz;
+                const float tn = fmaxf(fmaxf(nxt, nyt), fmaxf(nzt, 0.f)), tf = fminf(fminf(fxt, fyt), fminf(fzt, h.t));
+                key[k] = tn <= tf ? tn : __builtin_inff();
+            }
+            code[0] = ch.x; code[1] = ch.y; code[2] = ch.z; code[3] = ch.w;
+        } else {
+            // (uniform base + 32-bit byte offset: one VALU op of address arithmetic, saddr-form loads)
+            const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes4) + ((uint32_t)node << 6));
+            const uint4 v0 = np[0], v1 = np[1], v2 = np[2], v3 = np[3];
+            box4(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w);
+            code[0] = (int)v3.x; code[1] = (int)v3.y; code[2] = (int)v3.z; code[3] = (int)v3.w;
+        }
+        if (STATS) { n_nodes++; if (wave_iters && first_active()) wave_iters[0]++; }
+        // sort the four (key, code) pairs ascending: 5-comparator network
+#define TEXIR_CSWAP(a, b) { bool s_ = key[b] < key[a]; float ka = s_ ? key[b] : key[a], kb = s_ ? key[a] : key[b]; int ca = s_ ? code[b] : code[a], cb = s_ ? code[a] : code[b]; key[a] = ka; key[b] = kb; code[a] = ca; code[b] = cb; }
+        TEXIR_CSWAP(0, 1) TEXIR_CSWAP(2, 3) TEXIR_CSWAP(0, 2) TEXIR_CSWAP(1, 3) TEXIR_CSWAP(1, 2)
+#undef TEXIR_CSWAP
+        const float inf = __builtin_inff();
+        if (!__any(top + 3 * kBlock > lim)) {
+            // common case (one wave-uniform test per node): the whole update stays inside the LDS part of the stack
+            if (key[3] < inf) { *top = make(code[3], key[3]); top += kBlock; }
+            if (key[2] < inf) { *top = make(code[2], key[2]); top += kBlock; }
+            if (key[1] < inf) { *top = make(code[1], key[1]); top += kBlock; }
+            if (key[0] < inf) node = code[0];
+            else if constexpr (CULL) {
+                node = kSentinel;
+                while (top != base) { top -= kBlock; const Entry e = *top; if (__int_as_float(e.y) < h.t) { node = e.x; break; } }
+            }
+            else if (top != base) { top -= kBlock; node = *reinterpret_cast<const int*>(top); }
+            else node = kSentinel;
+        } else {
+            if (key[3] < inf) push(code[3], key[3]);
+            if (key[2] < inf) push(code[2], key[2]);
+            if (key[1] < inf) push(code[1], key[1]);
+            node = key[0] < inf ? code[0] : pop();
+        }
+    };
+
+    // ---- one node step of the binary tree (scenes too deep for the wide tree's stack bound, TEXIR_BVH_WIDTH=2) ----
+    auto node_step2 = [&]() __attribute__((always_inline)) {
+        const float4* np = sc.nodes + 4 * (size_t)node;
+        float4 n0 = np[0], n1 = np[1], n2 = np[2];
+        int2 ch = *reinterpret_cast<const int2*>(np + 3);
+        if (STATS) { n_nodes++; if (wave_iters && first_active()) wave_iters[0]++; }
+        float c0lox = n0.x * idx - oodx, c0hix = n0.y * idx - oodx, c0loy = n0.z * idy - oody, c0hiy = n0.w * idy - oody;
+        float c0loz = n2.x * idz - oodz, c0hiz = n2.y * idz - oodz;
+        float c1lox = n1.x * idx - oodx, c1hix = n1.y * idx - oodx, c1loy = n1.z * idy - oody, c1hiy = n1.w * idy - oody;
+        float c1loz = n2.z * idz - oodz, c1hiz = n2.w * idz - oodz;
+        float t0n = fmaxf(fmaxf(fminf(c0lox, c0hix), fminf(c0loy, c0hiy)), fmaxf(fminf(c0loz, c0hiz), 0.f));
+        float t0f = fminf(fminf(fmaxf(c0lox, c0hix), fmaxf(c0loy, c0hiy)), fminf(fmaxf(c0loz, c0hiz), h.t));
+        float t1n = fmaxf(fmaxf(fminf(c1lox, c1hix), fminf(c1loy, c1hiy)), fmaxf(fminf(c1loz, c1hiz), 0.f));
+        float t1f = fminf(fminf(fmaxf(c1lox, c1hix), fmaxf(c1loy, c1hiy)), fminf(fmaxf(c1loz, c1hiz), h.t));
+        bool h0 = t0n <= t0f, h1 = t1n <= t1f;
+        if (h0 && h1) {
+            bool swp = t1n < t0n;
+            int nearc = swp ? ch.y : ch.x, farc = swp ? ch.x : ch.y;
+            push(farc, swp ? t0n : t1n);
+            node = nearc;
+        } else if (h0) node = ch.x;
+        else if (h1) node = ch.y;
+        else node = pop();
+    };
+
+    // ---- one leaf: test its triangles, then pop (the pop drops what this leaf's hit has just put out of reach) ----
+    auto leaf_step = [&]() __attribute__((always_inline)) {
+        const uint32_t code = ~(uint32_t)node;
+        const int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
+        for (int i = first; i < first + cnt; i++) {
+            const float4* tp = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.tris) + (uint32_t)i * (uint32_t)(16 * kTriQuads));
+            float4 v0 = tp[0], e1 = tp[1], e2 = tp[2];
+            if (STATS) { n_tris++; if (wave_iters && first_active()) wave_iters[1]++; }
+#if TEXIR_TRI_WATERTIGHT
+            // (tp[1], tp[2] hold the vertices v1, v2 here, not edges.)  Shear the three vertices into ray space ...
+            const float a0 = v0.x - ox, a1 = v0.y - oy, a2 = v0.z - oz;
+            const float b0 = e1.x - ox, b1 = e1.y - oy, b2 = e1.z - oz;
+            const float c0 = e2.x - ox, c1 = e2.y - oy, c2 = e2.z - oz;
+            const float Ax = __builtin_fmaf(a2, mx[2], __builtin_fmaf(a1, mx[1], a0 * mx[0])), Ay = __builtin_fmaf(a2, my[2], __builtin_fmaf(a1, my[1], a0 * my[0]));
+            const float Bx = __builtin_fmaf(b2, mx[2], __builtin_fmaf(b1, mx[1], b0 * mx[0])), By = __builtin_fmaf(b2, my[2], __builtin_fmaf(b1, my[1], b0 * my[0]));
+            const float Cx = __builtin_fmaf(c2, mx[2], __builtin_fmaf(c1, mx[1], c0 * mx[0])), Cy = __builtin_fmaf(c2, my[2], __builtin_fmaf(c1, my[1], c0 * my[0]));
+            // ... 2D edge functions with exact signs (edge2_exact): U, V, W = unnormalised weights of v0, v1, v2
+            const float U = edge2_exact(Bx, By, Cx, Cy), V = edge2_exact(Cx, Cy, Ax, Ay), W = edge2_exact(Ax, Ay, Bx, By);
+            const float mn = fminf(fminf(U, V), W), mxw = fmaxf(fmaxf(U, V), W);
+            const float det = U + V + W;
+            const float Az = __builtin_fmaf(a2, mz[2], __builtin_fmaf(a1, mz[1], a0 * mz[0]));
+            const float Bz = __builtin_fmaf(b2, mz[2], __builtin_fmaf(b1, mz[1], b0 * mz[0]));
+            const float Cz = __builtin_fmaf(c2, mz[2], __builtin_fmaf(c1, mz[1], c0 * mz[0]));
+            const float inv = __builtin_amdgcn_rcpf(det);
+            const float t = (U * Az + V * Bz + W * Cz) * inv;
+            const float u = V * inv, v = W * inv;
+            // inside <=> no two of the signs differ (zeros -- the origin exactly on an edge or vertex -- count as inside for BOTH neighbours)
+            const bool ok = !((mn < 0.f) & (mxw > 0.f)) & (det != 0.f) & (t > 0.f) & (t < h.t);
+#else
+            // Moeller-Trumbore, same operation order as the oracle
+            float px = dy * e2.z - dz * e2.y, py = dz * e2.x - dx * e2.z, pz = dx * e2.y - dy * e2.x;
+            float det = e1.x * px + e1.y * py + e1.z * pz;
+            float inv = __builtin_amdgcn_rcpf(det);
+            float tx = ox - v0.x, ty = oy - v0.y, tz = oz - v0.z;
+            float u = (tx * px + ty * py + tz * pz) * inv;
+            float qx = ty * e1.z - tz * e1.y, qy = tz * e1.x - tx * e1.z, qz = tx * e1.y - ty * e1.x;
+            float v = (dx * qx + dy * qy + dz * qz) * inv;
+            float t = (e2.x * qx + e2.y * qy + e2.z * qz) * inv;
+            bool ok = (det != 0.f) & (u >= 0.f) & (u <= 1.f) & (v >= 0.f) & (u + v <= 1.f) & (t > 0.f) & (t < h.t);
+#endif
+            if (ok) { h.t = t; h.u = u; h.v = v; h.slot = i; }
+        }
+        node = pop();
+    };
+    auto node_step = [&]() __attribute__((always_inline)) { if constexpr (WIDTH == 4) node_step4(); else node_step2(); };
+
+#if TEXIR_SCHED
+    for (;;) {
+        const bool at_node = (uint32_t)node < (uint32_t)kSentinel;        // an inner node (>= 0 and not the sentinel)
+        const unsigned long long m_node = __ballot(at_node), m_leaf = __ballot(node < 0);
+        if (!(m_node | m_leaf)) break;
+        if (kSchedNodeWeight * __popcll(m_node) >= __popcll(m_leaf)) { if (at_node) node_step(); }
+        else if (node < 0) leaf_step();
+    }
+#else
+    while (node != kSentinel) {
+        while (node >= 0 && node != kSentinel) node_step();
+        while (node < 0) leaf_step();
+    }
+#endif
+    return h;
 }
 
 __device__ __forceinline__ float wave_sum(float x)

@@ -7,8 +7,9 @@
 
 namespace texir {
 hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, const float* shift, const int32_t* ids, int64_t n_ids,
-                      int N, int mode, float* irr, unsigned long long* stats, unsigned long long* work /*dev: chunk counter of this launch*/,
+                      int N, int mode, float* irr, unsigned long long* stats, unsigned long long* work /*dev: 8 * kWorkStride chunk counters of this launch*/,
                       hipStream_t st);
+constexpr int kWorkStride = 16;              // unsigned long longs between the per-XCD chunk counters of one launch (a 128-byte line each)
 struct IrtPlan { int per_wave, log2parts, width; char name[64]; };
 IrtPlan irt_plan(const SceneDev& sc, int64_t n_ids, int N);      // the kernel form launch_irt picks for this call
 size_t tex_retile_bytes(int Ht, int Wt, int layout, int* tiles_x, int* tiles_y);
@@ -42,7 +43,8 @@ hipError_t launch_tex_gather_bwd(float* d_tex, float* grad_rest, int H, int W, i
                                  int fold_to_level, hipStream_t st);
 hipError_t launch_adam_tex(float* p, const float* g /*nullable*/, const uint32_t* l0_mask /*nullable*/, const float* g1, const float* g2 /*nullable*/, float* m, float* v, float* mip1 /*nullable*/,
                            int H, int W, int C, float lr,
-                           float beta1, float beta2, float eps, int step, float lo, float hi, hipStream_t st);
+                           float beta1, float beta2, float eps, int step, float lo, float hi, const float* hyper /*dev, nullable: step size + bias correction*/, hipStream_t st);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step,
-                       float lo, float hi, hipStream_t st);
+                       float lo, float hi, const float* hyper /*dev, nullable*/, hipStream_t st);
+hipError_t launch_adam_tick(double* state, float* hyper, int n, unsigned long long mask, hipStream_t st);
 }  // namespace texir

@@ -59,6 +59,13 @@ constexpr int kGroupLstk = TEXIR_GROUP_LSTK;
 #endif
 constexpr int kGroupWaves = TEXIR_GROUP_WAVES;
 constexpr int kLstk = kCull ? kLdsStack / 2 : kLdsStack;   // the other tracing kernels: 24 KiB of stack per block either way
+// chunk hand-out of irt_group_kernel (see there): 0 = one counter, parts = elevation rings (round 2)
+#ifndef TEXIR_XCD_SCHED
+#define TEXIR_XCD_SCHED 1
+#endif
+#ifndef TEXIR_PART_WEDGE
+#define TEXIR_PART_WEDGE 1
+#endif
 
 // One texel per wave: the 64 lanes trace 64 samples of the texel per pass (any N, binary or 4-wide tree).  Kept as the
 // form for short texel lists (a 1024-point NIrF batch), for binary-tree scenes, and TEXIR_IRT_TEXELS_PER_WAVE=1.
@@ -156,16 +163,36 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
     // A chunk = GRP texels x (all passes / 2^log2parts).  With parts > 1 the raw partial sums go to partial[part][k][3] and
     // irt_combine_kernel adds them in part order: the result depends on N only, never on how the texel list is cut or scheduled.
     const int part_cells = n_cells >> log2parts;
+    // Which cells a part holds (TEXIR_PART_WEDGE = 1): the cells are walked azimuth-major (all elevations of one azimuth bin, then the next
+    // bin), so a part is an azimuthal WEDGE of the hemisphere (N = 2048: 2 of the 64 azimuth bins = 5.6 degrees, all 32 elevations) instead of a
+    // full ring of one elevation.  The rays of a wedge leave a surface patch towards one side of the room: what they touch deep in the tree,
+    // their triangles and their radiance-texture lines are shared by the chunks of neighbouring wedges -- which the hand-out below keeps on one XCD.
+    const int cell_bits = log2N < 0 ? 0 : log2N - LOG2M, bphi = (cell_bits + 1) >> 1, bth = cell_bits - bphi;
+    // XCD-aware hand-out (TEXIR_XCD_SCHED = 1): the 8 XCDs have private 4 MiB L2s; with ONE chunk counter consecutive chunks -- the 32 parts of the
+    // same 64 texels -- go to whichever waves ask next, so every L2 sees every direction of every region.  Here each XCD owns parts / 8
+    // neighbouring wedges (a 45-degree sector at N = 2048) of ALL texel groups and pulls them from its own counter (its own 128-byte line: 8
+    // heads also dequeue faster than one, MI355X_MICROARCH.md "dequeue"); an XCD whose sector has run dry steals from the next one's.  HW_REG_XCC_ID
+    // is a speed hint only: any wave may execute any chunk, the partial sums are indexed by (part, texel).
+    const int n_own = (TEXIR_XCD_SCHED && log2parts >= 3) ? 8 : 1;
+    const int log2ppo = log2parts - (n_own == 8 ? 3 : 0);                        // parts per owner
+    const int64_t n_groups = (n_ids + GRP - 1) / GRP;
+    int owner = n_own == 8 ? (__builtin_amdgcn_s_getreg(6164 /* hwreg(HW_REG_XCC_ID, 0, 4) */) & 7) : 0;
+    int dry = 0;
     for (;;) {
-        // persistent waves pull chunks from a global counter: a chunk is milliseconds of work, so a static round-robin would
+        // persistent waves pull chunks from a counter: a chunk is milliseconds of work, so a static round-robin would
         // leave the slowest wave's surplus (the sum of its chunk-time deviations) as an idle tail
         unsigned long long chunk = 0;
-        if (lane == 0) chunk = atomicAdd(work, 1ull);
+        if (lane == 0) chunk = atomicAdd(work + owner * kWorkStride, 1ull);
         chunk = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(chunk >> 32)) << 32) |
                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)chunk);
-        const int part = (int)(chunk & ((1ull << log2parts) - 1ull));
-        const int64_t k0 = (int64_t)(chunk >> log2parts) * GRP;
-        if (k0 >= n_ids) break;
+        if ((int64_t)(chunk >> log2ppo) >= n_groups) {
+            if (++dry >= n_own) break;                                           // every owner's queue is empty
+            owner = (owner + 1) & (n_own - 1);
+            continue;
+        }
+        dry = 0;
+        const int part = (owner << log2ppo) | (int)(chunk & ((1ull << log2ppo) - 1ull));
+        const int64_t k0 = (int64_t)(chunk >> log2ppo) * GRP;
         const int64_t k = k0 + grp;
         const bool live = k < n_ids;
         const int64_t t = live ? (ids ? (int64_t)ids[k] : k) : 0;
@@ -174,7 +201,8 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
         const float sh0 = shift[2 * t], sh1 = shift[2 * t + 1];
         const Frame f = make_frame(nx, ny, nz);
         float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
-        for (int J = part * part_cells; J < (part + 1) * part_cells; J++) {
+        for (int Lc = part * part_cells; Lc < (part + 1) * part_cells; Lc++) {
+            const int J = (TEXIR_PART_WEDGE && log2N >= 0) ? (((Lc & ((1 << bth) - 1)) << bphi) | (Lc >> bth)) : Lc;
             if (live) {
                 // (N not a power of two: only the one-sample-per-pass form is launched, in natural sample order)
                 const uint32_t i = log2N < 0 ? (uint32_t)J : sample_index_m(cell_to_pass_m((uint32_t)J, sh0, sh1, log2N, LOG2M), (uint32_t)sub, log2N, LOG2M);
@@ -534,7 +562,7 @@ hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, co
                       int N, int mode, float* irr, unsigned long long* stats, unsigned long long* work, hipStream_t st)
 {
     if (n_ids <= 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(work, 0, sizeof(unsigned long long), st);       // chunk counter of this launch
+    hipError_t e = hipMemsetAsync(work, 0, sizeof(unsigned long long) * 8 * kWorkStride, st);       // the chunk counters of this launch (one per XCD)
     if (e != hipSuccess) return e;
     const bool pow2 = (N & (N - 1)) == 0;
     const int l2 = ilog2_exact(N);

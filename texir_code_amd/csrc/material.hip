@@ -643,8 +643,9 @@ __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& 
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n, float beta1, float beta2, float eps, float step_size, float bc2_sqrt,
-                                                   float lo, float hi)
+                                                   float lo, float hi, const float* __restrict__ hyp)
 {
+    if (hyp) { step_size = hyp[0]; bc2_sqrt = hyp[1]; }          // device-resident step size / bias correction (adam_tick_kernel): hipGraph replays
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         adam_update(p[i], g[i], m[i], v[i], beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
     }
@@ -663,8 +664,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 template <int C>
 __global__ __launch_bounds__(256) void adam_tex_kernel(float* __restrict__ p, const float* __restrict__ g, const uint32_t* __restrict__ l0_mask,
                                                        const float* __restrict__ g1, const float* __restrict__ g2, float* __restrict__ m, float* __restrict__ v, float* __restrict__ mip1,
-                                                       int H, int W, float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float lo, float hi)
+                                                       int H, int W, float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float lo, float hi, const float* __restrict__ hyp)
 {
+    if (hyp) { step_size = hyp[0]; bc2_sqrt = hyp[1]; }
     // one thread per (2x2 block column, channel): t = bx * C + ch.  Its level-1 element and its g1 element sit at index t of the
     // half-resolution row (perfectly coalesced); its four texture elements are rows 2by / 2by+1 at bx * 2C + ch and + C (the two
     // loads of a row together cover the row densely, every 128-byte line is fetched once).
@@ -706,8 +708,9 @@ __global__ __launch_bounds__(256) void adam_tex_kernel(float* __restrict__ p, co
 template <int C>
 __global__ __launch_bounds__(256) void adam_tex_vec_kernel(float* __restrict__ p, const float* __restrict__ g, const uint32_t* __restrict__ l0_mask,
                                                            const float* __restrict__ g1, const float* __restrict__ g2, float* __restrict__ m, float* __restrict__ v, float* __restrict__ mip1,
-                                                           int H, int W, float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float lo, float hi)
+                                                           int H, int W, float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float lo, float hi, const float* __restrict__ hyp)
 {
+    if (hyp) { step_size = hyp[0]; bc2_sqrt = hyp[1]; }
     constexpr int EPB = (1024 / (2 * C)) * (2 * C);
     __shared__ float g1s[EPB / 2];
     __shared__ float ps[2][EPB];
@@ -765,36 +768,66 @@ __global__ __launch_bounds__(256) void adam_tex_vec_kernel(float* __restrict__ p
 }
 
 hipError_t launch_adam_tex(float* p, const float* g, const uint32_t* l0_mask, const float* g1, const float* g2, float* m, float* v, float* mip1, int H, int W, int C,
-                           float lr, float beta1, float beta2, float eps, int step, float lo, float hi, hipStream_t st)
+                           float lr, float beta1, float beta2, float eps, int step, float lo, float hi, const float* hyp, hipStream_t st)
 {
-    double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    float step_size = (float)((double)lr / bc1);
-    float bc2_sqrt = (float)sqrt(bc2);
+    // hyp == nullptr: step size and bias correction from (lr, step) here on the host; else the kernels read them from device memory
+    float step_size = 0.f, bc2_sqrt = 1.f;
+    if (!hyp) {
+        double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+        step_size = (float)((double)lr / bc1);
+        bc2_sqrt = (float)sqrt(bc2);
+    }
     if ((W * C) % 4 == 0 && !getenv("TEXIR_ADAM_SCALAR")) {
         const int epb = (1024 / (2 * C)) * (2 * C);
         dim3 gridv((W * C + epb - 1) / epb, (H >> 1) > 2048 ? 2048 : (H >> 1));
-        if (C == 1) hipLaunchKernelGGL(adam_tex_vec_kernel<1>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
-        else if (C == 2) hipLaunchKernelGGL(adam_tex_vec_kernel<2>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
-        else if (C == 3) hipLaunchKernelGGL(adam_tex_vec_kernel<3>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
-        else hipLaunchKernelGGL(adam_tex_vec_kernel<4>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+        if (C == 1) hipLaunchKernelGGL(adam_tex_vec_kernel<1>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp);
+        else if (C == 2) hipLaunchKernelGGL(adam_tex_vec_kernel<2>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp);
+        else if (C == 3) hipLaunchKernelGGL(adam_tex_vec_kernel<3>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp);
+        else hipLaunchKernelGGL(adam_tex_vec_kernel<4>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp);
         return hipGetLastError();
     }
     dim3 grid(((W >> 1) * C + 255) / 256, (H >> 1) > 4096 ? 4096 : (H >> 1));
-    if (C == 1) hipLaunchKernelGGL(adam_tex_kernel<1>, grid, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
-    else if (C == 2) hipLaunchKernelGGL(adam_tex_kernel<2>, grid, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
-    else if (C == 3) hipLaunchKernelGGL(adam_tex_kernel<3>, grid, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
-    else hipLaunchKernelGGL(adam_tex_kernel<4>, grid, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+    if (C == 1) hipLaunchKernelGGL(adam_tex_kernel<1>, grid, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp);
+    else if (C == 2) hipLaunchKernelGGL(adam_tex_kernel<2>, grid, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp);
+    else if (C == 3) hipLaunchKernelGGL(adam_tex_kernel<3>, grid, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp);
+    else hipLaunchKernelGGL(adam_tex_kernel<4>, grid, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp);
+    return hipGetLastError();
+}
+
+// One thread per parameter record: advances the step count and derives the step size / bias correction the Adam kernels read, in
+// double precision with the same expressions the host path uses (torch.optim.Adam's single-tensor path): a captured hipGraph that
+// contains this launch followed by the Adam kernels needs no host argument per replay.
+//   state [n][4] doubles: step count, lr, beta1, beta2      hyper [n][2] floats: lr / (1 - beta1^step), sqrt(1 - beta2^step)
+__global__ void adam_tick_kernel(double* __restrict__ state, float* __restrict__ hyper, int n, unsigned long long mask)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !((mask >> i) & 1ull)) return;
+    double* s = state + 4 * i;
+    const double step = s[0] + 1.0;
+    s[0] = step;
+    const double bc1 = 1.0 - pow(s[2], step), bc2 = 1.0 - pow(s[3], step);
+    hyper[2 * i] = (float)(s[1] / bc1);
+    hyper[2 * i + 1] = (float)sqrt(bc2);
+}
+
+hipError_t launch_adam_tick(double* state, float* hyper, int n, unsigned long long mask, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, st, state, hyper, n, mask);
     return hipGetLastError();
 }
 
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step,
-                       float lo, float hi, hipStream_t st)
+                       float lo, float hi, const float* hyp, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
-    double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    float step_size = (float)((double)lr / bc1);
-    float bc2_sqrt = (float)sqrt(bc2);
-    hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n, 256 * 4)), dim3(256), 0, st, p, g, m, v, n, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
+    float step_size = 0.f, bc2_sqrt = 1.f;
+    if (!hyp) {
+        double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+        step_size = (float)((double)lr / bc1);
+        bc2_sqrt = (float)sqrt(bc2);
+    }
+    hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n, 256 * 4)), dim3(256), 0, st, p, g, m, v, n, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp);
     return hipGetLastError();
 }
 

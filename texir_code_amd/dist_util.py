@@ -27,25 +27,50 @@ def assemble_sum(t):
 
 
 def reduce_texture_grads(params):
-    """sum the texture gradients over the ranks before the (replicated) optimiser step.  With FusedAdam(fuse_mip_fold=True) a
-    parameter's gradient is the pair (p.grad = level-0 scatter, p._texir_grad_l1 = level-1 stack with everything coarser folded in):
-    the level-1 stack (1/4 of the texture) is always reduced, the full-resolution part only if some rank's pixels sampled level 0 at
-    all (one tiny MAX all-reduce decides, identically on every rank) -- at 4k textures seen through 128^2 cube faces nothing does,
-    and the reduction shrinks from 335 MB to 84 MB."""
+    """sum the texture gradients over the ranks before the (replicated) optimiser step.  `params` must be the same list on every rank.
+    With FusedAdam(fuse_mip_fold=True) a parameter's gradient is the triple (p.grad = level-0 scatter, p._texir_grad_l1 = level-1 stack,
+    p._texir_grad_l2 = level-2 stack when the last two folds are left to the step): the coarse stacks (1/4 + 1/16 of the texture) are
+    reduced whenever some rank parked them, the full-resolution part only if some rank's pixels sampled level 0 at all -- at 4k textures
+    seen through 128^2 cube faces nothing does, and the reduction shrinks from 335 MB to 84 MB.
+
+    What a rank holds depends on ITS pixels (an empty pixel shard parks nothing, a view beyond the tap-list budget parks no level-2
+    stack), so the ranks first agree -- one small MAX all-reduce -- on which of the three parts exist anywhere; a rank that lacks a part
+    another rank has contributes zeros (taken from its slot of the optimiser's gradient arena).  Every rank therefore issues the same
+    collectives with the same sizes and ends up with the same parts attached."""
     import torch.distributed as dist
-    params = [p for p in params if p.grad is not None or getattr(p, "_texir_grad_l1", None) is not None]
+    params = list(params)
     if not params or not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         return
-    need = torch.tensor([0.0 if (getattr(p, "_texir_grad_l1", None) is not None and not getattr(p, "_texir_l0_touched", True)) else 1.0
-                         for p in params], device=params[0].device)
-    dist.all_reduce(need, op=dist.ReduceOp.MAX)
-    for p, n in zip(params, need.tolist()):
+    dev = params[0].device
+
+    def local(p):
         g1, g2 = getattr(p, "_texir_grad_l1", None), getattr(p, "_texir_grad_l2", None)
-        if g1 is not None:
-            dist.all_reduce(g1)
-        if g2 is not None:                     # (the fold level 2 -> 1 is left to the optimiser step as well: both parts are linear in the ranks' sums)
-            dist.all_reduce(g2)
-        if n > 0:
+        has_l0 = p.grad is not None and (g1 is None or bool(getattr(p, "_texir_l0_touched", True)))
+        return [1.0 if has_l0 else 0.0, 0.0 if g1 is None else 1.0, 0.0 if g2 is None else 1.0]
+
+    have = torch.tensor([local(p) for p in params], device=dev)
+    dist.all_reduce(have, op=dist.ReduceOp.MAX)
+    for p, (n0, n1, n2) in zip(params, have.tolist()):
+        if n1 > 0 or n2 > 0:
+            H, W, C = p.shape
+            e1, e2 = (H // 2) * (W // 2) * C, (H // 4) * (W // 4) * C
+            span = getattr(p, "_texir_arena_span", None) if getattr(p, "_texir_arena", None) is not None else None
+
+            def zeros(offset, n):
+                if span is not None and span[1] - span[0] >= offset + n and getattr(p, "_texir_grad_l1", None) is None:
+                    z = p._texir_arena["buf"][span[0] + offset:span[0] + offset + n]       # (this rank's backward left its slot unused)
+                    p._texir_arena["clean"].discard(id(p))
+                    return z.zero_()
+                return torch.zeros(n, device=p.device, dtype=torch.float32)
+
+            if n2 > 0 and getattr(p, "_texir_grad_l2", None) is None:
+                p._texir_grad_l2 = zeros(e1, e2)
+            if getattr(p, "_texir_grad_l1", None) is None:
+                p._texir_grad_l1 = zeros(0, e1)
+            dist.all_reduce(p._texir_grad_l1)
+            if n2 > 0:                         # (the fold level 2 -> 1 is left to the optimiser step as well: both parts are linear in the ranks' sums)
+                dist.all_reduce(p._texir_grad_l2)
+        if n0 > 0:
             if p.grad is None:                 # this rank's pixels touched no level-0 texel (the tensor was never made), another rank's did
                 p.grad = torch.zeros_like(p)
             dist.all_reduce(p.grad)

@@ -1,13 +1,20 @@
-"""hipGraph capture of the launch-bound part of a material-estimation step (forward + loss + backward: 18 kernels in stage 2 --
-mip builds, texture fetches, specular trace, three loss passes, one gradient-arena fill, gathers + folds).  The per-step GGX shifts still come from
-the CPU generator exactly as the reference draws them (utils/sample_util.py:102) -- they are copied into a static device
-buffer the captured kernels read.  Optimiser step and gradient all-reduce stay outside the graph."""
+"""hipGraph capture of a whole material-estimation step (trainer/train_material.py:408-458): forward + loss + backward AND the optimiser
+step -- mip builds, texture fetches, specular trace, loss passes, one gradient-arena fill, gathers + folds, one tick of the device-resident
+step counts and the fused Adam kernels (optim.FusedAdam keeps step count and learning rate in device memory, so no kernel argument
+changes from replay to replay).  The per-step GGX shifts still come from the CPU generator exactly as the reference draws them
+(utils/sample_util.py:102) -- they are copied into a static device buffer the captured kernels read.
+Multi-GPU runs (a gradient all-reduce between backward and step) keep the optimiser step outside the graph (step_in_graph=False)."""
 import torch
 
 
 class GraphedMatStep:
-    def __init__(self, model, loss_fn, optimizer, params):
+    def __init__(self, model, loss_fn, optimizer, params, step_in_graph=None):
         self.model, self.loss_fn, self.opt, self.params = model, loss_fn, optimizer, list(params)
+        if step_in_graph is None:
+            import torch.distributed as dist
+            step_in_graph = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        self.step_in_graph = bool(step_in_graph) and hasattr(optimizer, "note_replayed_step")
+        self.stepped = {}
         self.graphs, self.losses, self.outs, self.pool = {}, {}, {}, None
         self.side = torch.cuda.Stream()
         import os
@@ -19,21 +26,27 @@ class GraphedMatStep:
         self.static_shift = None
         self.grads = {}
         for p in self.params:
-            p._texir_l1_static = True          # FusedAdam(fuse_mip_fold=True): the parked level-1 gradients are graph-pool buffers too
+            p._texir_mip1_graph = True         # recorded mip builds start from level 1; step() keeps that level valid (texture._mips_for)
 
-    def _fwd_bwd(self, inp, stage):
+    def _fwd_bwd(self, inp, stage, record_step=False):
         mvp, cam, gt, gmask, seg, fm, room, key = inp
+        # grads are re-created by the backward itself (autograd assigns instead of accumulating): inside the captured graph their
+        # addresses are static, and the zero-fill + accumulate passes over the full textures disappear.  Before the forward: a gradient
+        # still parked on a parameter (a warm-up pass without optimiser step) would make the forward keep the gradient arena as it is.
+        self.opt.zero_grad(set_to_none=self.grads_to_none)
         preds = self.model(mvp, key, cam, stage)
         out = self.loss_fn(gt, preds, gmask, fm, seg, stage=stage, room_seg_mask=room)
         loss = out[0]
         # only detached views are kept: an autograd graph rooted in capture-time tensors must not outlive the capture
         self._last_out = (out[0].detach(),) + tuple(o.detach() if torch.is_tensor(o) else o for o in out[1:])
-        # grads are re-created by the backward itself (autograd assigns instead of accumulating): inside the captured graph their
-        # addresses are static, and the zero-fill + accumulate passes over the full textures disappear
-        self.opt.zero_grad(set_to_none=self.grads_to_none)
         if getattr(self, "_seed", None) is None or self._seed.device != loss.device:
             self._seed = torch.ones((), device=loss.device)          # (a persistent unit seed: loss.backward() would fill a fresh one per step)
         torch.autograd.backward(loss, self._seed)
+        if record_step:
+            # which parameters this graph steps (a stage-1 step leaves the albedo texture without gradient): their host-side step counts
+            # advance per replay (FusedAdam.note_replayed_step)
+            self._stepping = [p for p in self.params if p.grad is not None or getattr(p, "_texir_grad_l1", None) is not None]
+            self.opt.step(_count_on_host=False)
         return loss
 
     def capture(self, key, mvp, cam, gt, gmask, seg, fm, room, stage):
@@ -44,8 +57,10 @@ class GraphedMatStep:
         inp = (mvp, cam, gt, gmask, seg, fm, room, key)
         self.model._static_shift = None
         rng_state = torch.get_rng_state()               # warm-up must not consume the CPU-generator stream of the training run
-        self._fwd_bwd(inp, stage)                       # eager warm-up: G-buffer cache, mask compaction, mip-stack buffers
+        self._fwd_bwd(inp, stage)                       # eager warm-up: G-buffer cache, mask compaction, mip-stack buffers (no optimiser step)
         torch.set_rng_state(rng_state)
+        if hasattr(self.opt, "prepare"):
+            self.opt.prepare()                          # moments + device-resident step records exist before the capture
         self.model._static_shift = self.static_shift
         import gc
         from .scene import defer_destroy
@@ -58,8 +73,15 @@ class GraphedMatStep:
                 with torch.cuda.stream(self.side):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, pool=self.pool, stream=self.side):
-                        loss = self._fwd_bwd(inp, stage)
+                        loss = self._fwd_bwd(inp, stage, record_step=self.step_in_graph)
                 torch.cuda.current_stream().wait_stream(self.side)
+        except BaseException:
+            # a capture that aborts has RECORDED the arena fill without running it: the arena still holds the warm-up pass's gradients
+            for p in self.params:
+                if getattr(p, "_texir_arena", None) is not None:
+                    p._texir_arena["clean"] = set()
+            self.opt.zero_grad(set_to_none=True)
+            raise
         finally:
             self.model._static_shift = None
             if gc_was:
@@ -72,8 +94,10 @@ class GraphedMatStep:
                                      getattr(p, "_texir_l0_mask", None), getattr(p, "_texir_l0_sparse", False), getattr(p, "_texir_grad_l2", None))
                                     for p in self.params]
         self.graphs[(key, stage)] = g
+        self.stepped[(key, stage)] = list(getattr(self, "_stepping", [])) if self.step_in_graph else None
         self.losses[(key, stage)] = loss.detach()      # keep no autograd graph of the captured region alive
         self.outs[(key, stage)] = self._last_out
+        self.opt.zero_grad(set_to_none=self.grads_to_none)   # (the recorded backward parked its gradients on the parameters: they belong to the graph)
 
     def draw_shift(self):
         """the step's GGX shifts from the CPU generator, exactly the reference's draw (sample_util.py:102).  Callers may draw the
@@ -109,9 +133,14 @@ class GraphedMatStep:
         # texture was changed any other way since, rebuild the stack eagerly before replaying
         from .texture import refresh_mips
         for p in self.params:
-            if getattr(p, "_texir_mips", None) is not None and getattr(p, "_texir_mip1_version", None) != (p.data_ptr(), p._version):
+            if getattr(p, "_texir_mips", None) is not None and getattr(p, "_texir_mip1_fresh", None) != (p.data_ptr(), p._version):
                 refresh_mips(p)
+        if hasattr(self.opt, "prepare"):
+            self.opt.prepare()                         # a learning-rate scheduler's change reaches the device record here
         self.graphs[(key, stage)].replay()
+        if self.stepped[(key, stage)] is not None:
+            self.opt.note_replayed_step(self.stepped[(key, stage)])      # the replay contained the optimiser step
+            return self.losses[(key, stage)]
         for p, (g, g1, l0, mask, sparse, g2) in zip(self.params, self.grads[(key, stage)]):
             p.grad = g
             p._texir_grad_l1 = g1

@@ -25,6 +25,56 @@ class FusedAdam(torch.optim.Optimizer):
                 p._texir_grad_l1 = p._texir_grad_l2 = None
                 p._texir_l0_touched = False
         self._make_grad_arena()
+        self._dev = {}                 # per device: {"state": float64 [n,4], "hyper": float32 [n,2], "lr": [floats last written]}; record index per param
+        self._rec = {}
+
+    # ---- device-resident step count / learning rate (texir_adam_tick): the step needs no host argument that changes from step to step,
+    # so a captured hipGraph can contain it (graph_step.GraphedMatStep) and eager steps run the very same kernels ----
+    def _records(self, device):
+        d = self._dev.get(device)
+        if d is None:
+            ps = [(g, p) for g in self.param_groups for p in g["params"] if p.device == device]
+            if len(ps) > 64:
+                raise _lib.TexirError("FusedAdam: at most 64 parameters per device")
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.TexirError("FusedAdam state must exist before hipGraph capture (call prepare() first)")
+            host = torch.zeros((len(ps), 4), dtype=torch.float64)
+            for i, (g, p) in enumerate(ps):
+                self._rec[id(p)] = i
+                host[i] = torch.tensor([float(self.state[p].get("step", 0)) if self.state[p] else 0.0, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1])], dtype=torch.float64)
+            d = {"state": host.to(device), "hyper": torch.zeros((len(ps), 2), device=device, dtype=torch.float32), "lr": [float(g["lr"]) for g, _ in ps],
+                 "params": [p for _, p in ps], "groups": [g for g, _ in ps]}
+            self._dev[device] = d
+        return d
+
+    def prepare(self):
+        """allocate everything a step touches (moments, device records) and push learning-rate changes to the device: call before hipGraph
+        capture and before every replay (cheap: compares floats, launches something only when a scheduler has changed a learning rate)"""
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.is_cuda:
+                    st = self.state[p]
+                    if not st:
+                        st["step"] = 0
+                        st["exp_avg"] = torch.zeros_like(p)
+                        st["exp_avg_sq"] = torch.zeros_like(p)
+        for device in {p.device for g in self.param_groups for p in g["params"] if p.is_cuda}:
+            d = self._records(device)
+            for i, g in enumerate(d["groups"]):
+                if float(g["lr"]) != d["lr"][i]:
+                    d["state"][i, 1] = float(g["lr"])
+                    d["lr"][i] = float(g["lr"])
+
+    def load_state_dict(self, sd):
+        super().load_state_dict(sd)
+        self._dev, self._rec = {}, {}            # (the device records are rebuilt from the loaded step counts on next use)
+
+    def note_replayed_step(self, params):
+        """a hipGraph replay has run the recorded step of `params`: advance the host mirrors of what the device did"""
+        for p in params:
+            self.state[p]["step"] += 1
+            if getattr(p, "_texir_mips", None) is not None and getattr(p, "_texir_defer_fold", False):
+                p._texir_mip1_fresh = (p.data_ptr(), p._version)
 
     def _make_grad_arena(self):
         """ONE buffer for the mip-level gradient stacks of all deferring texture parameters (per device), so that a step clears them with
@@ -69,61 +119,99 @@ class FusedAdam(torch.optim.Optimizer):
                 p._texir_grad_l1 = p._texir_grad_l2 = None
                 p._texir_arena = None
 
+    def has_pending(self, p):
+        """True while a backward pass has left parts of p's gradient outside p.grad (parked mip-level stacks / the sparse level-0 buffer):
+        until step() has consumed them, p.grad alone is NOT the gradient -- use dense_grad(p) for norms, clipping or logging, and do not
+        step such a parameter with another optimiser (call release() first)."""
+        return getattr(p, "_texir_grad_l1", None) is not None
+
+    @torch.no_grad()
+    def dense_grad(self, p):
+        """the full gradient of p that step() is about to apply, materialised as one dense tensor (p.grad + the sparse level-0 part under
+        its bit mask + the parked level-1 / level-2 stacks folded down: each coarser texel adds a quarter of its value to its four children)"""
+        g = torch.zeros_like(p) if p.grad is None else p.grad.detach().clone()
+        g1 = getattr(p, "_texir_grad_l1", None)
+        if g1 is None:
+            return g
+        H, W, C = p.shape
+        if getattr(p, "_texir_l0_sparse", False) and getattr(p, "_texir_l0_mask", None) is not None:
+            mask = p._texir_l0_mask
+            bits = ((mask.view(-1, 1).to(torch.int64) >> torch.arange(32, device=p.device)) & 1).bool().reshape(-1)[:H * W].reshape(H, W)
+            g[bits] += p._texir_g0[bits]
+        up = lambda t: t.repeat_interleave(2, 0).repeat_interleave(2, 1)
+        l1 = g1.view(H // 2, W // 2, C).clone()
+        g2 = getattr(p, "_texir_grad_l2", None)
+        if g2 is not None:
+            l1 += 0.25 * up(g2.view(H // 4, W // 4, C))
+        return g + 0.25 * up(l1)
+
     def set_clamp(self, param, lo=-math.inf, hi=math.inf):
         """fuse `param.data.clamp_(lo, hi)` into every step of this parameter"""
         self._clamps[id(param)] = (float(lo), float(hi))
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, _count_on_host=True):
+        """_count_on_host=False: the call is being RECORDED into a hipGraph (the host-side step counts advance per replay instead,
+        note_replayed_step)"""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         L = _lib.lib()
+        self.prepare()
+        todo = []
         for group in self.param_groups:
-            b1, b2 = group["betas"]
             for p in group["params"]:
                 g1 = getattr(p, "_texir_grad_l1", None)
                 if p.grad is None and g1 is None:
                     continue
                 if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                     raise _lib.TexirError("FusedAdam needs contiguous float32 CUDA parameters")
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p)
-                    st["exp_avg_sq"] = torch.zeros_like(p)
+                todo.append((group, p, g1))
+        # one tick per device advances the step counts of the parameters that step now and derives their step sizes / bias corrections
+        for device in {p.device for _, p, _ in todo}:
+            d = self._records(device)
+            mask = 0
+            for _, p, _ in todo:
+                if p.device == device:
+                    mask |= 1 << self._rec[id(p)]
+            _lib.check(L.texir_adam_tick(_lib.ptr(d["state"]), _lib.ptr(d["hyper"]), d["state"].shape[0], mask, _lib.stream_ptr()))
+        for group, p, g1 in todo:
+            b1, b2 = group["betas"]
+            st = self.state[p]
+            if _count_on_host:
                 st["step"] += 1
-                lo, hi = self._clamps.get(id(p), (-math.inf, math.inf))
-                g = None if p.grad is None else p.grad.contiguous()      # None: level-0 gradient identically zero (texture.py backward)
-                mask = None
-                if g1 is not None and getattr(p, "_texir_l0_sparse", False):
-                    # texture.py's sparse level-0 gradient: valid only at the texels of the view's bit mask, in the parameter's own buffer
-                    mask = getattr(p, "_texir_l0_mask", None)
-                    if mask is not None:
-                        if g is None:
-                            g = p._texir_g0
-                        else:
-                            # (another fetch of the same parameter also produced a dense gradient in this backward pass: fold the sparse part in)
-                            H, W, C = p.shape
-                            bits = ((mask.view(-1, 1).to(torch.int64) >> torch.arange(32, device=p.device)) & 1).bool().reshape(-1)[:H * W].reshape(H, W)
-                            g[bits] += p._texir_g0[bits]
-                            mask = None
-                if g1 is not None:
-                    H, W, C = p.shape
-                    # level 1 of the next forward's mip stack is written on the way (texture._mips_for then builds levels 2.. only)
-                    mips = getattr(p, "_texir_mips", None)
-                    mip1 = mips[1] if (mips is not None and mips[1].numel() >= (H // 2) * (W // 2) * C and mips[1].device == p.device) else None
-                    _lib.check(L.texir_adam_step_tex(_lib.ptr(p), _lib.ptr(g), _lib.ptr(mask), _lib.ptr(g1), _lib.ptr(getattr(p, "_texir_grad_l2", None)),
-                                                     _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]),
-                                                     _lib.ptr(mip1), H, W, C, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                                     int(st["step"]), lo, hi, _lib.stream_ptr()))
-                    p._texir_mip1_version = (p.data_ptr(), p._version) if mip1 is not None else None
-                    if not getattr(p, "_texir_l1_static", False):      # (hipGraph replay re-fills the same buffer: keep it)
-                        p._texir_grad_l1 = p._texir_grad_l2 = None
-                else:
-                    p._texir_mip1_version = None                       # the texture changes behind the mip stack's back
-                    _lib.check(L.texir_adam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]), p.numel(),
-                                                 float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]), lo, hi,
-                                                 _lib.stream_ptr()))
+            hyper = self._dev[p.device]["hyper"][self._rec[id(p)]]
+            lo, hi = self._clamps.get(id(p), (-math.inf, math.inf))
+            g = None if p.grad is None else p.grad.contiguous()      # None: level-0 gradient identically zero (texture.py backward)
+            mask = None
+            if g1 is None and getattr(p, "_texir_l0_sparse", False):
+                raise _lib.TexirError("FusedAdam.step: a sparse level-0 gradient without its parked level-1 stack (state of another backward pass?)")
+            if g1 is not None and getattr(p, "_texir_l0_sparse", False):
+                # texture.py's sparse level-0 gradient: valid only at the texels of the view's bit mask, in the parameter's own buffer
+                mask = getattr(p, "_texir_l0_mask", None)
+                if mask is not None:
+                    if g is None:
+                        g = p._texir_g0
+                    else:
+                        # (another fetch of the same parameter also produced a dense gradient in this backward pass: fold the sparse part in)
+                        H, W, C = p.shape
+                        bits = ((mask.view(-1, 1).to(torch.int64) >> torch.arange(32, device=p.device)) & 1).bool().reshape(-1)[:H * W].reshape(H, W)
+                        g[bits] += p._texir_g0[bits]
+                        mask = None
+            if g1 is not None:
+                H, W, C = p.shape
+                # level 1 of the next forward's mip stack is written on the way (texture._mips_for then builds levels 2.. only)
+                mips = getattr(p, "_texir_mips", None)
+                mip1 = mips[1] if (mips is not None and mips[1].numel() >= (H // 2) * (W // 2) * C and mips[1].device == p.device) else None
+                _lib.check(L.texir_adam_step_tex_dev(_lib.ptr(p), _lib.ptr(g), _lib.ptr(mask), _lib.ptr(g1), _lib.ptr(getattr(p, "_texir_grad_l2", None)),
+                                                     _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]), _lib.ptr(mip1), H, W, C, _lib.ptr(hyper),
+                                                     float(b1), float(b2), float(group["eps"]), lo, hi, _lib.stream_ptr()))
+                # one-shot: the next mip build of this parameter may start from level 1 (texture._mips_for consumes the flag)
+                p._texir_mip1_fresh = (p.data_ptr(), p._version) if mip1 is not None else None
+                p._texir_grad_l1 = p._texir_grad_l2 = None         # consumed (a hipGraph replay re-attaches its own, graph_step.step)
+            else:
+                p._texir_mip1_fresh = None                         # the texture changes behind the mip stack's back
+                _lib.check(L.texir_adam_step_dev(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]), p.numel(), _lib.ptr(hyper),
+                                                 float(b1), float(b2), float(group["eps"]), lo, hi, _lib.stream_ptr()))
         return loss

@@ -31,14 +31,21 @@ def _mips_for(owner, t0, levels):
         if torch.cuda.is_current_stream_capturing():
             raise _lib.TexirError("mip stack must be allocated before hipGraph capture (run one eager step first)")
         rest = torch.empty(n, device=t0.device, dtype=torch.float32)
-    # FusedAdam(fuse_mip_fold=True) writes level 1 (the 2x2 average of the texels it has just updated) into this very buffer and stamps
-    # the tensor version it did that at: then only levels 2.. are rebuilt, and the pass over the whole level-0 texture disappears.  Any
-    # other in-place change of the texture (clamp_, copy_, ...) bumps the version and gets the full build.
-    fresh1 = (hit is not None and hit[1] is rest and getattr(owner, "_texir_mip1_version", None) == (t0.data_ptr(), t0._version) and levels > 2)
+    # FusedAdam(fuse_mip_fold=True) writes level 1 (the 2x2 average of the texels it has just updated) into this very buffer and raises a
+    # ONE-SHOT flag on the parameter: the next build then makes levels 2.. only, and the pass over the whole level-0 texture disappears.
+    # The flag is consumed here and never set by a plain forward build, so an edit between two forwards always gets the full build.  What
+    # cannot be seen is a write through `.data` (it bumps no version counter) BETWEEN the optimiser step and the next forward -- the
+    # reference's own clamp idiom (train_material.py:458): give that clamp to FusedAdam.set_clamp, or call refresh_mips(param) after it.
+    # Under hipGraph capture the build is recorded once and replayed after every optimiser step: graph_step.GraphedMatStep marks its
+    # parameters (_texir_mip1_graph) and promises a valid level 1 before every replay (it rebuilds the stack eagerly when the flag is stale).
+    capturing = torch.cuda.is_current_stream_capturing()
+    flagged = getattr(owner, "_texir_mip1_fresh", None) == (t0.data_ptr(), t0._version)
+    fresh1 = hit is not None and hit[1] is rest and levels > 2 and (flagged or (capturing and getattr(owner, "_texir_mip1_graph", False)))
     _lib.check(L.texir_mip_build(_lib.ptr(t0), _lib.ptr(rest), H, W, C, levels, 1 if fresh1 else 0, _lib.stream_ptr()))
     try:
         owner._texir_mips = (key, rest)
-        owner._texir_mip1_version = (t0.data_ptr(), t0._version)
+        if not capturing:
+            owner._texir_mip1_fresh = None          # consumed (a recorded build consumes nothing: it runs at replay time)
     except AttributeError:
         pass
     return rest
@@ -53,7 +60,7 @@ def refresh_mips(param):
     H, W, C = param.shape
     levels = hit[0][5]
     _lib.check(_lib.lib().texir_mip_build(_lib.ptr(param.detach()), _lib.ptr(hit[1]), H, W, C, levels, 0, _lib.stream_ptr()))
-    param._texir_mip1_version = (param.data_ptr(), param._version)
+    param._texir_mip1_fresh = None
 
 
 # Tap lists cost ~28 bytes per tap (8 taps per pixel and texture configuration); beyond this many bytes in total, further views fall
@@ -127,6 +134,10 @@ class _TexFetch(torch.autograd.Function):
         if not ctx.needs_input_grad[0]:
             return None, None, None, None, None, None, None, None
         if uv.shape[0] == 0:
+            # no fetch coordinates (an empty pixel shard): a deferring parameter gets no gradient part at all from this pass
+            # (dist_util.reduce_texture_grads supplies zeros where other ranks hold parts), any other texture a dense zero
+            if ctx.owner is not None and getattr(ctx.owner, "_texir_defer_fold", False):
+                return None, None, None, None, None, None, None, None
             return torch.zeros((H, W, C), device=d_out.device, dtype=torch.float32), None, None, None, None, None, None, None
         L = _lib.lib()
         d_out = d_out.contiguous()
@@ -238,9 +249,12 @@ def texture(tex, uv, uv_da=None, filter_mode="linear", max_mip_level=13, cache=N
     if arena is not None and mode == 1 and tex.requires_grad and torch.is_grad_enabled() and id(owner) not in arena["clean"]:
         # first deferring fetch of a step: clear the gradient stacks of every trainable parameter of the arena with one fill (in the forward:
         # stream-ordered before every backward of the step, whichever parameter's comes first)
+        # ... unless a gradient parked by an earlier backward pass is still waiting for its optimiser step (gradient accumulation: fwd, bwd, fwd,
+        # bwd, step): the fill would wipe it.  The later backward passes then do not defer and fold into private stacks (texture.py backward).
         ps = [q for q in arena["params"] if q.requires_grad]
-        arena["buf"][min(q._texir_arena_span[0] for q in ps):max(q._texir_arena_span[1] for q in ps)].zero_()
-        arena["clean"] = set(id(q) for q in ps)
+        if not any(getattr(q, "_texir_grad_l1", None) is not None for q in arena["params"]):
+            arena["buf"][min(q._texir_arena_span[0] for q in ps):max(q._texir_arena_span[1] for q in ps)].zero_()
+            arena["clean"] = set(id(q) for q in ps)
     if cache is not None and tex.requires_grad and torch.is_grad_enabled() and uvf.shape[0] > 0:
         taps = _tap_lists(cache, H, W, C, levels, mode, uvf, daf)
     out = _TexFetch.apply(tex, rest, uvf, daf, mode, levels, owner if isinstance(owner, torch.nn.Parameter) else None, taps)

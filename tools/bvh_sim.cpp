@@ -66,9 +66,9 @@ static uint32_t sample_index(uint32_t cell, int log2N)
     return (th << (log2N - bth)) | low;
 }
 
-struct Ray { float o[3], d[3], id[3], ood[3]; float t; int slot; int node; std::vector<int> stk; std::vector<float> stk_t; };
+struct Ray { float o[3], d[3], id[3], ood[3]; float t; int slot; int node; int pleaf = 0; std::vector<int> stk; std::vector<float> stk_t; };
 
-struct Counters { double rays = 0, nodes = 0, tris = 0, wnode = 0, wtri = 0, culled = 0, hits = 0, wcull = 0, maxsp = 0, wuni = 0, wuni0 = 0, wdeep[4] = {0, 0, 0, 0}, lines = 0; };
+struct Counters { double rays = 0, nodes = 0, tris = 0, wnode = 0, wtri = 0, culled = 0, hits = 0, wcull = 0, maxsp = 0, wuni = 0, wuni0 = 0, wdeep[4] = {0, 0, 0, 0}, lines = 0, wmaxn = 0, rounds = 0, wmaxt = 0, refills = 0, refill_lanes = 0, spread = 0, specpops = 0; };
 
 static const int kSent = 0x7FFFFFFF;
 
@@ -77,8 +77,8 @@ int main(int argc, char** argv)
     if (argc < 2) { fprintf(stderr, "usage: bvh_sim <dir> [groups=64] [passes=64] [variant flags: cull cull8 nosort]\n"); return 1; }
     std::string dir = argv[1];
     int n_groups = argc > 2 ? atoi(argv[2]) : 64, n_pass = argc > 3 ? atoi(argv[3]) : 64;
-    bool cull = false, cull8 = false, nosort = false, psort3 = false;
-    for (int i = 4; i < argc; i++) { if (!strcmp(argv[i], "cull")) cull = true; if (!strcmp(argv[i], "cull8")) cull = cull8 = true; if (!strcmp(argv[i], "nosort")) nosort = true; if (!strcmp(argv[i], "psort3")) psort3 = true; }
+    bool cull = false, cull8 = false, nosort = false, psort3 = false; int policy = 0; double alpha = 1.0, alpha2 = 1.0, tricost = 1.5; int refillK = 0; int spec = 0;
+    for (int i = 4; i < argc; i++) { if (!strcmp(argv[i], "cull")) cull = true; if (!strcmp(argv[i], "cull8")) cull = cull8 = true; if (!strcmp(argv[i], "nosort")) nosort = true; if (!strcmp(argv[i], "psort3")) psort3 = true; if (!strcmp(argv[i], "spec")) spec = 1; if (!strcmp(argv[i], "spec2")) spec = 2; if (!strncmp(argv[i], "refill:", 7)) refillK = atoi(argv[i] + 7); if (!strncmp(argv[i], "maj", 3)) { policy = 1; if (argv[i][3] == ':') { alpha = alpha2 = atof(argv[i] + 4); const char* c2 = strchr(argv[i] + 4, ','); if (c2) alpha2 = atof(c2 + 1); } } if (!strncmp(argv[i], "tricost:", 8)) tricost = atof(argv[i] + 8); }
     auto verts = load<float>(dir + "/verts.f32"); auto tris = load<int32_t>(dir + "/tris.i32"); auto uvs = load<float>(dir + "/tri_uvs.f32");
     auto pos = load<float>(dir + "/pos.f32"); auto nrm = load<float>(dir + "/nrm.f32"); auto shift = load<float>(dir + "/shift.f32");
     auto ids = load<int32_t>(dir + "/ids.i32"); auto meta = load<int32_t>(dir + "/meta.i32");
@@ -192,9 +192,8 @@ int main(int argc, char** argv)
             const int64_t g = (int64_t)((double)gi / n_groups * n_grp_total);
             Frame fr[64];
             for (int l = 0; l < 64; l++) { int t = ids[g * 64 + l]; fr[l] = make_frame(nrm[3 * t], nrm[3 * t + 1], nrm[3 * t + 2]); }
-            for (int pj = 0; pj < n_pass; pj++) {
-                const uint32_t J = (uint32_t)((double)pj / n_pass * N);
-                for (int l = 0; l < 64; l++) {
+            int lane_pass[64];
+            auto init_ray = [&](int l, uint32_t J) {
                     int t = ids[g * 64 + l];
                     float sh0 = shift[2 * t], sh1 = shift[2 * t + 1];
                     uint32_t i = sample_index(cell_to_pass(J, sh0, sh1, log2N), log2N);
@@ -204,9 +203,17 @@ int main(int argc, char** argv)
                     Ray& r = R[l];
                     for (int a = 0; a < 3; a++) { r.o[a] = pos[3 * t + a]; r.d[a] = fr[l].V[a] * sp + fr[l].n[a] * ct + fr[l].U[a] * cp; }
                     for (int a = 0; a < 3; a++) { float d = fabsf(r.d[a]) > 8.271806e-25f ? r.d[a] : copysignf(8.271806e-25f, r.d[a]); r.id[a] = 1.f / d; r.ood[a] = r.o[a] * r.id[a]; }
-                    r.t = INFINITY; r.slot = -1; r.node = 0; r.stk.clear(); r.stk_t.clear();
-                }
+                    r.t = INFINITY; r.slot = -1; r.node = 0; r.pleaf = 0; r.stk.clear(); r.stk_t.clear();
+            };
+            // refill mode: the lanes of a wave walk n_pass CONSECUTIVE cells each at its own pace; finished lanes take their next cell when at least
+            // refillK lanes are idle (or nothing else is left to do)
+            const uint32_t Jbase = (uint32_t)((gi * 97) % 32) * (uint32_t)(N / 32);
+            for (int pj = 0; pj < (refillK ? 1 : n_pass); pj++) {
+                const uint32_t J = refillK ? Jbase : (uint32_t)((double)pj / n_pass * N);
+                for (int l = 0; l < 64; l++) { init_ray(l, J); lane_pass[l] = 0; }
+                if (refillK) { c.refills++; c.refill_lanes += 64; }
                 c.rays += 64;
+                int lane_nodes[64] = {0}, lane_tris[64] = {0};
                 bool still_uni = true;      // no divergent node step yet in this pass
                 auto pop = [&](Ray& r) -> int {
                     for (;;) {
@@ -216,12 +223,7 @@ int main(int argc, char** argv)
                         return v;
                     }
                 };
-                for (;;) {
-                    bool any = false; for (auto& r : R) any |= r.node != kSent;
-                    if (!any) break;
-                    for (;;) {
-                        bool anyn = false; for (auto& r : R) anyn |= (r.node >= 0 && r.node != kSent);
-                        if (!anyn) break;
+                auto node_step = [&]() {
                         c.wnode++;
                         {   // wave-uniform step? (all lanes that take part hold the same node); how deep are the stacks; distinct 128-B lines fetched
                             int first = -1; bool uni = true; size_t deep = 0; std::vector<int> ln;
@@ -233,7 +235,7 @@ int main(int argc, char** argv)
                         }
                         for (auto& r : R) {
                             if (!(r.node >= 0 && r.node != kSent)) continue;
-                            c.nodes++;
+                            c.nodes++; lane_nodes[&r - &R[0]]++;
                             const GpuNode4& n = h.nodes4[r.node];
                             float key[4]; int code[4];
                             const float cell[3] = {n.cell_x, n.cell_y, n.cell_z};
@@ -256,19 +258,19 @@ int main(int argc, char** argv)
                             for (int k = 3; k >= 1; k--) if (key[k] < INFINITY) { r.stk.push_back(code[k]); r.stk_t.push_back(cull8 ? q8(key[k]) : key[k]); }
                             if ((double)r.stk.size() > c.maxsp) c.maxsp = (double)r.stk.size();
                             if (key[0] < INFINITY) r.node = code[0]; else r.node = pop(r);
+                            if (spec && r.node < 0 && r.pleaf == 0) { r.pleaf = r.node; r.node = pop(r); c.specpops++; }
                         }
-                    }
-                    for (;;) {
-                        bool anyl = false; for (auto& r : R) anyl |= r.node < 0;
-                        if (!anyl) break;
+                };
+                auto leaf_step = [&]() {
                         int mx = 0;
                         for (auto& r : R) {
-                            if (r.node >= 0) continue;
-                            uint32_t code = ~(uint32_t)r.node;
+                            if (r.node >= 0 && r.pleaf == 0) continue;
+                            const bool from_p = r.pleaf != 0;
+                            uint32_t code = ~(uint32_t)(from_p ? r.pleaf : r.node);
                             int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
                             if (cnt > mx) mx = cnt;
                             for (int i = first; i < first + cnt; i++) {
-                                c.tris++;
+                                c.tris++; lane_tris[&r - &R[0]]++;
                                 const GpuTri& tr = h.tris[i];
                                 float px = r.d[1] * tr.e2[2] - r.d[2] * tr.e2[1], py = r.d[2] * tr.e2[0] - r.d[0] * tr.e2[2], pz = r.d[0] * tr.e2[1] - r.d[1] * tr.e2[0];
                                 float det = tr.e1[0] * px + tr.e1[1] * py + tr.e1[2] * pz, inv = 1.f / det;
@@ -278,22 +280,49 @@ int main(int argc, char** argv)
                                 float v = (r.d[0] * qx + r.d[1] * qy + r.d[2] * qz) * inv, t = (tr.e2[0] * qx + tr.e2[1] * qy + tr.e2[2] * qz) * inv;
                                 if (det != 0.f && u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t > 0.f && t < r.t) { r.t = t; r.slot = i; }
                             }
-                            r.node = pop(r);
+                            if (from_p) r.pleaf = 0; else r.node = pop(r);
+                            if (spec && r.node < 0 && r.pleaf == 0) { r.pleaf = r.node; r.node = pop(r); }
                         }
                         c.wtri += mx;
+                };
+                // scheduling policy: 0 = the kernel's while-while (node phase until no lane holds an inner node, then leaf phase until no lane holds a leaf);
+                // 1 = per step, the phase with more waiting lanes (node lanes weighted by `alpha`)
+                int phase = 0;
+                for (;;) {
+                    int nn = 0, nl = 0;
+                    int nl_any = 0;
+                    for (auto& r : R) { if (r.pleaf) nl_any++; if (r.node == kSent) { if (r.pleaf) nl++; continue; } if (r.node >= 0) nn++; else { nl++; if (!r.pleaf) nl_any++; } }
+                    if (spec == 2) nl = nl_any;
+                    if (refillK) {
+                        int idle = 0; for (int l = 0; l < 64; l++) if (R[l].node == kSent && !R[l].pleaf && lane_pass[l] + 1 < n_pass) idle++;
+                        if (idle && (idle >= refillK || (!nn && !nl))) {
+                            c.refills++; c.refill_lanes += idle;
+                            for (int l = 0; l < 64; l++) if (R[l].node == kSent && !R[l].pleaf && lane_pass[l] + 1 < n_pass) { if (R[l].slot >= 0) c.hits++; lane_pass[l]++; init_ray(l, Jbase + lane_pass[l]); c.rays++; nn++; }
+                            { int lo = 1 << 30, hi = 0; for (int l = 0; l < 64; l++) { lo = std::min(lo, lane_pass[l]); hi = std::max(hi, lane_pass[l]); } c.spread += hi - lo; }
+                        }
                     }
+                    if (!nn && !nl) break;
+                    int want;
+                    if (policy == 0) want = phase == 0 ? (nn ? 0 : 1) : (nl ? 1 : 0);
+                    else want = !nn ? 1 : (!nl_any ? 0 : ((double)nn * (phase == 0 ? alpha : alpha2) >= (double)nl ? 0 : 1));
+                    if (want != phase || c.rays == 0) c.rounds += 0.5;
+                    phase = want;
+                    if (phase == 0) node_step(); else leaf_step();
                 }
                 for (auto& r : R) if (r.slot >= 0) c.hits++;
+                { int mn = 0, mt = 0; for (int l = 0; l < 64; l++) { mn = std::max(mn, lane_nodes[l]); mt = std::max(mt, lane_tris[l]); } c.wmaxn += mn; c.wmaxt += mt; }
             }
         }
 #pragma omp critical
-        { tot.rays += c.rays; tot.nodes += c.nodes; tot.tris += c.tris; tot.wnode += c.wnode; tot.wtri += c.wtri; tot.culled += c.culled; tot.hits += c.hits; tot.wuni += c.wuni; tot.wuni0 += c.wuni0; tot.lines += c.lines; for (int q = 0; q < 4; q++) tot.wdeep[q] += c.wdeep[q]; if (c.maxsp > tot.maxsp) tot.maxsp = c.maxsp; }
+        { tot.rays += c.rays; tot.nodes += c.nodes; tot.tris += c.tris; tot.wnode += c.wnode; tot.wtri += c.wtri; tot.culled += c.culled; tot.hits += c.hits; tot.wuni += c.wuni; tot.wuni0 += c.wuni0; tot.lines += c.lines; tot.wmaxn += c.wmaxn; tot.wmaxt += c.wmaxt; tot.rounds += c.rounds; tot.refills += c.refills; tot.refill_lanes += c.refill_lanes; tot.spread += c.spread; for (int q = 0; q < 4; q++) tot.wdeep[q] += c.wdeep[q]; if (c.maxsp > tot.maxsp) tot.maxsp = c.maxsp; }
     }
     double wr = tot.rays / 64.0;
     printf("per ray: %.2f node visits, %.2f tri tests, %.2f culled pops, hit %.4f, max stack %.0f\n", tot.nodes / tot.rays, tot.tris / tot.rays, tot.culled / tot.rays, tot.hits / tot.rays, tot.maxsp);
     printf("per pass: %.2f wave node steps (util %.3f), %.2f wave tri steps (util %.3f)\n", tot.wnode / wr, tot.nodes / (64.0 * tot.wnode), tot.wtri / wr, tot.tris / (64.0 * tot.wtri));
     printf("wave node steps: %.3f uniform (%.3f in the initial all-uniform run), %.2f distinct node lines per step; steps whose push could pass 8/10/11/16 entries: %.4f %.4f %.4f %.4f\n", tot.wuni / tot.wnode, tot.wuni0 / tot.wnode, tot.lines / tot.wnode,
            tot.wdeep[0] / tot.wnode, tot.wdeep[1] / tot.wnode, tot.wdeep[2] / tot.wnode, tot.wdeep[3] / tot.wnode);
-    printf("VALU model (124/node step, 62/tri step): %.0f per pass\n", 124.0 * tot.wnode / wr + 62.0 * tot.wtri / wr);
+    printf("per pass: max-lane node visits %.2f, max-lane tri tests %.2f, while-while rounds %.2f\n", tot.wmaxn / wr, tot.wmaxt / wr, tot.rounds / wr);
+    if (tot.refills > 0) printf("refill events per 64 rays %.3f (lanes per event %.1f, pass spread at refill %.1f)\n", tot.refills / wr, tot.refill_lanes / tot.refills, tot.spread / tot.refills);
+    printf("cost model (node step 1, triangle test %.2f): %.2f per pass\n", tricost, tot.wnode / wr + tricost * tot.wtri / wr);
     return 0;
 }

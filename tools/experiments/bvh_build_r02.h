@@ -25,17 +25,33 @@ static_assert(sizeof(GpuNode) == 64, "node must be 64 bytes");
 #define TEXIR_TRI_WATERTIGHT 1
 #endif
 
-// 48-byte triangle (v0, prim), (a, 0), (b, 0) with (a, b) = (v1, v2) [watertight] or (e1, e2) = (v1-v0, v2-v0), + a separate 32-byte uv
-// record fetched only for the closest hit.  (A 64-byte record carrying the uvs measured -2 %: tools/experiments/.)
+// TEXIR_TRI64 = 0 (default): 48-byte triangle (v0, prim), (a, 0), (b, 0) + a separate 32-byte uv record (uv0, uv1), (uv2, 0, 0).
+// TEXIR_TRI64 = 1 (A/B variant, measured -2 % on c4 / c2: 16 more bytes per triangle TEST cost more cache than the one uv line per RAY they save):
+//   64-byte triangle, one cache line holding the three positions AND the corner uvs the hit shader needs:
+//   (v0, uv0.x), (a, uv0.y), (b, uv1.x), (uv1.y, uv2.x, uv2.y, prim id bits)   with (a, b) = (v1, v2) [watertight] or (e1, e2) = (v1-v0, v2-v0).
+#ifndef TEXIR_TRI64
+#define TEXIR_TRI64 0
+#endif
+#if TEXIR_TRI64
+struct alignas(16) GpuTri {
+    float v0[3]; float uv0x;
+    float e1[3]; float uv0y;
+    float e2[3]; float uv1x;
+    float uv1y, uv2x, uv2y; uint32_t prim;
+};
+static_assert(sizeof(GpuTri) == 64, "triangle must be 64 bytes");
+constexpr int kTriQuads = 4;          // float4s per triangle record
+#else
 struct alignas(16) GpuTri {
     float v0[3]; uint32_t prim;
     float e1[3]; float pad1;
     float e2[3]; float pad2;
 };
 static_assert(sizeof(GpuTri) == 48, "triangle must be 48 bytes");
-constexpr int kTriQuads = 3;          // float4s per triangle record
+constexpr int kTriQuads = 3;
+#endif
 
-// 32-byte leaf-ordered corner uvs: (uv0, uv1), (uv2, 0, 0)
+// 32-byte leaf-ordered corner uvs: (uv0, uv1), (uv2, 0, 0)   (TEXIR_TRI64 = 0 only)
 struct alignas(16) GpuTriUV {
     float uv[8];
 };
@@ -55,10 +71,20 @@ struct alignas(16) GpuNode4 {
 };
 static_assert(sizeof(GpuNode4) == 64, "wide node must be 64 bytes");
 
-// The same 4-wide tree with full float child boxes (padded by the same absolute slack, not quantised), 128 bytes per node, index for
-// index with the quantised nodes.  Wave-uniform node steps read this form through the scalar cache (device_common.h, node_step4):
-//   plane[0..5] = (lo.x[4], hi.x[4], lo.y[4], hi.y[4], lo.z[4], hi.z[4])   one float per child, child k in lane k
-//   c           = (child0..3),  pad
+// TEXIR_NODE_F32 = 1: the same 4-wide tree with full float child boxes, 128 bytes per node (A/B variant: no byte -> float conversion
+// and no sign select in the node step -- the near / far planes are picked by per-ray load offsets -- for twice the node bytes):
+//   f0..f5 = (lo.x[4], hi.x[4], lo.y[4], hi.y[4], lo.z[4], hi.z[4])   one float per child, child k in lane k
+//   f6     = (child0..3),  f7 = padding
+#ifndef TEXIR_NODE_F32
+#define TEXIR_NODE_F32 0
+#endif
+// TEXIR_UNIFORM_SLOAD (see traverse in device_common.h) = 2 (default) keeps BOTH forms of the tree: the quantised nodes for per-lane
+// fetches, the float nodes for wave-uniform node steps, which read them through the scalar cache.  1: wave-uniform steps read the quantised
+// node through the scalar cache; 0: every step fetches per lane (round-1 / early round-2 kernel).
+#ifndef TEXIR_UNIFORM_SLOAD
+#define TEXIR_UNIFORM_SLOAD 2
+#endif
+#define TEXIR_BUILD_F32NODES (TEXIR_NODE_F32 || TEXIR_UNIFORM_SLOAD >= 2)
 struct alignas(16) GpuNode4F {
     float plane[6][4];
     int32_t c[4];
@@ -73,7 +99,7 @@ constexpr int kMaxDepth = 60;                // traversal stack bound (LDS part 
 struct BvhHost {
     std::vector<GpuNode> nodes;
     std::vector<GpuNode4> nodes4;
-    std::vector<GpuNode4F> nodes4f;     // index-for-index with nodes4
+    std::vector<GpuNode4F> nodes4f;     // filled (index-for-index with nodes4) when TEXIR_BUILD_F32NODES
     std::vector<GpuTri> tris;
     std::vector<GpuTriUV> uvs;
     int max_depth = 0, max_depth4 = 0;

@@ -8,10 +8,7 @@ from texir_code_amd import scene as S, synth, dist_util
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c4"
 n_tex = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
-T, res, tex_res, spp = bench.WORKLOADS[wl]
-sc0 = synth.make_scene(T, seed=666, tex_res=tex_res)
-pos, nrm, valid = synth.make_texel_gbuffer(sc0, res)
-shift = synth.make_shifts(res * res)
+sc0, pos, nrm, valid, shift, res, spp = bench.make_workload(wl)
 dev = torch.device("cuda", 0)
 sc = S.Scene(sc0["verts"], sc0["tris"], sc0["tri_uvs"], sc0["hdr"], device=0)
 ids = dist_util.morton_order(torch.nonzero(torch.from_numpy(valid.reshape(-1)) > 0)[:, 0].to(torch.int32), res)

@@ -17,6 +17,68 @@ from texir_code_amd import conf as C, dist_util, scene as S, synth, tools  # noq
 from texir_code_amd.nirf import IRFLoss, TracerO3dIrrF  # noqa: E402
 
 
+def rel_l2(x, y):
+    x, y = np.asarray(x, np.float64), np.asarray(y, np.float64)
+    return float(np.linalg.norm(x - y) / max(np.linalg.norm(y), 1e-30))
+
+
+def checks(a, sc, sc0, m, P, N, vid, d_pos, d_nrm, d_shift, ids, irr, dev):
+    """--check: the oracle (test infrastructure) is the checker here, never on the timed path"""
+    from oracle import oracle as O
+    from texir_code_amd.graph_step import GraphedMatStep
+    O.set_num_threads(os.cpu_count() or 1)
+    osc = O.Scene(sc0["verts"], sc0["tris"], sc0["tri_uvs"], sc0["hdr"])
+    c = {}
+    # NIrF ground truth (TracerO3dIrrF.trace_gt: cosine-weighted irradiance of 256 random surface points at 8 x 16 = 128 spp) vs the oracle
+    rng = np.random.default_rng(5)
+    sel = np.sort(rng.choice(vid, 256, replace=False))
+    p, n = P[sel].to(dev), N[sel].to(dev)
+    shift = torch.rand(256, 2, generator=torch.Generator().manual_seed(11))
+    gt = m.trace_gt(p, n, [8, 16], shift=shift).cpu().numpy()
+    ref = osc.irt_generate(P[sel].numpy(), N[sel].numpy(), None, shift.numpy(), 128, "uniform", tracer="bvh")
+    c["nirf_gt_vs_oracle_rel_l2"] = rel_l2(gt, ref)
+    # IrT: a random texel sample of the full-size texture vs the oracle; the union of the 8 block-cyclic rank shards vs the whole, bit for bit
+    pick = np.sort(rng.choice(vid, 300, replace=False))
+    ref = osc.irt_generate(P[pick].numpy(), N[pick].numpy(), None, d_shift[torch.from_numpy(pick).to(dev)].cpu().numpy(), a.spp, "uniform", tracer="bvh")
+    c["irt_sample_vs_oracle_rel_l2"] = rel_l2(irr[torch.from_numpy(pick).to(dev)].cpu().numpy(), ref)
+    acc = torch.zeros_like(irr)
+    st_total = 0
+    for r in range(8):
+        part = dist_util.shard_block_cyclic(ids, r, 8, bench.BLOCK)
+        _, st = sc.irt_generate(d_pos, d_nrm, d_shift, a.spp, "uniform", texel_ids=part, out=acc, stats=True)
+        st_total += int(st[0])
+    c["irt_shard_union_equals_whole"] = bool(torch.equal(acc, irr))
+    c["irt_rays_traced"] = st_total
+    del acc
+    # material step at 4k textures on this mesh: three steps through hipGraph replay vs the same three steps in eager call order
+    cube = 128
+    shifts = [torch.rand(6 * cube * cube, 2, generator=torch.Generator().manual_seed(100 + k)) for k in range(3)]
+    res = []
+    for graph in (False, True):
+        model, views, data, loss_fn, opt = bench.mat_setup(sc, sc0, irr, a.res, dev, cube=cube, S=16, tres=4096, n_views=2)
+        gs = GraphedMatStep(model, loss_fn, opt, [model.materials_a, model.materials_r]) if graph else None
+        if gs is not None:
+            for i in range(2):
+                mvp, cam, gt, gmask, seg, fm, room = data[i]
+                gs.capture(i, mvp, cam, gt, gmask, seg, fm, room, 2)
+        for k in range(3):
+            i = k % 2
+            mvp, cam, gt, gmask, seg, fm, room = data[i]
+            if gs is not None:
+                gs.step(i, 2, shift=shifts[k])
+            else:
+                model._static_shift = shifts[k].to(dev)
+                opt.zero_grad()
+                loss_fn(gt, model(mvp, i, cam, 2), gmask, fm, seg, stage=2, room_seg_mask=room)[0].backward()
+                opt.step()
+        model._static_shift = None
+        res.append((model.materials_a.detach().clone(), model.materials_r.detach().clone()))
+        del model, opt, gs, data
+    c["mat_graph_vs_eager_max_abs"] = float(max((res[0][0] - res[1][0]).abs().max(), (res[0][1] - res[1][1]).abs().max()))
+    c["mat_params_moved"] = float((res[0][0] - 0.5).abs().max())
+    return c
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tris", type=int, default=2000000)
@@ -24,6 +86,8 @@ def main():
     ap.add_argument("--spp", type=int, default=2048)
     ap.add_argument("--nirf-steps", type=int, default=50)
     ap.add_argument("--mat-steps", type=int, default=50)
+    ap.add_argument("--check", action="store_true", help="verify every stage (tests/test_gpu_scan_and_configs.py): NIrF ground truth and an IrT texel "
+                    "sample against the CPU oracle, IrT 8-shard union == whole, material step hipGraph replay == eager call order")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.set_num_threads(1)                    # as the runners and bench.py (tiny host torch ops; avoids OpenMP fork/join jitter)
@@ -79,7 +143,9 @@ def main():
     sc.irt_generate(d_pos, d_nrm, d_shift, a.spp, "uniform", texel_ids=ids, out=irr)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    out["irt"] = {"valid_texels": int(ids.numel()), "seconds": round(dt, 3), "Mrays_s": round(ids.numel() * a.spp / dt / 1e6, 1)}
+    out["irt"] = {"valid_texels": int(ids.numel()), "seconds": round(dt, 3), "Mrays_s": round(ids.numel() * a.spp / dt / 1e6, 1), "res": a.res, "spp": a.spp}
+    if a.check:
+        out["checks"] = checks(a, sc, sc0, m, P, N, vid, d_pos, d_nrm, d_shift, ids, irr, dev)
 
     # 3. the asset step in between (tools/padding_texture.py) + material step
     t0 = time.perf_counter()
