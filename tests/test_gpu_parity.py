@@ -366,7 +366,7 @@ def test_fused_adam_matches_torch_adam(tx):
         ob.step()
         sa.step()
         sb.step()
-        assert (a - b).abs().max().item() < 1e-6, it
+        assert (a - b).abs().max().item() < 2e-6, it          # (step size / bias correction are derived on the device, texir_adam_tick: an ulp of float32 apart at most)
 
 
 @pytest.fixture(scope="module")

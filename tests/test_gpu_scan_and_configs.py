@@ -211,6 +211,7 @@ def test_material_step_at_4k_textures_fused_vs_reference_forms(tx, monkeypatch):
             monkeypatch.delenv(k, raising=False)
         for k, val in env.items():
             monkeypatch.setenv(k, val)
+        torch.manual_seed(3)           # (mat_setup renders its ground truth with GGX shifts from the global CPU generator)
         model, views, data, loss_fn, opt = bench.mat_setup(sc, sc0, irr, 256, dev, cube=cube, S=16, tres=4096, n_views=2, fuse=fuse)
         with torch.no_grad():          # start away from the constant initialisation so that every mip level carries signal
             model.materials_a.copy_(0.3 + 0.4 * torch.rand(4096, 4096, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(1)))

@@ -66,6 +66,10 @@ constexpr int kLstk = kCull ? kLdsStack / 2 : kLdsStack;   // the other tracing 
 #ifndef TEXIR_PART_WEDGE
 #define TEXIR_PART_WEDGE 1
 #endif
+// azimuth sine / cosine of the fused IrT sampling from v_sin_f32 / v_cos_f32 (device_common.h sample_dir<FAST>)
+#ifndef TEXIR_IRT_FAST_SINCOS
+#define TEXIR_IRT_FAST_SINCOS 1
+#endif
 
 // One texel per wave: the 64 lanes trace 64 samples of the texel per pass (any N, binary or 4-wide tree).  Kept as the
 // form for short texel lists (a 1024-point NIrF batch), for binary-tree scenes, and TEXIR_IRT_TEXELS_PER_WAVE=1.
@@ -209,13 +213,13 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
                 float s0 = shift_wrap_clamp(ham0(i, (uint32_t)N), sh0);
                 float s1 = shift_wrap_clamp(ham1(i), sh1);
                 float d[3];
-                sample_dir(mode, s0, s1, 0.f, f, d);
+                sample_dir<TEXIR_IRT_FAST_SINCOS != 0>(mode, s0, s1, 0.f, f, d);
+                const float ndl = cosw ? 1.f : fminf(fmaxf(nx * d[0] + ny * d[1] + nz * d[2], 0.f), 1.f);       // :170, RAW normal (before the trace: one live register instead of three)
                 Hit h = trace_closest<STATS, kGroupLstk, WIDTH, kCull>(sc, px, py, pz, d[0], d[1], d[2], cn, ct, STATS ? wi : nullptr);
                 if (STATS) c_rays++;
                 if (h.slot >= 0 && h.t > 1e-4f) {          // tracer_o3d_irt.py:248
                     float L[3];
                     shade_hit(sc, h.slot, h.u, h.v, L);
-                    float ndl = cosw ? 1.f : fminf(fmaxf(nx * d[0] + ny * d[1] + nz * d[2], 0.f), 1.f);       // :170, RAW normal
                     acc0 += L[0] * ndl; acc1 += L[1] * ndl; acc2 += L[2] * ndl;
                     if (STATS) c_hits++;
                 }

@@ -1,0 +1,66 @@
+"""What the runners of trainer/*.py share: experiment directories, checkpoints, and ONE epoch / batch loop with hooks.
+
+The reference repeats this scaffolding in every runner (trainer/train_material.py:31-130, trainer/train_irrf.py:27-140 set up the
+same ../<exps>/<prefix>-<name>/<timestamp>/{plots,checkpoints/ModelParameters} tree; their run() methods are the same nested loop with
+different things hung on it).  Here the runners declare WHAT happens at each hook; the order of the hooks is the order in which the
+reference's loops do things, which is what keeps the optimisation trajectories (and the CPU random stream) identical."""
+import os
+import sys
+from datetime import datetime
+
+import torch
+
+from ..conf import ConfigFactory
+
+
+class RunnerBase:
+    model_params_subdir = "ModelParameters"
+
+    def setup_experiment(self, kwargs, prefix, exps_root="../", make_dirs=True, keep_conf_copy=False):
+        """conf, names and the run directory layout of the reference's runners (kwargs of trainer/exp_runner.py:69-80)"""
+        torch.set_default_dtype(torch.float32)
+        torch.set_num_threads(1)                 # as the reference's runners (e.g. trainer/train_material.py:34): host torch ops are tiny
+        self.conf = ConfigFactory.parse_file(kwargs["conf"])
+        self.exps_folder_name = kwargs["exps_folder_name"]
+        self.train_batch_size = self.conf.get_int("train.batch_size")
+        self.max_niters = kwargs["max_niters"]
+        self.GPU_INDEX = kwargs["gpu_index"]
+        self.expname = prefix + "-" + kwargs["expname"]
+        self.expdir = os.path.join(exps_root, self.exps_folder_name, self.expname)
+        self.timestamp = "{:%Y_%m_%d_%H_%M_%S}".format(datetime.now())
+        self.plots_dir = os.path.join(self.expdir, self.timestamp, "plots")
+        self.checkpoints_path = os.path.join(self.expdir, self.timestamp, "checkpoints")
+        if make_dirs:
+            for d in (self.plots_dir, os.path.join(self.checkpoints_path, self.model_params_subdir)):
+                os.makedirs(d, exist_ok=True)
+            if keep_conf_copy:
+                try:
+                    import shutil
+                    shutil.copy(kwargs["conf"], os.path.join(self.expdir, self.timestamp, "runconf.conf"))
+                except OSError:
+                    pass
+        print("shell command : {0}".format(" ".join(sys.argv)))
+
+    def save_checkpoints(self, epoch):
+        torch.save({"epoch": epoch, "model_state_dict": self.model.state_dict()},
+                   os.path.join(self.checkpoints_path, self.model_params_subdir, "latest.pth"))
+
+    def fit(self, loader, first_epoch, last_epoch, step, epoch_begin=None, takes=None, before_step=None, after_step=None, epoch_end=None):
+        """for epoch in first_epoch..last_epoch: epoch_begin(epoch); for every batch this rank `takes`: before_step, step, after_step;
+        epoch_end(epoch).  A hook that returns True from after_step ends the run (the runners' step budgets).  Returns True if ended early."""
+        for epoch in range(first_epoch, last_epoch + 1):
+            if epoch_begin is not None:
+                epoch_begin(epoch)
+            for data_index, batch in enumerate(loader):
+                if takes is not None and not takes(data_index):
+                    continue
+                self.model.train()
+                if before_step is not None:
+                    before_step(epoch, data_index)
+                out = step(batch)
+                self.cur_iter += 1
+                if after_step is not None and after_step(epoch, data_index, out):
+                    return True
+            if epoch_end is not None:
+                epoch_end(epoch)
+        return False

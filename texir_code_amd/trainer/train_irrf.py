@@ -2,46 +2,27 @@
 random mesh points.  Same kwargs, conf keys, checkpoint layout (ModelParameters/latest.pth) and loop order as the reference;
 the GT tracing runs on the IrT kernel, the MLP on stock PyTorch-ROCm."""
 import os
-import sys
 import time
-from datetime import datetime
 
 import numpy as np
 import torch
 
 from .. import io_formats as IO
-from ..conf import ConfigFactory
 from ..nirf import hdr_recover
 from ..plugin import get_class
+from .base import RunnerBase
 
 
-class IRRFTrainRunner:
+class IRRFTrainRunner(RunnerBase):
     def __init__(self, **kwargs):
-        torch.set_default_dtype(torch.float32)
-        torch.set_num_threads(1)                 # as the reference's runners (e.g. trainer/train_material.py:34): host torch ops are tiny
-        self.conf = ConfigFactory.parse_file(kwargs["conf"])
-        self.exps_folder_name = kwargs["exps_folder_name"]
-        self.train_batch_size = self.conf.get_int("train.batch_size")
+        self.setup_experiment(kwargs, "IRRF", exps_root=kwargs.get("exps_root", "../"))
         self.val_batch_size = self.conf.get_int("val.batch_size")
         self.nepochs = self.conf.get_int("train.irf_epoch")
-        self.max_niters = kwargs["max_niters"]
-        self.GPU_INDEX = kwargs["gpu_index"]
         self.is_hdr_texture = self.conf.get_bool("train.is_hdr_texture")
-        self.expname = "IRRF-" + kwargs["expname"]
-        root = kwargs.get("exps_root", "../")
         is_continue, timestamp = kwargs["is_continue"], kwargs["timestamp"]
-        self.expdir = os.path.join(root, self.exps_folder_name, self.expname)
         if is_continue and timestamp == "latest":
-            stamps = sorted(os.listdir(self.expdir)) if os.path.exists(self.expdir) else []
+            stamps = sorted(t for t in os.listdir(self.expdir) if t != self.timestamp) if os.path.exists(self.expdir) else []
             is_continue, timestamp = (True, stamps[-1]) if stamps else (False, None)
-        os.makedirs(self.expdir, exist_ok=True)
-        self.timestamp = "{:%Y_%m_%d_%H_%M_%S}".format(datetime.now())
-        self.plots_dir = os.path.join(self.expdir, self.timestamp, "plots")
-        self.checkpoints_path = os.path.join(self.expdir, self.timestamp, "checkpoints")
-        self.model_params_subdir = "ModelParameters"
-        os.makedirs(self.plots_dir, exist_ok=True)
-        os.makedirs(os.path.join(self.checkpoints_path, self.model_params_subdir), exist_ok=True)
-        print("shell command : {0}".format(" ".join(sys.argv)))
 
         print("Loading training data ...")
         path_mesh = self.conf.get_string("train.path_mesh_open3d")
@@ -73,10 +54,6 @@ class IRRFTrainRunner:
         self.val_resolution = self.conf.get_list("train.val_sample_res", default=[8, 16])
         self.losses = []
 
-    def save_checkpoints(self, epoch):
-        torch.save({"epoch": epoch, "model_state_dict": self.model.state_dict()},
-                   os.path.join(self.checkpoints_path, self.model_params_subdir, "latest.pth"))
-
     def plot_to_disk(self):
         """train_irrf.py:184-231: irradiance panorama of the validation view, traced GT (first call only) next to the prediction"""
         self.model.eval()
@@ -102,30 +79,38 @@ class IRRFTrainRunner:
         self.first_val = False
 
     def run(self):
+        """train_irrf.py:233-275 as hooks on the shared loop: new surface points every epoch; before a step the periodic checkpoint and the
+        validation panorama (which consumes CPU random numbers on its first call: its position in the loop is part of the trajectory)"""
         print("training...")
         self.cur_iter = self.start_epoch * len(self.train_dataloader)
-        for epoch in range(self.start_epoch, self.nepochs + 1):
-            self.train_dataset.change_points()
-            for data_index, one_sample in enumerate(self.train_dataloader):
-                t0 = time.time()
-                self.model.train()
-                if self.cur_iter % self.ckpt_freq == 0 and not self.cur_iter == 0:
-                    self.save_checkpoints(epoch)
-                if self.cur_iter % self.plot_freq == 0:
-                    self.plot_to_disk()
-                points, normals = one_sample["point"].float().cuda(), one_sample["normal"].float().cuda()
-                res = self.model(points, normals, self.train_resolution)
-                radiance_loss = self.irf_loss(res)
-                self.irf_optimizer.zero_grad()
-                radiance_loss.backward()
-                self.irf_optimizer.step()
-                if self.cur_iter % 50 == 0:
-                    print("{0} [{1}] ({2}/{3}): radiance_loss = {4}, batch cost time : {5:.4f}s".format(
-                        self.expname, epoch, data_index, self.n_batches, radiance_loss.item(), time.time() - t0))
-                    self.losses.append(radiance_loss.item())
-                self.cur_iter += 1
-                if self.cur_iter >= self.max_niters:
-                    self.save_checkpoints(epoch)
-                    return
-            self.irf_scheduler.step()
-        self.save_checkpoints(self.nepochs)
+        t0 = [0.0]
+
+        def before_step(epoch, data_index):
+            t0[0] = time.time()
+            if self.cur_iter % self.ckpt_freq == 0 and not self.cur_iter == 0:
+                self.save_checkpoints(epoch)
+            if self.cur_iter % self.plot_freq == 0:
+                self.plot_to_disk()
+
+        def step(one_sample):
+            points, normals = one_sample["point"].float().cuda(), one_sample["normal"].float().cuda()
+            radiance_loss = self.irf_loss(self.model(points, normals, self.train_resolution))
+            self.irf_optimizer.zero_grad()
+            radiance_loss.backward()
+            self.irf_optimizer.step()
+            return radiance_loss
+
+        def after_step(epoch, data_index, radiance_loss):
+            if (self.cur_iter - 1) % 50 == 0:
+                print("{0} [{1}] ({2}/{3}): radiance_loss = {4}, batch cost time : {5:.4f}s".format(
+                    self.expname, epoch, data_index, self.n_batches, radiance_loss.item(), time.time() - t0[0]))
+                self.losses.append(radiance_loss.item())
+            if self.cur_iter >= self.max_niters:
+                self.save_checkpoints(epoch)
+                return True
+            return False
+
+        ended = self.fit(self.train_dataloader, self.start_epoch, self.nepochs, step, epoch_begin=lambda epoch: self.train_dataset.change_points(),
+                         before_step=before_step, after_step=after_step, epoch_end=lambda epoch: self.irf_scheduler.step())
+        if not ended:
+            self.save_checkpoints(self.nepochs)

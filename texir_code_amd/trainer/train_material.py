@@ -5,18 +5,17 @@ output and are not reproduced."""
 import os
 import sys
 import time
-from datetime import datetime
 
 import numpy as np
 import torch
 import torch.nn.functional as F
 
 from .. import dist_util, io_formats as IO
-from ..conf import ConfigFactory
 from ..datasets import parse_roomseg
 from ..models import rgb_to_intensity
 from ..optim import FusedAdam
 from ..plugin import get_class
+from .base import RunnerBase
 
 N_SEG_CLASSES = 49          # trainer/train_material.py:188
 
@@ -44,34 +43,14 @@ def build_masks(segs, stage_m1_rgb, room_img=None, positions=None, room_meta=Non
     return source_seg_mask, floor_max_mask, room_mask
 
 
-class MatTrainRunner:
+class MatTrainRunner(RunnerBase):
     def __init__(self, **kwargs):
-        torch.set_default_dtype(torch.float32)
-        torch.set_num_threads(1)                 # as the reference's runners (e.g. trainer/train_material.py:34): host torch ops are tiny
-        self.conf = ConfigFactory.parse_file(kwargs["conf"])
-        self.exps_folder_name = kwargs["exps_folder_name"]
-        self.train_batch_size = self.conf.get_int("train.batch_size")
-        self.nepochs = self.conf.get_int("train.mat_epoch")
-        self.max_niters = kwargs["max_niters"]
-        self.GPU_INDEX = kwargs["gpu_index"]
-        self.expname = "Mat-" + kwargs["expname"]
         # --is_continue: the reference's resume path is dead code; the flags are accepted and ignored
-        self.expdir = os.path.join("../", self.exps_folder_name, self.expname)
-        self.timestamp = "{:%Y_%m_%d_%H_%M_%S}".format(datetime.now())
-        self.plots_dir = os.path.join(self.expdir, self.timestamp, "plots")
-        self.checkpoints_path = os.path.join(self.expdir, self.timestamp, "checkpoints")
-        if int(os.environ.get("RANK", "0")) == 0 and not kwargs.get("dry_dirs", False):
-            for d in (self.plots_dir, os.path.join(self.checkpoints_path, "ModelParameters")):
-                os.makedirs(d, exist_ok=True)
-            try:
-                import shutil
-                shutil.copy(kwargs["conf"], os.path.join(self.expdir, self.timestamp, "runconf.conf"))
-            except OSError:
-                pass
+        self.setup_experiment(kwargs, "Mat", make_dirs=int(os.environ.get("RANK", "0")) == 0 and not kwargs.get("dry_dirs", False), keep_conf_copy=True)
+        self.nepochs = self.conf.get_int("train.mat_epoch")
         torch.manual_seed(666)
         torch.cuda.manual_seed(666)
         np.random.seed(666)
-        print("shell command : {0}".format(" ".join(sys.argv)))
         print("Loading data ...")
         self.train_dataset = get_class(self.conf.get_string("train.dataset_class"))(
             self.conf.get_string("train.path_mesh_open3d"), self.conf.get_list("train.pano_img_res"), self.conf.get_float("train.hdr_exposure"))
@@ -147,10 +126,6 @@ class MatTrainRunner:
         self.mat_scheduler = torch.optim.lr_scheduler.StepLR(self.mat_optimizer, self.conf.get_int("train.mat_sched_step", default=100),
                                                             gamma=self.conf.get_float("train.mat_sched_factor", default=0.0))
 
-    def save_checkpoints(self, epoch):
-        torch.save({"epoch": epoch, "model_state_dict": self.model.state_dict()},
-                   os.path.join(self.checkpoints_path, "ModelParameters", "latest.pth"))
-
     def plot_materials(self):
         """the user-facing output of plot_to_disk_cube (train_material.py:352-353): the current material textures as
         plots/mat_albedo-1_<iter>.hdr and plots/mat_roughness-1_<iter>.hdr (Radiance RGBE, roughness replicated to 3 channels)"""
@@ -224,27 +199,34 @@ class MatTrainRunner:
         self.plot_materials()
 
     def _stage(self, stage, max_steps=None):
-        for epoch in range(self.start_epoch, self.nepochs + 1):
+        """one stage of train_material.py:416-605 as hooks on the shared loop"""
+        rank, world, _ = dist_util.world_info()
+        t0 = [0.0]
+
+        def epoch_begin(epoch):
             if stage > 0 and epoch % self.plot_freq == 0 and not self.cur_iter == 0:      # train_material.py:484-485, 550-551
                 self.validation_forward(stage)
-            rank, world, _ = dist_util.world_info()
             if world > 1 and self.mat_shard == "view" and len(self.train_dataset) % world:
                 raise ValueError("train.mat_shard = view needs the number of views (%d) to be a multiple of the world size (%d)"
                                  % (len(self.train_dataset), world))
-            for data_index, gt_item in enumerate(self.train_dataloader):
-                if world > 1 and self.mat_shard == "view" and data_index % world != rank:
-                    continue                     # throughput mode: `world` different views per optimiser step (gradients summed)
-                t0 = time.time()
-                self.model.train()
-                loss, seg_item = self.train_step(gt_item, stage)
-                self.log.append((stage, epoch, data_index, float(loss.item()), float(seg_item)))     # the reference prints .item() every step too
-                print("{0} [{1}] ({2}/{3}): img_loss_stage{7} ({5}) = {4}, seg_loss = {6}, batch cost time : {8:.4f}s".format(
-                    self.expname, epoch, data_index, self.n_batches, loss.item(), self.conf.get_string("render_loss.loss_type"), seg_item, stage,
-                    time.time() - t0))
-                self.cur_iter += 1
-                if max_steps is not None and self.cur_iter >= max_steps:
-                    return
-            self.mat_scheduler.step()
+
+        def takes(data_index):
+            # throughput mode: `world` different views per optimiser step (gradients summed)
+            return not (world > 1 and self.mat_shard == "view" and data_index % world != rank)
+
+        def before_step(epoch, data_index):
+            t0[0] = time.time()
+
+        def after_step(epoch, data_index, out):
+            loss, seg_item = out
+            self.log.append((stage, epoch, data_index, float(loss.item()), float(seg_item)))     # the reference prints .item() every step too
+            print("{0} [{1}] ({2}/{3}): img_loss_stage{7} ({5}) = {4}, seg_loss = {6}, batch cost time : {8:.4f}s".format(
+                self.expname, epoch, data_index, self.n_batches, loss.item(), self.conf.get_string("render_loss.loss_type"), seg_item, stage,
+                time.time() - t0[0]))
+            return max_steps is not None and self.cur_iter >= max_steps
+
+        self.fit(self.train_dataloader, self.start_epoch, self.nepochs, lambda gt_item: self.train_step(gt_item, stage), epoch_begin=epoch_begin,
+                 takes=takes, before_step=before_step, after_step=after_step, epoch_end=lambda epoch: self.mat_scheduler.step())
 
     def run(self):
         print("training...")

@@ -55,6 +55,7 @@ def checks(a, sc, sc0, m, P, N, vid, d_pos, d_nrm, d_shift, ids, irr, dev):
     shifts = [torch.rand(6 * cube * cube, 2, generator=torch.Generator().manual_seed(100 + k)) for k in range(3)]
     res = []
     for graph in (False, True):
+        torch.manual_seed(3)           # (mat_setup renders its ground truth with GGX shifts from the global CPU generator)
         model, views, data, loss_fn, opt = bench.mat_setup(sc, sc0, irr, a.res, dev, cube=cube, S=16, tres=4096, n_views=2)
         gs = GraphedMatStep(model, loss_fn, opt, [model.materials_a, model.materials_r]) if graph else None
         if gs is not None:

@@ -8,9 +8,9 @@ python - "$f" <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-# the last adam launch ends a step; take the kernels between the two last "step boundaries" (second adam of a step)
-idx=[i for i,r in enumerate(rows) if 'adam_' in r['Kernel_Name']]
-end=idx[-1]; start=idx[-3]+1            # two adam launches per step
+# the roughness texture's Adam launch (one channel) ends a step: take the kernels between the last two of them
+idx=[i for i,r in enumerate(rows) if 'adam_tex' in r['Kernel_Name'] and 'kernel<1>' in r['Kernel_Name']]
+end=idx[-1]; start=idx[-2]+1
 seg=rows[start:end+1]
 t0=int(seg[0]['Start_Timestamp']); tot=0
 for r in seg:
