@@ -210,14 +210,17 @@ def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5):
             model._static_shift = None
     graphs = gs is not None
     times = []
-    nxt = gs.draw_shift() if gs is not None else None
+    view_of = lambda it: (it * world + rank) % len(views)
+    if gs is not None:
+        gs.stage_shift(view_of(0), gs.draw_shift())
     for it in range(warmup + steps):
-        v = (it * world + rank) % len(views)
+        v = view_of(it)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if gs is not None:
-            gs.step(v, 2, reduce_grads=dist_util.reduce_texture_grads if world > 1 else None, shift=nxt)
-            nxt = gs.draw_shift()           # next step's CPU-generator draw overlaps this step's GPU work (same stream order)
+            gs.step(v, 2, reduce_grads=dist_util.reduce_texture_grads if world > 1 else None, staged=True)
+            # the next step's CPU-generator draw (same stream order as the reference's) and its placement overlap this step's GPU work
+            gs.stage_shift(view_of(it + 1), gs.draw_shift())
         else:
             eager_step(v)
         torch.cuda.synchronize()
@@ -236,10 +239,23 @@ def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5):
     step_bytes = 28.0 * n_par + 4.0 * n_par * (1.0 + 1.0 / 3.0) + 4.0 * n_par / 4.0 + P * (24 + 8 + 16 + 12 + 2 + 12 + 3 * 16 * 12.0)
     # N > 1: throughput mode -- every rank renders a different view per optimiser step and the dense texture gradients (335 MB at 4k^2) are
     # all-reduced, so one step covers `world` views: compare ms_per_view across N, not ms
+    # measured fabric traffic of one replayed step (tools/mat_step_pmc.sh -> profiles/pmc_mat_step.json; refused when taken with other sources)
+    traffic = tnote = None
+    pm = os.path.join(ROOT, "profiles", "pmc_mat_step.json")
+    if os.path.exists(pm):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from mat_step_pmc import mat_src_sha
+        tj = json.load(open(pm))
+        if tj.get("mat_src_sha") == mat_src_sha():
+            traffic = tj["fabric_bytes_per_step"]
+            tnote = "measured: %.2f GB read + %.2f GB written per step over the fabric (profiles/pmc_mat_step.json)" % (tj["read_bytes_per_step"] / 1e9, tj["write_bytes_per_step"] / 1e9)
+        else:
+            tnote = "profiles/pmc_mat_step.json was taken with other sources"
     return {"ms": round(med, 3), "views_per_step": world, "ms_per_view": round(med / world, 3),
             "stage": 2, "steps": steps, "warmup": warmup, "hipgraph": bool(graphs),
             "roofline": {"bound": "hbm", "achieved": round(step_bytes / (med * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(step_bytes / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_step": int(step_bytes),
+                         "traffic": traffic, "traffic_note": tnote,
                          "note": "algorithmic bytes: Adam 28 B x %.1f M params + mip build + level-1 gradient + per-pixel streams; the %d x %d specular "
                                  "rays are cache-served BVH traffic and are not counted" % (n_par / 1e6, P, S)},
             "config": "stage-2 step: albedo %d^2x3 + roughness %d^2x1 (%.1f M params), %d px x %d spp, %d-tri mesh, %d views%s"
@@ -342,7 +358,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-mat", action="store_true")
     ap.add_argument("--extra", default=None, help="comma-separated extra workloads timed after the headline (IrT only), reported under extra_workloads; "
-                    "default: c4_scan (the hostile sibling) next to the c4 headline, nothing otherwise; `none` switches it off")
+                    "default: c4_scan (the hostile sibling) next to the full c4 headline line, nothing otherwise or with --no-cpu / --no-mat; `none` switches it off")
     args = ap.parse_args()
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
@@ -488,8 +504,8 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
     # further workloads (IrT only), never the headline
-    if args.extra is None:
-        args.extra = "c4_scan" if args.workload == "c4" else ""
+    if args.extra is None:          # the full default line (what the driver runs) carries the hostile sibling; tool invocations (--no-cpu / --no-mat) stay lean
+        args.extra = "c4_scan" if (args.workload == "c4" and not args.no_cpu and not args.no_mat) else ""
     extras = [w for w in args.extra.split(",") if w and w != "none"]
     if extras:
         del r

@@ -68,7 +68,7 @@ constexpr int kLstk = kCull ? kLdsStack / 2 : kLdsStack;   // the other tracing 
 #endif
 // azimuth sine / cosine of the fused IrT sampling from v_sin_f32 / v_cos_f32 (device_common.h sample_dir<FAST>)
 #ifndef TEXIR_IRT_FAST_SINCOS
-#define TEXIR_IRT_FAST_SINCOS 1
+#define TEXIR_IRT_FAST_SINCOS 0
 #endif
 
 // One texel per wave: the 64 lanes trace 64 samples of the texel per pass (any N, binary or 4-wide tree).  Kept as the

@@ -701,7 +701,12 @@ __global__ __launch_bounds__(256) void adam_tex_kernel(float* __restrict__ p, co
     }
 }
 
-// The same step with 16-byte accesses: a block owns EPB consecutive floats of a row pair (EPB = the largest multiple of 2C <= 1024, so
+// floats of a row pair one block of adam_tex_vec_kernel owns: the largest multiple of BOTH 2C (no 2x2 texel block straddles two blocks) and 32
+// (a block's segment starts and ends on a 128-byte line: with 1020 floats per block -- the largest multiple of 6 -- every segment boundary of
+// the 3-channel texture split a line between two blocks, i.e. two CUs / XCDs each wrote part of it) that fits 256 threads x one float4
+constexpr int adam_vec_epb(int C) { return C == 3 ? 960 : (1024 / (2 * C)) * (2 * C); }
+
+// The same step with 16-byte accesses: a block owns EPB consecutive floats of a row pair (adam_vec_epb, so
 // that no 2x2 texel block straddles two blocks), every thread one float4 of each row; the level-1 gradient segment and the updated
 // texels go through LDS so that the level-1 texels come out in the mip build's own summation order ((p00 + p01) + p10) + p11.
 // Needs W*C % 4 == 0 (16-byte aligned rows); launch_adam_tex falls back to adam_tex_kernel otherwise.  Identical bits.
@@ -711,7 +716,7 @@ __global__ __launch_bounds__(256) void adam_tex_vec_kernel(float* __restrict__ p
                                                            int H, int W, float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float lo, float hi, const float* __restrict__ hyp)
 {
     if (hyp) { step_size = hyp[0]; bc2_sqrt = hyp[1]; }
-    constexpr int EPB = (1024 / (2 * C)) * (2 * C);
+    constexpr int EPB = adam_vec_epb(C);
     __shared__ float g1s[EPB / 2];
     __shared__ float ps[2][EPB];
     const int row_elems = W * C, Wh = W >> 1, Hh = H >> 1;
@@ -778,8 +783,9 @@ hipError_t launch_adam_tex(float* p, const float* g, const uint32_t* l0_mask, co
         bc2_sqrt = (float)sqrt(bc2);
     }
     if ((W * C) % 4 == 0 && !getenv("TEXIR_ADAM_SCALAR")) {
-        const int epb = (1024 / (2 * C)) * (2 * C);
+        const int epb = adam_vec_epb(C);
         dim3 gridv((W * C + epb - 1) / epb, (H >> 1) > 2048 ? 2048 : (H >> 1));
+        if (const char* e = getenv("TEXIR_ADAM_GRID_Y")) { const int v = atoi(e); if (v >= 1 && v < (int)gridv.y) gridv.y = v; }      // (probe: fewer, longer blocks leave wave slots to a concurrent kernel)
         if (C == 1) hipLaunchKernelGGL(adam_tex_vec_kernel<1>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp);
         else if (C == 2) hipLaunchKernelGGL(adam_tex_vec_kernel<2>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp);
         else if (C == 3) hipLaunchKernelGGL(adam_tex_vec_kernel<3>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp);

@@ -13,8 +13,18 @@ class GraphedMatStep:
         if step_in_graph is None:
             import torch.distributed as dist
             step_in_graph = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        import os
+        if os.environ.get("TEXIR_GRAPH_STEP") == "0":        # A/B switch: optimiser step launched eagerly after the replay (round 2)
+            step_in_graph = False
         self.step_in_graph = bool(step_in_graph) and hasattr(optimizer, "note_replayed_step")
         self.stepped = {}
+        # The GGX shifts of a step are drawn on the host (CPU generator, as the reference) into a PINNED buffer of the view, and the recorded
+        # kernels read that host memory directly (pinned allocations are mapped into the device's address space): no staging copy sits between
+        # the draw and the replay (0.8 MB per step: 98 304 x 2 floats, read once by the forward and once by the backward over the host
+        # link, hidden inside the 220 us specular kernel).  One buffer per captured view, so the next step's shifts can be written while the
+        # current step still runs.  TEXIR_SHIFT_ZEROCOPY=0 keeps round 2's device buffer + async copy through a pinned ring.
+        self.zero_copy = os.environ.get("TEXIR_SHIFT_ZEROCOPY", "1") != "0"
+        self.shift_bufs = {}
         self.graphs, self.losses, self.outs, self.pool = {}, {}, {}, None
         self.side = torch.cuda.Stream()
         import os
@@ -54,6 +64,8 @@ class GraphedMatStep:
         P = gt.shape[0] * gt.shape[1] * gt.shape[2]
         if self.static_shift is None:
             self.static_shift = torch.zeros((P, 2), device=gt.device)
+        if self.zero_copy and key not in self.shift_bufs:
+            self.shift_bufs[key] = [torch.zeros((P, 2), dtype=torch.float32).pin_memory(), torch.cuda.Event(), False]
         inp = (mvp, cam, gt, gmask, seg, fm, room, key)
         self.model._static_shift = None
         rng_state = torch.get_rng_state()               # warm-up must not consume the CPU-generator stream of the training run
@@ -61,7 +73,7 @@ class GraphedMatStep:
         torch.set_rng_state(rng_state)
         if hasattr(self.opt, "prepare"):
             self.opt.prepare()                          # moments + device-resident step records exist before the capture
-        self.model._static_shift = self.static_shift
+        self.model._static_shift = self.shift_bufs[key][0] if self.zero_copy else self.static_shift
         import gc
         from .scene import defer_destroy
         gc.collect()                                    # finalisers (hipFree of dead scenes/tensors) must not run inside the capture
@@ -105,6 +117,17 @@ class GraphedMatStep:
         P = self.static_shift.shape[0]
         return torch.rand(P, 1, 2).reshape(P, 2)
 
+    def stage_shift(self, key, shift):
+        """write the shifts of the NEXT step on view `key` where its recorded kernels will read them.  Callers that know the next view may call
+        this right after launching a step (then pass staged=True to step()): the host-side copy then overlaps the GPU work."""
+        if not self.zero_copy:
+            return self._stage_shift(shift)
+        buf, ev, pending = self.shift_bufs[key]
+        if pending:
+            ev.synchronize()                 # the previous replay of this view has finished reading the buffer
+            self.shift_bufs[key][2] = False
+        buf.copy_(shift)
+
     def _stage_shift(self, shift):
         """host -> device copy of the step's shifts through a ring of pinned buffers.  The copy is asynchronous, so a staging buffer
         may only be rewritten once ITS previous copy has run: each slot carries an event recorded right after its copy, and a slot is
@@ -123,12 +146,13 @@ class GraphedMatStep:
         self._ring_used[i] = True
         self._ring_next = (i + 1) % len(self._ring)
 
-    def step(self, key, stage, reduce_grads=None, shift=None):
-        """one optimiser step on a captured view; returns the (static) loss tensor of that graph"""
-        if stage != 0:                                  # stage 0 is Lambertian only: the reference draws no shifts there
+    def step(self, key, stage, reduce_grads=None, shift=None, staged=False):
+        """one optimiser step on a captured view; returns the (static) loss tensor of that graph.  staged=True: the caller has already put
+        this step's shifts in place (stage_shift)"""
+        if stage != 0 and not staged:                   # stage 0 is Lambertian only: the reference draws no shifts there
             if shift is None:
                 shift = self.draw_shift()
-            self._stage_shift(shift)
+            self.stage_shift(key, shift)
         # the captured forward may build only mip levels 2.. (level 1 comes from the previous optimiser step, optim.FusedAdam): if the
         # texture was changed any other way since, rebuild the stack eagerly before replaying
         from .texture import refresh_mips
@@ -138,6 +162,9 @@ class GraphedMatStep:
         if hasattr(self.opt, "prepare"):
             self.opt.prepare()                         # a learning-rate scheduler's change reaches the device record here
         self.graphs[(key, stage)].replay()
+        if self.zero_copy and key in self.shift_bufs:
+            self.shift_bufs[key][1].record()
+            self.shift_bufs[key][2] = True
         if self.stepped[(key, stage)] is not None:
             self.opt.note_replayed_step(self.stepped[(key, stage)])      # the replay contained the optimiser step
             return self.losses[(key, stage)]

@@ -186,8 +186,14 @@ def spec_render(scene, normal, albedo, roughness, points, irr, cam_position, shi
     P = normal.reshape(-1, 3).shape[0]
     f = lambda t, s: t.to(device=dev, dtype=torch.float32).reshape(*s).contiguous()
     S = int(num_samples)
+    # a PINNED host tensor as `shift` is handed to the kernels as it is: pinned allocations are mapped into the device's address space, and a
+    # recorded hipGraph (graph_step.py) can then read each step's freshly drawn shifts without a staging copy
+    if torch.is_tensor(shift) and shift.device.type == "cpu" and shift.is_pinned() and shift.dtype == torch.float32 and shift.is_contiguous() and shift.numel() == 2 * P:
+        sh = shift.reshape(P, 2)
+    else:
+        sh = f(shift, (P, 2))
     return _SpecRender.apply(scene, f(normal, (P, 3)), f(albedo, (P, 3)), f(roughness, (P,)), f(points, (P, 3)), f(irr, (P, 3)),
-                             f(cam_position, (3,)), f(shift, (P, 2)), S, float(clamp_eps), None if lighting is None else f(lighting, (P, S, 3)))
+                             f(cam_position, (3,)), sh, S, float(clamp_eps), None if lighting is None else f(lighting, (P, S, 3)))
 
 
 def diffuse_irradiance(scene, points, normals, shift, num_samples, sample_type="uniform"):

@@ -78,7 +78,7 @@ int main(int argc, char** argv)
     std::string dir = argv[1];
     int n_groups = argc > 2 ? atoi(argv[2]) : 64, n_pass = argc > 3 ? atoi(argv[3]) : 64;
     bool cull = false, cull8 = false, nosort = false, psort3 = false; int policy = 0; double alpha = 1.0, alpha2 = 1.0, tricost = 1.5; int refillK = 0; int spec = 0;
-    for (int i = 4; i < argc; i++) { if (!strcmp(argv[i], "cull")) cull = true; if (!strcmp(argv[i], "cull8")) cull = cull8 = true; if (!strcmp(argv[i], "nosort")) nosort = true; if (!strcmp(argv[i], "psort3")) psort3 = true; if (!strcmp(argv[i], "spec")) spec = 1; if (!strcmp(argv[i], "spec2")) spec = 2; if (!strncmp(argv[i], "refill:", 7)) refillK = atoi(argv[i] + 7); if (!strncmp(argv[i], "maj", 3)) { policy = 1; if (argv[i][3] == ':') { alpha = alpha2 = atof(argv[i] + 4); const char* c2 = strchr(argv[i] + 4, ','); if (c2) alpha2 = atof(c2 + 1); } } if (!strncmp(argv[i], "tricost:", 8)) tricost = atof(argv[i] + 8); }
+    for (int i = 4; i < argc; i++) { if (!strcmp(argv[i], "cull")) cull = true; if (!strcmp(argv[i], "cull8")) cull = cull8 = true; if (!strcmp(argv[i], "nosort")) nosort = true; if (!strcmp(argv[i], "psort3")) psort3 = true; if (!strcmp(argv[i], "spec")) spec = 1; if (!strcmp(argv[i], "spec2")) spec = 2; if (!strncmp(argv[i], "refill:", 7)) refillK = atoi(argv[i] + 7); if (!strncmp(argv[i], "arr", 3)) { policy = 2; if (argv[i][3] == ':') { alpha = alpha2 = atof(argv[i] + 4); const char* c2 = strchr(argv[i] + 4, ','); if (c2) alpha2 = atof(c2 + 1); } } if (!strncmp(argv[i], "maj", 3)) { policy = 1; if (argv[i][3] == ':') { alpha = alpha2 = atof(argv[i] + 4); const char* c2 = strchr(argv[i] + 4, ','); if (c2) alpha2 = atof(c2 + 1); } } if (!strncmp(argv[i], "tricost:", 8)) tricost = atof(argv[i] + 8); }
     auto verts = load<float>(dir + "/verts.f32"); auto tris = load<int32_t>(dir + "/tris.i32"); auto uvs = load<float>(dir + "/tri_uvs.f32");
     auto pos = load<float>(dir + "/pos.f32"); auto nrm = load<float>(dir + "/nrm.f32"); auto shift = load<float>(dir + "/shift.f32");
     auto ids = load<int32_t>(dir + "/ids.i32"); auto meta = load<int32_t>(dir + "/meta.i32");
@@ -287,7 +287,7 @@ int main(int argc, char** argv)
                 };
                 // scheduling policy: 0 = the kernel's while-while (node phase until no lane holds an inner node, then leaf phase until no lane holds a leaf);
                 // 1 = per step, the phase with more waiting lanes (node lanes weighted by `alpha`)
-                int phase = 0;
+                int phase = 0, prev_nl = 0;
                 for (;;) {
                     int nn = 0, nl = 0;
                     int nl_any = 0;
@@ -304,7 +304,17 @@ int main(int argc, char** argv)
                     if (!nn && !nl) break;
                     int want;
                     if (policy == 0) want = phase == 0 ? (nn ? 0 : 1) : (nl ? 1 : 0);
-                    else want = !nn ? 1 : (!nl_any ? 0 : ((double)nn * (phase == 0 ? alpha : alpha2) >= (double)nl ? 0 : 1));
+                    else if (policy == 1) want = !nn ? 1 : (!nl_any ? 0 : ((double)nn * (phase == 0 ? alpha : alpha2) >= (double)nl ? 0 : 1));
+                    else {
+                        // policy 2 ("arrivals"): node steps while lanes keep ARRIVING at leaves (the batch is still growing) and the node lanes are the
+                        // weighted majority (alpha); once a node step brought no new leaf lane, the batch is taken if it holds at least nn / alpha2 lanes
+                        const bool grew = nl > prev_nl;
+                        if (!nn) want = 1; else if (!nl_any) want = 0;
+                        else if ((double)nl >= (double)nn * 1.0) want = 1;                     // leaf lanes are the plain majority
+                        else if (!grew && phase == 0 && (double)nl * alpha2 >= (double)nn) want = 1;
+                        else want = ((double)nn * alpha >= (double)nl) ? 0 : 1;
+                    }
+                    prev_nl = (want == 1) ? 0 : nl;
                     if (want != phase || c.rays == 0) c.rounds += 0.5;
                     phase = want;
                     if (phase == 0) node_step(); else leaf_step();

@@ -8,6 +8,7 @@ from texir_code_amd import _lib, scene as S
 
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
+torch.set_num_threads(1)
 sc0, pos, nrm, valid, shift, res, spp = bench.make_workload("c4")
 sc = S.Scene(sc0["verts"], sc0["tris"], sc0["tri_uvs"], sc0["hdr"], device=0)
 irr = torch.rand(res * res, 3, device=dev)
@@ -55,3 +56,9 @@ print("adam alone      %.1f us" % timeit(lambda: adam(s1)))
 print("serial          %.1f us" % timeit(lambda: (spec(s1), adam(s1))))
 print("two streams     %.1f us" % timeit(lambda: (spec(s1), adam(s2))))
 print("two streams rev %.1f us" % timeit(lambda: (adam(s2), spec(s1))))
+for gy in (1024, 256, 128, 85, 64, 43, 32, 21):
+    os.environ["TEXIR_ADAM_GRID_Y"] = str(gy)
+    print("adam grid.y %4d (%5d blocks): alone %.1f us, with spec on a second stream %.1f us (adam first), %.1f us (spec first)"
+          % (gy, 12 * gy, timeit(lambda: adam(s1)), timeit(lambda: (adam(s2), spec(s1))), timeit(lambda: (spec(s1), adam(s2)))))
+
+
