@@ -77,6 +77,9 @@ def make_workload(name, cache=None):
         z = np.load(path)
         sc0 = {k: z[k] for k in ("verts", "tris", "tri_uvs", "hdr", "tri_class")}
         sc0.update({"T": T, "style": style, "seed": 666})
+        if "patch_rects" in z:               # the charts' atlas rectangles: all the material leg needs of the patch list (synth.make_gt_materials)
+            import types
+            sc0["patches"] = [types.SimpleNamespace(rect=tuple(float(x) for x in r)) for r in z["patch_rects"]]
         return sc0, z["pos"], z["nrm"], z["valid"], z["shift"], res, spp
     sc0 = synth.make_scene(T, seed=666, tex_res=tex_res, style=style)
     pos, nrm, valid = synth.make_texel_gbuffer(sc0, res)
@@ -84,7 +87,8 @@ def make_workload(name, cache=None):
     if path:
         os.makedirs(cache, exist_ok=True)
         tmp = path + ".tmp%d.npz" % os.getpid()
-        np.savez(tmp, pos=pos, nrm=nrm, valid=valid, shift=shift, **{k: sc0[k] for k in ("verts", "tris", "tri_uvs", "hdr", "tri_class")})
+        np.savez(tmp, pos=pos, nrm=nrm, valid=valid, shift=shift, patch_rects=np.array([p.rect for p in sc0["patches"]], np.float64),
+                 **{k: sc0[k] for k in ("verts", "tris", "tri_uvs", "hdr", "tri_class")})
         os.replace(tmp, path)
     return sc0, pos, nrm, valid, shift, res, spp
 

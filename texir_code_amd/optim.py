@@ -52,18 +52,24 @@ class FusedAdam(torch.optim.Optimizer):
         capture and before every replay (cheap: compares floats, launches something only when a scheduler has changed a learning rate)"""
         for group in self.param_groups:
             for p in group["params"]:
-                if p.is_cuda:
-                    st = self.state[p]
-                    if not st:
-                        st["step"] = 0
-                        st["exp_avg"] = torch.zeros_like(p)
-                        st["exp_avg_sq"] = torch.zeros_like(p)
+                if p.is_cuda and p.requires_grad:            # (frozen members of the model -- the irradiance texture -- get no moments)
+                    self._ensure_state(p)
         for device in {p.device for g in self.param_groups for p in g["params"] if p.is_cuda}:
             d = self._records(device)
             for i, g in enumerate(d["groups"]):
                 if float(g["lr"]) != d["lr"][i]:
                     d["state"][i, 1] = float(g["lr"])
                     d["lr"][i] = float(g["lr"])
+
+    def _ensure_state(self, p):
+        st = self.state[p]
+        if not st:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.TexirError("FusedAdam moments must exist before hipGraph capture (call prepare() first)")
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p)
+            st["exp_avg_sq"] = torch.zeros_like(p)
+        return st
 
     def load_state_dict(self, sd):
         super().load_state_dict(sd)
@@ -178,7 +184,7 @@ class FusedAdam(torch.optim.Optimizer):
             _lib.check(L.texir_adam_tick(_lib.ptr(d["state"]), _lib.ptr(d["hyper"]), d["state"].shape[0], mask, _lib.stream_ptr()))
         for group, p, g1 in todo:
             b1, b2 = group["betas"]
-            st = self.state[p]
+            st = self._ensure_state(p)
             if _count_on_host:
                 st["step"] += 1
             hyper = self._dev[p.device]["hyper"][self._rec[id(p)]]

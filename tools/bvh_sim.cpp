@@ -68,7 +68,7 @@ static uint32_t sample_index(uint32_t cell, int log2N)
 
 struct Ray { float o[3], d[3], id[3], ood[3]; float t; int slot; int node; int pleaf = 0; std::vector<int> stk; std::vector<float> stk_t; };
 
-struct Counters { double rays = 0, nodes = 0, tris = 0, wnode = 0, wtri = 0, culled = 0, hits = 0, wcull = 0, maxsp = 0, wuni = 0, wuni0 = 0, wdeep[4] = {0, 0, 0, 0}, lines = 0, wmaxn = 0, rounds = 0, wmaxt = 0, refills = 0, refill_lanes = 0, spread = 0, specpops = 0; };
+struct Counters { double rays = 0, nodes = 0, tris = 0, wnode = 0, wtri = 0, culled = 0, hits = 0, wcull = 0, maxsp = 0, wuni = 0, wuni0 = 0, wdeep[4] = {0, 0, 0, 0}, lines = 0, wmaxn = 0, rounds = 0, wmaxt = 0, refills = 0, refill_lanes = 0, spread = 0, specpops = 0, dh[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dl[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };
 
 static const int kSent = 0x7FFFFFFF;
 
@@ -77,8 +77,8 @@ int main(int argc, char** argv)
     if (argc < 2) { fprintf(stderr, "usage: bvh_sim <dir> [groups=64] [passes=64] [variant flags: cull cull8 nosort]\n"); return 1; }
     std::string dir = argv[1];
     int n_groups = argc > 2 ? atoi(argv[2]) : 64, n_pass = argc > 3 ? atoi(argv[3]) : 64;
-    bool cull = false, cull8 = false, nosort = false, psort3 = false; int policy = 0; double alpha = 1.0, alpha2 = 1.0, tricost = 1.5; int refillK = 0; int spec = 0;
-    for (int i = 4; i < argc; i++) { if (!strcmp(argv[i], "cull")) cull = true; if (!strcmp(argv[i], "cull8")) cull = cull8 = true; if (!strcmp(argv[i], "nosort")) nosort = true; if (!strcmp(argv[i], "psort3")) psort3 = true; if (!strcmp(argv[i], "spec")) spec = 1; if (!strcmp(argv[i], "spec2")) spec = 2; if (!strncmp(argv[i], "refill:", 7)) refillK = atoi(argv[i] + 7); if (!strncmp(argv[i], "arr", 3)) { policy = 2; if (argv[i][3] == ':') { alpha = alpha2 = atof(argv[i] + 4); const char* c2 = strchr(argv[i] + 4, ','); if (c2) alpha2 = atof(c2 + 1); } } if (!strncmp(argv[i], "maj", 3)) { policy = 1; if (argv[i][3] == ':') { alpha = alpha2 = atof(argv[i] + 4); const char* c2 = strchr(argv[i] + 4, ','); if (c2) alpha2 = atof(c2 + 1); } } if (!strncmp(argv[i], "tricost:", 8)) tricost = atof(argv[i] + 8); }
+    bool cull = false, cull8 = false, nosort = false, psort3 = false; int policy = 0; double alpha = 1.0, alpha2 = 1.0, tricost = 1.5; int refillK = 0; int spec = 0; int switch_after = 0;
+    for (int i = 4; i < argc; i++) { if (!strcmp(argv[i], "cull")) cull = true; if (!strcmp(argv[i], "cull8")) cull = cull8 = true; if (!strcmp(argv[i], "nosort")) nosort = true; if (!strcmp(argv[i], "psort3")) psort3 = true; if (!strncmp(argv[i], "after:", 6)) switch_after = atoi(argv[i] + 6); if (!strcmp(argv[i], "spec")) spec = 1; if (!strcmp(argv[i], "spec2")) spec = 2; if (!strncmp(argv[i], "refill:", 7)) refillK = atoi(argv[i] + 7); if (!strncmp(argv[i], "arr", 3)) { policy = 2; if (argv[i][3] == ':') { alpha = alpha2 = atof(argv[i] + 4); const char* c2 = strchr(argv[i] + 4, ','); if (c2) alpha2 = atof(c2 + 1); } } if (!strncmp(argv[i], "maj", 3)) { policy = 1; if (argv[i][3] == ':') { alpha = alpha2 = atof(argv[i] + 4); const char* c2 = strchr(argv[i] + 4, ','); if (c2) alpha2 = atof(c2 + 1); } } if (!strncmp(argv[i], "tricost:", 8)) tricost = atof(argv[i] + 8); }
     auto verts = load<float>(dir + "/verts.f32"); auto tris = load<int32_t>(dir + "/tris.i32"); auto uvs = load<float>(dir + "/tri_uvs.f32");
     auto pos = load<float>(dir + "/pos.f32"); auto nrm = load<float>(dir + "/nrm.f32"); auto shift = load<float>(dir + "/shift.f32");
     auto ids = load<int32_t>(dir + "/ids.i32"); auto meta = load<int32_t>(dir + "/meta.i32");
@@ -232,6 +232,12 @@ int main(int argc, char** argv)
                             if (uni && still_uni) c.wuni0++; else still_uni = false;
                             if (deep + 3 > 8) c.wdeep[0]++; if (deep + 3 > 10) c.wdeep[1]++; if (deep + 3 > 11) c.wdeep[2]++; if (deep + 3 > 16) c.wdeep[3]++;
                             std::sort(ln.begin(), ln.end()); c.lines += (double)(std::unique(ln.begin(), ln.end()) - ln.begin());
+                            {   // histogram of DISTINCT NODES per wave-level step (and of the lanes that take part), bucket = min(distinct, 8) - 1
+                                std::vector<int> nd; for (auto& r : R) if (r.node >= 0 && r.node != kSent) nd.push_back(r.node);
+                                const int lanes = (int)nd.size();
+                                std::sort(nd.begin(), nd.end()); const int dn = (int)(std::unique(nd.begin(), nd.end()) - nd.begin());
+                                const int bk = std::min(dn, 8) - 1; c.dh[bk] += 1; c.dl[bk] += lanes;
+                            }
                         }
                         for (auto& r : R) {
                             if (!(r.node >= 0 && r.node != kSent)) continue;
@@ -287,8 +293,9 @@ int main(int argc, char** argv)
                 };
                 // scheduling policy: 0 = the kernel's while-while (node phase until no lane holds an inner node, then leaf phase until no lane holds a leaf);
                 // 1 = per step, the phase with more waiting lanes (node lanes weighted by `alpha`)
-                int phase = 0, prev_nl = 0;
+                int phase = 0, prev_nl = 0, sched_iter = -1;
                 for (;;) {
+                    sched_iter++;
                     int nn = 0, nl = 0;
                     int nl_any = 0;
                     for (auto& r : R) { if (r.pleaf) nl_any++; if (r.node == kSent) { if (r.pleaf) nl++; continue; } if (r.node >= 0) nn++; else { nl++; if (!r.pleaf) nl_any++; } }
@@ -304,7 +311,7 @@ int main(int argc, char** argv)
                     if (!nn && !nl) break;
                     int want;
                     if (policy == 0) want = phase == 0 ? (nn ? 0 : 1) : (nl ? 1 : 0);
-                    else if (policy == 1) want = !nn ? 1 : (!nl_any ? 0 : ((double)nn * (phase == 0 ? alpha : alpha2) >= (double)nl ? 0 : 1));
+                    else if (policy == 1) want = !nn ? 1 : (!nl_any ? 0 : ((double)nn * (switch_after > 0 ? (sched_iter < switch_after ? alpha : alpha2) : (phase == 0 ? alpha : alpha2)) >= (double)nl ? 0 : 1));
                     else {
                         // policy 2 ("arrivals"): node steps while lanes keep ARRIVING at leaves (the batch is still growing) and the node lanes are the
                         // weighted majority (alpha); once a node step brought no new leaf lane, the batch is taken if it holds at least nn / alpha2 lanes
@@ -324,7 +331,7 @@ int main(int argc, char** argv)
             }
         }
 #pragma omp critical
-        { tot.rays += c.rays; tot.nodes += c.nodes; tot.tris += c.tris; tot.wnode += c.wnode; tot.wtri += c.wtri; tot.culled += c.culled; tot.hits += c.hits; tot.wuni += c.wuni; tot.wuni0 += c.wuni0; tot.lines += c.lines; tot.wmaxn += c.wmaxn; tot.wmaxt += c.wmaxt; tot.rounds += c.rounds; tot.refills += c.refills; tot.refill_lanes += c.refill_lanes; tot.spread += c.spread; for (int q = 0; q < 4; q++) tot.wdeep[q] += c.wdeep[q]; if (c.maxsp > tot.maxsp) tot.maxsp = c.maxsp; }
+        { tot.rays += c.rays; tot.nodes += c.nodes; tot.tris += c.tris; tot.wnode += c.wnode; tot.wtri += c.wtri; tot.culled += c.culled; tot.hits += c.hits; tot.wuni += c.wuni; tot.wuni0 += c.wuni0; tot.lines += c.lines; tot.wmaxn += c.wmaxn; tot.wmaxt += c.wmaxt; tot.rounds += c.rounds; for (int q = 0; q < 8; q++) { tot.dh[q] += c.dh[q]; tot.dl[q] += c.dl[q]; } tot.refills += c.refills; tot.refill_lanes += c.refill_lanes; tot.spread += c.spread; for (int q = 0; q < 4; q++) tot.wdeep[q] += c.wdeep[q]; if (c.maxsp > tot.maxsp) tot.maxsp = c.maxsp; }
     }
     double wr = tot.rays / 64.0;
     printf("per ray: %.2f node visits, %.2f tri tests, %.2f culled pops, hit %.4f, max stack %.0f\n", tot.nodes / tot.rays, tot.tris / tot.rays, tot.culled / tot.rays, tot.hits / tot.rays, tot.maxsp);
@@ -332,7 +339,8 @@ int main(int argc, char** argv)
     printf("wave node steps: %.3f uniform (%.3f in the initial all-uniform run), %.2f distinct node lines per step; steps whose push could pass 8/10/11/16 entries: %.4f %.4f %.4f %.4f\n", tot.wuni / tot.wnode, tot.wuni0 / tot.wnode, tot.lines / tot.wnode,
            tot.wdeep[0] / tot.wnode, tot.wdeep[1] / tot.wnode, tot.wdeep[2] / tot.wnode, tot.wdeep[3] / tot.wnode);
     printf("per pass: max-lane node visits %.2f, max-lane tri tests %.2f, while-while rounds %.2f\n", tot.wmaxn / wr, tot.wmaxt / wr, tot.rounds / wr);
-    if (tot.refills > 0) printf("refill events per 64 rays %.3f (lanes per event %.1f, pass spread at refill %.1f)\n", tot.refills / wr, tot.refill_lanes / tot.refills, tot.spread / tot.refills);
+    printf("distinct nodes per wave-level node step (share of steps : mean lanes taking part):"); for (int q = 0; q < 8; q++) printf(" %d%s %.3f:%.1f", q + 1, q == 7 ? "+" : "", tot.dh[q] / tot.wnode, tot.dh[q] > 0 ? tot.dl[q] / tot.dh[q] : 0.0); printf("\n");
+    if (tot.refills > 0) printf("refill events per 64 rays %.3f (lanes per event %.1f, pass spread at refill %.1f); cost incl. %.1f per refill event: %.2f per pass\n", tot.refills / wr, tot.refill_lanes / tot.refills, tot.spread / tot.refills, 2.6, tot.wnode / wr + tricost * tot.wtri / wr + 2.6 * tot.refills / wr);
     printf("cost model (node step 1, triangle test %.2f): %.2f per pass\n", tricost, tot.wnode / wr + tricost * tot.wtri / wr);
     return 0;
 }

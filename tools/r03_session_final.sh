@@ -1,0 +1,22 @@
+#!/bin/bash
+# round-3 final GPU session: GPU suite, PMC passes of c1 (c4 / c2 / c4_scan: sessions 7 / 8, same kernel sources), kernel-trace stats of the default bench,
+# material-step trace + PMC, bench lines (default incl. c4_scan, c2, c1)
+R=${GRAFT_REPO_ROOT:-/root/repo}
+out=$R/gpurun_out/r03_final
+mkdir -p $out
+cd $R
+export TEXIR_SYNTH_CACHE=/tmp/texir_synth
+timeout 3000 python -m pytest tests -m gpu -q > $out/pytest_gpu.txt 2>&1
+tail -n 3 $out/pytest_gpu.txt | cut -c1-200
+bash tools/profile_round.sh r03_final/prof c1 > $out/profile_round.log 2>&1
+tail -n 2 $out/profile_round.log | cut -c1-300
+cp $R/profiles/pmc_c1.json $out/ 2>/dev/null
+bash tools/trace_mat_step.sh > $out/mat_step_trace.txt 2>&1
+tail -n 3 $out/mat_step_trace.txt | cut -c1-110
+bash tools/mat_step_pmc.sh r03_final/matpmc > $out/mat_pmc.log 2>&1
+head -n 1 $out/mat_pmc.log | cut -c1-300
+timeout 900 python bench.py > $out/bench_default.json 2> $out/bench_default.err
+tail -n 1 $out/bench_default.json | cut -c1-300
+timeout 600 python bench.py --workload c2 > $out/bench_c2.json 2>> $out/bench_default.err
+timeout 600 python bench.py --workload c1 --steps 5 --warmup 1 > $out/bench_c1.json 2>> $out/bench_default.err
+tail -n 1 $out/bench_c1.json | cut -c1-200
