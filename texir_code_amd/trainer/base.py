@@ -27,6 +27,8 @@ class RunnerBase:
         self.GPU_INDEX = kwargs["gpu_index"]
         self.expname = prefix + "-" + kwargs["expname"]
         self.expdir = os.path.join(exps_root, self.exps_folder_name, self.expname)
+        # earlier runs of this experiment, listed BEFORE this run's own directory is made (`--is_continue --timestamp latest` picks the last one)
+        self.prior_timestamps = sorted(os.listdir(self.expdir)) if os.path.isdir(self.expdir) else []
         self.timestamp = "{:%Y_%m_%d_%H_%M_%S}".format(datetime.now())
         self.plots_dir = os.path.join(self.expdir, self.timestamp, "plots")
         self.checkpoints_path = os.path.join(self.expdir, self.timestamp, "checkpoints")

@@ -21,8 +21,7 @@ class IRRFTrainRunner(RunnerBase):
         self.is_hdr_texture = self.conf.get_bool("train.is_hdr_texture")
         is_continue, timestamp = kwargs["is_continue"], kwargs["timestamp"]
         if is_continue and timestamp == "latest":
-            stamps = sorted(t for t in os.listdir(self.expdir) if t != self.timestamp) if os.path.exists(self.expdir) else []
-            is_continue, timestamp = (True, stamps[-1]) if stamps else (False, None)
+            is_continue, timestamp = (True, self.prior_timestamps[-1]) if self.prior_timestamps else (False, None)
 
         print("Loading training data ...")
         path_mesh = self.conf.get_string("train.path_mesh_open3d")
