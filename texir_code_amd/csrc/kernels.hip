@@ -544,7 +544,11 @@ IrtPlan irt_plan(const SceneDev& sc, int64_t n_ids, int N)
     p.width = sc.nodes4 ? 4 : 2;
     p.per_wave = !sc.nodes4 ? 1 : (forced ? forced : (n_ids >= 32768 ? 64 : 1));
     p.log2parts = 0;
-    if (sc.nodes4 && p.per_wave == 64 && pow2) { while (p.log2parts < 5 && (N >> (p.log2parts + 1)) >= 64) p.log2parts++; }
+    // parts per texel: up to 32, down to 8 passes per part (N = 2048: 32 parts of 64 passes; N = 64 -- the reference's own configuration -- 8 parts of 8:
+    // with 64-pass parts its 3 053 chunks left two thirds of the 8 192 resident waves without work).  A function of N alone.
+    int min_cells = 8;
+    if (const char* e = getenv("TEXIR_IRT_MIN_PART_CELLS")) { const int v = atoi(e); if (v >= 1) min_cells = v; }       // A/B switch (round 2: 64)
+    if (sc.nodes4 && p.per_wave == 64 && pow2) { while (p.log2parts < 5 && (N >> (p.log2parts + 1)) >= min_cells) p.log2parts++; }
     if (const char* cap = getenv("TEXIR_IRT_LOG2PARTS")) { if (p.log2parts > atoi(cap)) p.log2parts = atoi(cap) < 0 ? 0 : atoi(cap); }   // A/B switch
     snprintf(p.name, sizeof(p.name), p.per_wave == 64 ? "irt_group_kernel<false, %d, 6>" : "irt_kernel<false, %d>", p.width);
     return p;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-3 final GPU session: GPU suite, PMC passes of c1 (c4 / c2 / c4_scan: sessions 7 / 8, same kernel sources), kernel-trace stats of the default bench,
+# round-3 final GPU session: GPU suite, PMC passes of c4 / c2 / c4_scan / c1, kernel-trace stats of the default bench,
 # material-step trace + PMC, bench lines (default incl. c4_scan, c2, c1)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/r03_final
@@ -8,9 +8,9 @@ cd $R
 export TEXIR_SYNTH_CACHE=/tmp/texir_synth
 timeout 3000 python -m pytest tests -m gpu -q > $out/pytest_gpu.txt 2>&1
 tail -n 3 $out/pytest_gpu.txt | cut -c1-200
-bash tools/profile_round.sh r03_final/prof c1 > $out/profile_round.log 2>&1
+bash tools/profile_round.sh r03_final/prof c4 c2 c4_scan c1 > $out/profile_round.log 2>&1
 tail -n 2 $out/profile_round.log | cut -c1-300
-cp $R/profiles/pmc_c1.json $out/ 2>/dev/null
+cp $R/profiles/pmc_c4.json $R/profiles/pmc_c2.json $R/profiles/pmc_c4_scan.json $R/profiles/pmc_c1.json $out/ 2>/dev/null
 bash tools/trace_mat_step.sh > $out/mat_step_trace.txt 2>&1
 tail -n 3 $out/mat_step_trace.txt | cut -c1-110
 bash tools/mat_step_pmc.sh r03_final/matpmc > $out/mat_pmc.log 2>&1
