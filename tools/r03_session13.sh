@@ -1,4 +1,5 @@
 #!/bin/bash
+# (session 13 and tools/trace_mat_pipeline.sh ran on a tree with tools/experiments/pipelined_material_step.patch applied: the pipelined step is not in the product)
 # round-3 GPU session 13: the pipelined material step -- 4k-texture trajectory test (eager == graph == split == pipelined), bench A/B
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/r03_s13
