@@ -62,6 +62,10 @@ TEXIR_API int texir_scene_set_texture(texir_scene* scene, const float* tex, int3
 /* out[0]=inner nodes of the traversal tree (4-wide quantised by default), [1]=triangles, [2]=max depth, [3]=node bytes,
  * [4]=triangle bytes, [5]=uv bytes, [6]=texture bytes, [7]=device */
 TEXIR_API int texir_scene_info(const texir_scene* scene, int64_t out[8]);
+/* The traversal's phase scheduler weighs the lanes at inner nodes against the lanes at leaves (csrc/device_common.h); the weight is a property of the
+ * scene, decided by the first long texir_irt_generate call on it from the measured fullness of its node steps (out[1], -1 = not measured;
+ * out[0] = the weight in use: 0 = not decided yet -> 2).  Speed only: results never depend on it. */
+TEXIR_API int texir_scene_scheduler(const texir_scene* scene, double out[2]);
 
 /* Replaces query_irf (models/tracer_o3d_irt.py:240-269, models/mat_nvdiffrast.py:292-320):
  * closest hit (Embree semantics: t>0, t in units of |dir|), hit mask t>t_min (reference: 1e-4) & finite,

@@ -18,7 +18,7 @@ using namespace texir;
 
 struct texir_scene {
     int device = 0;
-    SceneDev dev{};
+    mutable SceneDev dev{};              // (mutable: the scheduler weight is decided by the first long launch on the -- otherwise immutable -- scene)
     void* d_nodes4 = nullptr; void* d_nodes4f = nullptr;
     void* d_nodes = nullptr; void* d_tris = nullptr; void* d_uvs = nullptr; float* d_tex = nullptr;
     float* d_tex_tiled = nullptr;        // retiled copy read by the hit shader (texture layouts 1, 2); d_tex stays the row-major master
@@ -33,6 +33,8 @@ struct texir_scene {
     static constexpr int kWorkSlots = 64;
     unsigned long long* d_work = nullptr;
     mutable std::atomic<unsigned> work_next{0};      // (launching on an immutable scene still advances the slot)
+    mutable std::atomic<int> sched_state{0};         // 0: the scheduler weight of this scene has not been decided yet (texir_irt_generate)
+    mutable double node_utilisation = -1.0;          // what that decision measured (texir_scene_info)
 };
 
 static thread_local std::string g_err;
@@ -102,7 +104,7 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
     if ((e = hipMemcpy(s->d_tex, hdr_tex, s->tex_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload texture");
     s->dev.nodes4 = (const float4*)s->d_nodes4; s->dev.nodes4f = (const float4*)s->d_nodes4f;
     s->dev.nodes = (const float4*)s->d_nodes; s->dev.tris = (const float4*)s->d_tris; s->dev.uvs = (const float4*)s->d_uvs;
-    s->dev.tex = s->d_tex; s->dev.Ht = Ht; s->dev.Wt = Wt; s->dev.tex_layout = 0; s->dev.tiles_x = 0;
+    s->dev.tex = s->d_tex; s->dev.Ht = Ht; s->dev.Wt = Wt; s->dev.tex_layout = 0; s->dev.tiles_x = 0; s->dev.sched_weight = 0;
     // hit-shader texture layout: 2 (one 128-byte line per bilinear footprint) by default, TEXIR_TEX_LAYOUT=0|1|2 for A/B runs
     const char* lenv = getenv("TEXIR_TEX_LAYOUT");
     const int layout = lenv ? atoi(lenv) : 2;
@@ -153,6 +155,13 @@ int texir_scene_info(const texir_scene* s, int64_t out[8])
     return TEXIR_OK;
 }
 
+int texir_scene_scheduler(const texir_scene* s, double out[2])
+{
+    if (!s || !out) return fail(TEXIR_ERR_INVALID, "texir_scene_scheduler: null argument");
+    out[0] = (double)s->dev.sched_weight; out[1] = s->node_utilisation;
+    return TEXIR_OK;
+}
+
 int texir_trace_shade(const texir_scene* s, const float* org, const float* dir, int64_t R, float t_min, float* radiance, float* t_hit,
                       uint32_t* prim_id, float* prim_uv, void* stream)
 {
@@ -181,6 +190,22 @@ int texir_irt_generate(const texir_scene* s, const float* pos, const float* nrm,
     if (Nt >= (1ll << 31)) return fail(TEXIR_ERR_INVALID, "texir_irt_generate: Nt too large");
     int64_t n = texel_ids ? n_ids : Nt;
     unsigned long long* work = s->d_work + (size_t)(s->work_next.fetch_add(1) % texir_scene::kWorkSlots) * 8 * kWorkStride;
+    // The phase scheduler's weight is a property of the scene (device_common.h, TEXIR_SCHED): the first long launch on a scene measures how full
+    // its node steps run on 16 384 texels from the middle of the list (~2 ms, blocking) and keeps weight 2 (coherent scenes) or picks 1 (cluttered
+    // ones: below 60 %).  Either way every texel gets the same bits; TEXIR_SCHED_WEIGHT = 1 | 2 skips the measurement.
+    if (s->sched_state.load() == 0 && texel_ids && n >= 65536 && N >= 256 && s->width == 4) {
+        int w = 0;
+        if (const char* e = getenv("TEXIR_SCHED_WEIGHT")) w = atoi(e);
+        double util = -1.0;
+        if (w != 1 && w != 2) {
+            const int64_t count = 16384, first = ((n / 3) / 64) * 64;
+            HIP_TRY(irt_probe_node_utilisation(s->dev, pos, nrm, shift, texel_ids, first, count, N, mode, work, (hipStream_t)stream, &util));
+            w = (util >= 0.0 && util < 0.60) ? 1 : 2;
+        }
+        s->dev.sched_weight = w;
+        s->node_utilisation = util;
+        s->sched_state.store(1);
+    }
     HIP_TRY(launch_irt(s->dev, pos, nrm, shift, texel_ids, n, N, mode, irr, (unsigned long long*)stats, work, (hipStream_t)stream));
     return TEXIR_OK;
 }

@@ -20,6 +20,7 @@ struct SceneDev {
     int Ht, Wt;
     int tex_layout;        // 0 row-major; 1 = 8x8-texel tiles of 12-byte texels; 2 = overlapping 3x3 tiles at stride 2, one 128-byte line each
     int tiles_x;           // tiles per tile row (layouts 1, 2)
+    int sched_weight;      // phase scheduler of trace_closest: weight of the lanes at inner nodes (2; 1 for scenes whose node steps run less than ~60 % full: texir_irt_generate measures it once per scene)
 };
 
 constexpr int kBlock = 256;          // 4 waves
@@ -192,12 +193,14 @@ struct Hit { float t, u, v; int slot; };
 //      long run of inner nodes keeps 63 lanes waiting at their leaves: on cluttered scenes the wave executes 2.8x the node steps of
 //      its average ray (c4_scan: 55 wave-level node steps per pass for 19.7 per ray, of which only 30 are the slowest lane's).
 //   1: per step, ballot + population count of both kinds of lanes and the body with more lanes waiting runs; node lanes count
-//      kSchedNodeWeight-fold (a leaf step -- 1 or 2 watertight triangle tests and the culling pop -- costs ~1.5 node steps, and leaf lanes
-//      are worth batching).  Every lane still performs exactly the same node visits, triangle tests and stack operations in the same
-//      order (the schedule only decides WHEN a lane's next step issues), so hits are identical bit for bit.
-//      CPU replay of the kernel's schedule (tools/bvh_sim.cpp): c4_scan 55.3 -> 36.8 (weight 1) / 40.6 (weight 2) wave-level node
-//      steps per pass, c4 19.5 -> 17.6 / 17.8.  Measured (gpurun_out/r03_s1, r03_s2; Grays/s, while-while = 1): weight 1: c4_scan 1.26-1.28,
-//      c4 0.97-1.00 (the leaf batches get smaller: wave-level triangle steps 5.2 -> 7.1); weight 2: c4_scan 1.23, c4 1.00; weight 3: 1.19, 1.00.
+//      w-fold (a leaf step -- 1 or 2 watertight triangle tests and the culling pop -- costs ~1.5 node steps, and on coherent scenes leaf lanes
+//      arrive in bursts that are worth a short wait).  Every lane still performs exactly the same node visits, triangle tests and stack
+//      operations in the same order (the schedule only decides WHEN a lane's next step issues), so hits are identical bit for bit.
+//      CPU replay of the kernel's schedule (tools/bvh_sim.cpp): c4_scan 55.3 -> 36.8 (w = 1) / 40.6 (w = 2) wave-level node steps per pass,
+//      c4 19.5 -> 17.6 / 17.8.  Measured (profiles/r03/ab_tables.txt; Grays/s, while-while = 1): w = 1: c4_scan 1.28, c4 0.98 (the leaf
+//      batches get smaller: wave-level triangle steps 5.2 -> 7.1); w = 2: c4_scan 1.24, c4 1.00; w = 3: 1.19, 1.00.
+//      w comes with the scene (SceneDev::sched_weight): kSchedNodeWeight = 2 unless texir_irt_generate has measured that the scene's node steps
+//      run less than 60 % full (cluttered scenes), then 1.
 #ifndef TEXIR_SCHED
 #define TEXIR_SCHED 1
 #endif
@@ -436,11 +439,12 @@ __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float
     auto node_step = [&]() __attribute__((always_inline)) { if constexpr (WIDTH == 4) node_step4(); else node_step2(); };
 
 #if TEXIR_SCHED
+    const int sched_w = sc.sched_weight > 0 ? sc.sched_weight : kSchedNodeWeight;      // (wave-uniform: an SGPR)
     for (;;) {
         const bool at_node = (uint32_t)node < (uint32_t)kSentinel;        // an inner node (>= 0 and not the sentinel)
         const unsigned long long m_node = __ballot(at_node), m_leaf = __ballot(node < 0);
         if (!(m_node | m_leaf)) break;
-        if (kSchedNodeWeight * __popcll(m_node) >= __popcll(m_leaf)) { if (at_node) node_step(); }
+        if (sched_w * __popcll(m_node) >= __popcll(m_leaf)) { if (at_node) node_step(); }
         else if (node < 0) leaf_step();
     }
 #else

@@ -10,6 +10,8 @@ hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, co
                       int N, int mode, float* irr, unsigned long long* stats, unsigned long long* work /*dev: 8 * kWorkStride chunk counters of this launch*/,
                       hipStream_t st);
 constexpr int kWorkStride = 16;              // unsigned long longs between the per-XCD chunk counters of one launch (a 128-byte line each)
+hipError_t irt_probe_node_utilisation(const SceneDev& sc, const float* pos, const float* nrm, const float* shift, const int32_t* ids, int64_t first, int64_t count,
+                                      int N, int mode, unsigned long long* work, hipStream_t st, double* util);
 struct IrtPlan { int per_wave, log2parts, width; char name[64]; };
 IrtPlan irt_plan(const SceneDev& sc, int64_t n_ids, int N);      // the kernel form launch_irt picks for this call
 size_t tex_retile_bytes(int Ht, int Wt, int layout, int* tiles_x, int* tiles_y);

@@ -606,6 +606,36 @@ hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, co
     return hipGetLastError();
 }
 
+// How full do this scene's node steps run?  A counting launch of the 64-texel form over `count` listed texels starting at `first` (min(N, 256) samples,
+// weight 2, partial sums into scratch: the caller's irradiance buffer is not touched) -> lanes taking part per wave-level node step / 64.
+// Blocks until the counters are back (once per scene: texir_irt_generate).
+hipError_t irt_probe_node_utilisation(const SceneDev& sc, const float* pos, const float* nrm, const float* shift, const int32_t* ids, int64_t first, int64_t count,
+                                      int N, int mode, unsigned long long* work, hipStream_t st, double* util)
+{
+    *util = -1.0;
+    if (!sc.nodes4 || !ids || count < 64 || (N & (N - 1))) return hipSuccess;
+    const int Nc = N > 256 ? 256 : N;
+    const int l2 = ilog2_exact(Nc);
+    int log2parts = 0;
+    while (log2parts < 5 && (Nc >> (log2parts + 1)) >= 8) log2parts++;
+    if (!log2parts) return hipSuccess;
+    hipError_t e;
+    float* partial = nullptr; unsigned long long* stats = nullptr;
+    if ((e = hipMemsetAsync(work, 0, sizeof(unsigned long long) * 8 * kWorkStride, st)) != hipSuccess) return e;
+    if ((e = hipMallocAsync((void**)&partial, (sizeof(float) * 3 * (size_t)count << log2parts) + 8 * sizeof(unsigned long long), st)) != hipSuccess) return e;
+    stats = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(partial) + (sizeof(float) * 3 * (size_t)count << log2parts));
+    if ((e = hipMemsetAsync(stats, 0, 8 * sizeof(unsigned long long), st)) != hipSuccess) return e;
+    SceneDev probe = sc;
+    probe.sched_weight = kSchedNodeWeight;
+    irt_launch(irt_group_kernel<true, 4, 6>, ((count + 63) / 64) << log2parts, probe, pos, nrm, shift, ids + first, count, Nc, l2, mode, (float*)nullptr, stats, work, partial, log2parts, st);
+    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if ((e = hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    if ((e = hipFreeAsync(partial, st)) != hipSuccess) return e;
+    if (h[4]) *util = (double)h[1] / (64.0 * (double)h[4]);          // node fetches / (64 x wave-level node steps)
+    return hipGetLastError();
+}
+
 hipError_t launch_trace_shade(const SceneDev& sc, const float* org, const float* dir, int64_t R, float t_min, float* rad, float* t_hit,
                               uint32_t* prim, float* puv, hipStream_t st)
 {

@@ -73,7 +73,11 @@ class Scene:
         out = np.zeros(8, np.int64)
         _lib.check(_lib.lib().texir_scene_info(self.h, _lib.ptr(out)))
         keys = ["inner_nodes", "triangles", "max_depth", "node_bytes", "tri_bytes", "uv_bytes", "tex_bytes", "device"]
-        return dict(zip(keys, (int(x) for x in out)))
+        d = dict(zip(keys, (int(x) for x in out)))
+        sch = np.zeros(2, np.float64)
+        _lib.check(_lib.lib().texir_scene_scheduler(self.h, _lib.ptr(sch)))
+        d["sched_weight"], d["node_step_fill"] = int(sch[0]), (None if sch[1] < 0 else round(float(sch[1]), 4))
+        return d
 
     def irt_kernel_name(self, n_ids, n_samples):
         """the kernel form one irt_generate call over n_ids listed texels launches (the launcher's own decision)"""
