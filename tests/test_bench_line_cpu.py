@@ -1,0 +1,69 @@
+"""CPU: the bench line says one thing -- every printed fraction can be recomputed from the printed numbers -- and the
+runners' shared loop calls its hooks in the reference loops' order."""
+import json
+import os
+import sys
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+
+
+def test_roofline_fields_are_self_consistent(monkeypatch):
+    import bench
+    pmc = {"kernel_src_sha": bench.kernel_src_sha(), "kernel": "void texir::irt_group_kernel<false, 4, 6>", "rays_per_launch": 1000000,
+           "fabric_bytes_per_launch": 3.0e8, "SQ_INSTS_VALU": 5.0e7, "tcp_cache_accesses": 3.0e7, "tcp_clocks": 4.0e7, "kernel_ms_under_pmc": [0.1, 0.1],
+           "l2_hit_rate": 0.5, "valu_lane_utilisation": 0.7, "source": "unit test"}
+    monkeypatch.setattr(bench, "load_pmc", lambda w, k: (pmc, None))
+    r = bench.roofline("c4", "irt_group_kernel<false, 4, 6>", 0.1, 1000000, 1, (1952.0, 54.6, 3.65, 1.0))
+    # top level = the memory side, always: frac = achieved / peak, achieved = traffic / time
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["traffic"] / (r["kernel_ms"] * 1e-3) / 1e9) < 0.1
+    # every limit carries its own numerator and denominator, and `binding` names the largest fraction
+    fr = {k: v["frac"] for k, v in r["limits"].items() if v}
+    for k, v in r["limits"].items():
+        if v:
+            assert abs(v["frac"] - v["achieved"] / v["peak"]) < 2e-3, k
+    assert r["binding"] == max(fr, key=fr.get)
+    assert "SELF-CALIBRATED" in r["limits"]["l1"]["note"]
+    assert r["algorithmic"]["bytes_per_ray"] == 1952.0
+    json.dumps(r)
+    # a profile of other kernel sources is refused, loudly, and the line then carries no measured bound
+    monkeypatch.setattr(bench, "load_pmc", lambda w, k: (None, "profiles/pmc_c4.json was taken with other kernel sources"))
+    r = bench.roofline("c4", "irt_group_kernel<false, 4, 6>", 0.1, 1000000, 1, None)
+    assert r["frac"] is None and "other kernel sources" in r["note"]
+
+
+def test_committed_profiles_match_the_committed_kernel_sources():
+    """profiles/pmc_<workload>.json are only read when they were taken with THESE sources: the committed pair must agree"""
+    import bench
+    sha = bench.kernel_src_sha()
+    for w in ("c4", "c2", "c4_scan", "c1"):
+        p = os.path.join(ROOT, "profiles", "pmc_%s.json" % w)
+        assert os.path.exists(p), p
+        d = json.load(open(p))
+        assert d["kernel_src_sha"] == sha, (w, d["kernel_src_sha"], sha)
+        assert d["fabric_bytes_per_launch"] > 0 and d["rays_per_launch"] > 0
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from mat_step_pmc import mat_src_sha
+    assert json.load(open(os.path.join(ROOT, "profiles", "pmc_mat_step.json")))["mat_src_sha"] == mat_src_sha()
+
+
+def test_runner_base_hook_order():
+    from texir_code_amd.trainer.base import RunnerBase
+
+    class M:
+        def train(self):
+            log.append("train")
+
+    log = []
+    r = RunnerBase()
+    r.model, r.cur_iter = M(), 0
+    ended = r.fit([10, 11, 12], 0, 1, lambda b: (log.append("step %d" % b), b)[1], epoch_begin=lambda e: log.append("begin %d" % e),
+                  takes=lambda i: i != 1, before_step=lambda e, i: log.append("before %d.%d" % (e, i)),
+                  after_step=lambda e, i, out: (log.append("after %d.%d=%d it%d" % (e, i, out, r.cur_iter)), r.cur_iter >= 3)[1],
+                  epoch_end=lambda e: log.append("end %d" % e))
+    assert ended is True
+    assert log == ["begin 0", "train", "before 0.0", "step 10", "after 0.0=10 it1", "train", "before 0.2", "step 12", "after 0.2=12 it2", "end 0",
+                   "begin 1", "train", "before 1.0", "step 10", "after 1.0=10 it3"]
