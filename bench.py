@@ -316,11 +316,13 @@ def roofline(workload, kernel, kern_ms, rays_this_rank, world, alg):
                                 "note": "L2 <-> Infinity Cache / HBM: TCC_EA0_RDREQ x request size + WRITE_SIZE (MI355X_MICROARCH.md HBM section), / kernel time / 8 TB/s"},
                         "valu": {"frac": round(valu_frac, 4), "achieved": round(valu / t / 1e9, 2), "peak": round(SIMDS * CLOCK_HZ / 2.0 / 1e9, 2), "unit": "G wave-instructions/s",
                                  "insts_per_launch": valu, "insts_per_64_rays": round(valu / (rays_this_rank / 64.0), 1), "lane_utilisation": pmc.get("valu_lane_utilisation"),
-                                 "note": "SQ_INSTS_VALU / t against 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction"},
+                                 "note": "SQ_INSTS_VALU / t against 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction (raw count: conversions, compares, selects, min / max and shifts "
+                                         "-- two thirds of the node step -- take ~1.65 of an fma's issue time at 8 waves per SIMD, profiles/r02/issue_rate.txt)"},
                         "l1": None if l1 is None else {"frac": round(l1, 4), "achieved": round(float(pmc["tcp_cache_accesses"]) * scale / t / 1e9, 2),
                                                        "peak": round(tcp_hz / 1e9, 2), "unit": "G cache accesses/s", "accesses_per_launch": float(pmc["tcp_cache_accesses"]) * scale,
                                                        "note": "vector-L1 (TCP) tag lookups; the peak -- one access per clock per TCP, 256 TCPs at the clock TCP_GATE_EN1 reports -- is "
-                                                               "SELF-CALIBRATED (tools/tcp_rate.hip on this hardware, profiles/r02/tcp_rate.txt), not a documented figure"}},
+                                                               "SELF-CALIBRATED (tools/tcp_rate.hip on this hardware, profiles/r02/tcp_rate.txt), not a documented figure; a build with a quarter fewer "
+                                                               "node-fetch loads (48-byte nodes, profiles/r03/ab_node48_s18.txt) was not faster: read the fraction as how busy the L1 is, not as proof that it binds"}},
                     "waves": {"wait_any_frac": pmc.get("sq_wait_any_frac"), "active_inst_any_frac": pmc.get("sq_active_inst_any_frac"),
                               "note": "share of the resident waves' cycles spent waiting / issuing (SQ_WAIT_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES)"},
                     "scalar_path": None if pmc.get("smem_insts") is None else {"smem_insts_per_launch": float(pmc["smem_insts"]) * scale,

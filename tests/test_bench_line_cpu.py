@@ -67,3 +67,15 @@ def test_runner_base_hook_order():
     assert ended is True
     assert log == ["begin 0", "train", "before 0.0", "step 10", "after 0.0=10 it1", "train", "before 0.2", "step 12", "after 0.2=12 it2", "end 0",
                    "begin 1", "train", "before 1.0", "step 10", "after 1.0=10 it3"]
+
+
+def test_fused_adam_groups_are_fixed_at_construction():
+    import pytest
+    import torch
+    from texir_code_amd._lib import TexirError
+    from texir_code_amd.optim import FusedAdam
+    a, b = torch.nn.Parameter(torch.zeros(4, 4, 3)), torch.nn.Parameter(torch.zeros(3))
+    opt = FusedAdam([{"params": [a]}, {"params": [b], "lr": 1e-2}], lr=1e-3)
+    assert len(opt.param_groups) == 2 and opt.param_groups[1]["lr"] == 1e-2
+    with pytest.raises(TexirError, match="fixed at construction"):
+        opt.add_param_group({"params": [torch.nn.Parameter(torch.zeros(2))]})

@@ -105,3 +105,20 @@ def test_dense_grad_of_sparse_level0_state(tx):
     assert ob.has_pending(b)                              # (what a caller checks before handing the parameter to anything that reads p.grad)
     ob.step()
     assert not ob.has_pending(b)
+
+
+def test_tap_list_budget_counts_live_lists_only(tx):
+    """the global tap-list budget (TEXIR_TAP_CACHE_GB) gets a dropped view cache's share back, so a long-lived process that walks through many
+    scenes does not end up on the float-atomic fallback for good"""
+    import gc
+    from texir_code_amd import texture as T
+    p = torch.nn.Parameter(torch.rand(64, 64, 3, device="cuda"))
+    uv, da, w = _fetch_args(500, 9)
+    before = T._tap_bytes
+    cache = {}
+    (T.texture(p, uv, da, "linear-mipmap-linear", 13, cache=cache) * w).sum().backward()
+    assert T._tap_bytes > before
+    del cache
+    p.grad = None
+    gc.collect()
+    assert T._tap_bytes == before

@@ -27,7 +27,6 @@ class GraphedMatStep:
         self.shift_bufs = {}
         self.graphs, self.losses, self.outs, self.pool = {}, {}, {}, None
         self.side = torch.cuda.Stream()
-        import os
         self.grads_to_none = os.environ.get("TEXIR_GRAPH_GRADS_TO_NONE", "1") == "1"
         if not self.grads_to_none:
             for p in self.params:

@@ -25,8 +25,15 @@ class FusedAdam(torch.optim.Optimizer):
                 p._texir_grad_l1 = p._texir_grad_l2 = None
                 p._texir_l0_touched = False
         self._make_grad_arena()
-        self._dev = {}                 # per device: {"state": float64 [n,4], "hyper": float32 [n,2], "lr": [floats last written]}; record index per param
+        self._dev = {}                 # per device: {"state": float64 [n,4], "hyper": float32 [n,2], "lr": [(lr, beta1, beta2) last written]}; record index per param
         self._rec = {}
+
+    def add_param_group(self, param_group):
+        # (torch.optim.Optimizer.__init__ adds the constructor's groups through this method, before the attributes above exist)
+        if hasattr(self, "_rec"):
+            raise _lib.TexirError("FusedAdam: parameter groups are fixed at construction (the gradient arena and the device-resident step records "
+                                  "are laid out over them); build a new optimiser instead")
+        super().add_param_group(param_group)
 
     # ---- device-resident step count / learning rate (texir_adam_tick): the step needs no host argument that changes from step to step,
     # so a captured hipGraph can contain it (graph_step.GraphedMatStep) and eager steps run the very same kernels ----
@@ -42,14 +49,16 @@ class FusedAdam(torch.optim.Optimizer):
             for i, (g, p) in enumerate(ps):
                 self._rec[id(p)] = i
                 host[i] = torch.tensor([float(self.state[p].get("step", 0)) if self.state[p] else 0.0, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1])], dtype=torch.float64)
-            d = {"state": host.to(device), "hyper": torch.zeros((len(ps), 2), device=device, dtype=torch.float32), "lr": [float(g["lr"]) for g, _ in ps],
+            d = {"state": host.to(device), "hyper": torch.zeros((len(ps), 2), device=device, dtype=torch.float32),
+                 "lr": [(float(g["lr"]), float(g["betas"][0]), float(g["betas"][1])) for g, _ in ps],
                  "params": [p for _, p in ps], "groups": [g for g, _ in ps]}
             self._dev[device] = d
         return d
 
     def prepare(self):
-        """allocate everything a step touches (moments, device records) and push learning-rate changes to the device: call before hipGraph
-        capture and before every replay (cheap: compares floats, launches something only when a scheduler has changed a learning rate)"""
+        """allocate everything a step touches (moments, device records) and push learning-rate / beta changes to the device: call before hipGraph
+        capture and before every replay (cheap: compares floats, launches something only when a scheduler has changed a learning rate).
+        (A recorded step keeps the betas of its capture in its kernel arguments: re-capture after changing betas.)"""
         for group in self.param_groups:
             for p in group["params"]:
                 if p.is_cuda and p.requires_grad:            # (frozen members of the model -- the irradiance texture -- get no moments)
@@ -57,9 +66,10 @@ class FusedAdam(torch.optim.Optimizer):
         for device in {p.device for g in self.param_groups for p in g["params"] if p.is_cuda}:
             d = self._records(device)
             for i, g in enumerate(d["groups"]):
-                if float(g["lr"]) != d["lr"][i]:
-                    d["state"][i, 1] = float(g["lr"])
-                    d["lr"][i] = float(g["lr"])
+                now = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]))
+                if now != d["lr"][i]:
+                    d["state"][i, 1:4] = torch.tensor(now, dtype=torch.float64)
+                    d["lr"][i] = now
 
     def _ensure_state(self, p):
         st = self.state[p]

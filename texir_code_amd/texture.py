@@ -69,6 +69,11 @@ _TAP_BUDGET = int(float(__import__("os").environ.get("TEXIR_TAP_CACHE_GB", "16")
 _tap_bytes = 0
 
 
+def _tap_release(nbytes):
+    global _tap_bytes
+    _tap_bytes -= nbytes
+
+
 def _tap_lists(cache, H, W, C, levels, mode, uv, uv_da):
     """sorted tap lists of a fixed set of fetch coordinates (one view): built once, kept in the caller's per-view cache dict"""
     global _tap_bytes
@@ -106,7 +111,9 @@ def _tap_lists(cache, H, W, C, levels, mode, uv, uv_da):
     hit = (seg_key.contiguous(), starts.contiguous(), counts.to(torch.int32).contiguous(), (order // 8).to(torch.int32).contiguous(),
            wts[order].contiguous(), has_l0, l0_mask)
     cache[key] = hit
-    _tap_bytes += sum(t.numel() * t.element_size() for t in hit[:5]) + (0 if l0_mask is None else l0_mask.numel() * 4)
+    nbytes = sum(t.numel() * t.element_size() for t in hit[:5]) + (0 if l0_mask is None else l0_mask.numel() * 4)
+    _tap_bytes += nbytes
+    __import__("weakref").finalize(hit[0], _tap_release, nbytes)        # the budget counts LIVE lists: a dropped view cache gives its share back
     return hit
 
 
@@ -178,8 +185,6 @@ class _TexFetch(torch.autograd.Function):
                     g_rest.zero_()
             else:
                 g_rest = torch.zeros(n_rest, device=d_out.device, dtype=torch.float32)
-        # a deferred fetch over cached tap lists none of which samples level 0 has an identically zero level-0 gradient: it is not
-        # materialised at all (no 4 * H * W * C byte fill, and the optimiser does not read it) -- autograd gets None for the texture
         # A deferred fetch over cached tap lists (single process): the level-0 gradient is SPARSE -- only the texels the lists name get a
         # value, usually none or a handful (4k textures through 128^2 cube faces sample levels >= 3).  It goes to a buffer owned by the
         # parameter that is never cleared; the view's bit mask (one bit per texel) tells the fused optimiser where to read it.  No
