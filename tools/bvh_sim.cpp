@@ -68,7 +68,7 @@ static uint32_t sample_index(uint32_t cell, int log2N)
 
 struct Ray { float o[3], d[3], id[3], ood[3]; float t; int slot; int node; int pleaf = 0; std::vector<int> stk; std::vector<float> stk_t; };
 
-struct Counters { double rays = 0, nodes = 0, tris = 0, wnode = 0, wtri = 0, culled = 0, hits = 0, wcull = 0, maxsp = 0, wuni = 0, wuni0 = 0, wdeep[4] = {0, 0, 0, 0}, lines = 0, wmaxn = 0, rounds = 0, wmaxt = 0, refills = 0, refill_lanes = 0, spread = 0, specpops = 0, dh[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dl[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };
+struct Counters { double rays = 0, nodes = 0, tris = 0, wnode = 0, wtri = 0, culled = 0, hits = 0, wcull = 0, maxsp = 0, wuni = 0, wuni0 = 0, wdeep[4] = {0, 0, 0, 0}, lines = 0, wmaxn = 0, rounds = 0, wmaxt = 0, refills = 0, refill_lanes = 0, spread = 0, specpops = 0, un_nodes = 0, un_leaves = 0, dh[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dl[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };
 
 static const int kSent = 0x7FFFFFFF;
 
@@ -214,6 +214,7 @@ int main(int argc, char** argv)
                 if (refillK) { c.refills++; c.refill_lanes += 64; }
                 c.rays += 64;
                 int lane_nodes[64] = {0}, lane_tris[64] = {0};
+                std::vector<int> pass_nodes, pass_leaves;      // every (lane, node) / (lane, leaf) visit of this pass: their distinct counts = what ONE packet traversal of the wave would visit
                 bool still_uni = true;      // no divergent node step yet in this pass
                 auto pop = [&](Ray& r) -> int {
                     for (;;) {
@@ -241,7 +242,7 @@ int main(int argc, char** argv)
                         }
                         for (auto& r : R) {
                             if (!(r.node >= 0 && r.node != kSent)) continue;
-                            c.nodes++; lane_nodes[&r - &R[0]]++;
+                            c.nodes++; lane_nodes[&r - &R[0]]++; pass_nodes.push_back(r.node);
                             const GpuNode4& n = h.nodes4[r.node];
                             float key[4]; int code[4];
                             const float cell[3] = {n.cell_x, n.cell_y, n.cell_z};
@@ -275,6 +276,7 @@ int main(int argc, char** argv)
                             uint32_t code = ~(uint32_t)(from_p ? r.pleaf : r.node);
                             int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
                             if (cnt > mx) mx = cnt;
+                            pass_leaves.push_back((int)code);
                             for (int i = first; i < first + cnt; i++) {
                                 c.tris++; lane_tris[&r - &R[0]]++;
                                 const GpuTri& tr = h.tris[i];
@@ -328,10 +330,12 @@ int main(int argc, char** argv)
                 }
                 for (auto& r : R) if (r.slot >= 0) c.hits++;
                 { int mn = 0, mt = 0; for (int l = 0; l < 64; l++) { mn = std::max(mn, lane_nodes[l]); mt = std::max(mt, lane_tris[l]); } c.wmaxn += mn; c.wmaxt += mt; }
+                { std::sort(pass_nodes.begin(), pass_nodes.end()); c.un_nodes += (double)(std::unique(pass_nodes.begin(), pass_nodes.end()) - pass_nodes.begin());
+                  std::sort(pass_leaves.begin(), pass_leaves.end()); c.un_leaves += (double)(std::unique(pass_leaves.begin(), pass_leaves.end()) - pass_leaves.begin()); }
             }
         }
 #pragma omp critical
-        { tot.rays += c.rays; tot.nodes += c.nodes; tot.tris += c.tris; tot.wnode += c.wnode; tot.wtri += c.wtri; tot.culled += c.culled; tot.hits += c.hits; tot.wuni += c.wuni; tot.wuni0 += c.wuni0; tot.lines += c.lines; tot.wmaxn += c.wmaxn; tot.wmaxt += c.wmaxt; tot.rounds += c.rounds; for (int q = 0; q < 8; q++) { tot.dh[q] += c.dh[q]; tot.dl[q] += c.dl[q]; } tot.refills += c.refills; tot.refill_lanes += c.refill_lanes; tot.spread += c.spread; for (int q = 0; q < 4; q++) tot.wdeep[q] += c.wdeep[q]; if (c.maxsp > tot.maxsp) tot.maxsp = c.maxsp; }
+        { tot.rays += c.rays; tot.nodes += c.nodes; tot.tris += c.tris; tot.wnode += c.wnode; tot.wtri += c.wtri; tot.culled += c.culled; tot.hits += c.hits; tot.wuni += c.wuni; tot.wuni0 += c.wuni0; tot.lines += c.lines; tot.wmaxn += c.wmaxn; tot.wmaxt += c.wmaxt; tot.rounds += c.rounds; for (int q = 0; q < 8; q++) { tot.dh[q] += c.dh[q]; tot.dl[q] += c.dl[q]; } tot.refills += c.refills; tot.refill_lanes += c.refill_lanes; tot.spread += c.spread; tot.un_nodes += c.un_nodes; tot.un_leaves += c.un_leaves; for (int q = 0; q < 4; q++) tot.wdeep[q] += c.wdeep[q]; if (c.maxsp > tot.maxsp) tot.maxsp = c.maxsp; }
     }
     double wr = tot.rays / 64.0;
     printf("per ray: %.2f node visits, %.2f tri tests, %.2f culled pops, hit %.4f, max stack %.0f\n", tot.nodes / tot.rays, tot.tris / tot.rays, tot.culled / tot.rays, tot.hits / tot.rays, tot.maxsp);
@@ -339,6 +343,7 @@ int main(int argc, char** argv)
     printf("wave node steps: %.3f uniform (%.3f in the initial all-uniform run), %.2f distinct node lines per step; steps whose push could pass 8/10/11/16 entries: %.4f %.4f %.4f %.4f\n", tot.wuni / tot.wnode, tot.wuni0 / tot.wnode, tot.lines / tot.wnode,
            tot.wdeep[0] / tot.wnode, tot.wdeep[1] / tot.wnode, tot.wdeep[2] / tot.wnode, tot.wdeep[3] / tot.wnode);
     printf("per pass: max-lane node visits %.2f, max-lane tri tests %.2f, while-while rounds %.2f\n", tot.wmaxn / wr, tot.wmaxt / wr, tot.rounds / wr);
+    printf("union over the 64 rays of a pass (= the visits of ONE packet traversal of the wave): %.1f inner nodes, %.1f leaves\n", tot.un_nodes / wr, tot.un_leaves / wr);
     printf("distinct nodes per wave-level node step (share of steps : mean lanes taking part):"); for (int q = 0; q < 8; q++) printf(" %d%s %.3f:%.1f", q + 1, q == 7 ? "+" : "", tot.dh[q] / tot.wnode, tot.dh[q] > 0 ? tot.dl[q] / tot.dh[q] : 0.0); printf("\n");
     if (tot.refills > 0) printf("refill events per 64 rays %.3f (lanes per event %.1f, pass spread at refill %.1f); cost incl. %.1f per refill event: %.2f per pass\n", tot.refills / wr, tot.refill_lanes / tot.refills, tot.spread / tot.refills, 2.6, tot.wnode / wr + tricost * tot.wtri / wr + 2.6 * tot.refills / wr);
     printf("cost model (node step 1, triangle test %.2f): %.2f per pass\n", tricost, tot.wnode / wr + tricost * tot.wtri / wr);
