@@ -647,6 +647,16 @@ def test_full_size_c2_properties(c2_workload, tx):
         part = dist_util.shard_block_cyclic(ids, r, 4, 4096)
         sc.irt_generate(pos, nrm, shift, N, "uniform", texel_ids=part, out=acc)
     assert torch.equal(acc, base)
+    # parity at the configuration's own size and sample count: 300 random valid texels of the 2048-spp texture against the C oracle
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    pick = np.sort(rng.choice(np.argwhere(valid.reshape(-1) > 0)[:, 0], 300, replace=False))
+    tp = torch.from_numpy(pick).cuda()
+    osc = O.Scene(sc0["verts"], sc0["tris"], sc0["tri_uvs"], sc0["hdr"])
+    ref = osc.irt_generate(pos[tp].cpu().numpy(), nrm[tp].cpu().numpy(), None, shift[tp].cpu().numpy(), N, "uniform", tracer="bvh")
+    e = rel_l2(base[tp].cpu().numpy(), ref)
+    print("c2 at 2048 spp, 300 texels vs oracle: rel-L2 %.2e" % e)
+    assert e < 1e-3 and e < 1e-4, e
 
 
 def test_irradiance_at_random_mesh_points_vs_oracle(room):
