@@ -42,6 +42,9 @@ typedef struct texir_scene texir_scene;
 
 TEXIR_API const char* texir_last_error(void);
 TEXIR_API int texir_version(void);
+/* The library's run-time switches (TEXIR_* environment variables, csrc/env.h) are parsed once when the library is loaded; this re-reads them
+ * (for test suites that flip a switch between two launches; not to be called while launches are being issued from other threads). */
+TEXIR_API int texir_reload_env(void);
 
 /* Replaces TracerO3d.__init__ scene part (models/tracer_o3d_irt.py:75-89) and MaterialModel.__init__
  * (models/mat_nvdiffrast.py:87-101): o3d.t.geometry.RaycastingScene().add_triangles(mesh) + the CPU-resident
@@ -63,8 +66,15 @@ TEXIR_API int texir_scene_set_texture(texir_scene* scene, const float* tex, int3
  * [4]=triangle bytes, [5]=uv bytes, [6]=texture bytes, [7]=device */
 TEXIR_API int texir_scene_info(const texir_scene* scene, int64_t out[8]);
 /* The traversal's phase scheduler weighs the lanes at inner nodes against the lanes at leaves (csrc/device_common.h); the weight is a property of the
- * scene, decided by the first long texir_irt_generate call on it from the measured fullness of its node steps (out[1], -1 = not measured;
- * out[0] = the weight in use: 0 = not decided yet -> 2).  Speed only: results never depend on it. */
+ * scene.  texir_scene_tune decides it ONCE per scene from the measured fullness of the scene's node steps on a sample of the caller's own texel
+ * list (a counting launch over 16 384 listed texels, ~2 ms, BLOCKING: it synchronises `stream` and must not be called while the stream is being
+ * captured); lists shorter than 65 536 texels or N < 256 decide nothing.  No other entry point measures or synchronises: texir_irt_generate,
+ * texir_spec_forward, ... launch with the weight in force (2 until tuned) and can be recorded into a hipGraph from their first call on.  The
+ * Python host layer calls it before the first long irt_generate of a scene (scene.Scene.irt_generate); the reference has no counterpart (Embree
+ * picks its traversal internally, models/tracer_o3d_irt.py:243-244).  Speed only: results never depend on the weight.
+ * texir_scene_scheduler: out[0] = the weight in use (0 = not decided -> 2), out[1] = measured fullness (-1 = not measured). */
+TEXIR_API int texir_scene_tune(const texir_scene* scene, const float* pos /*dev*/, const float* nrm /*dev*/, const float* shift /*dev*/,
+                               const int32_t* texel_ids /*dev*/, int64_t n_ids, int32_t N, int32_t mode, void* stream);
 TEXIR_API int texir_scene_scheduler(const texir_scene* scene, double out[2]);
 
 /* Replaces query_irf (models/tracer_o3d_irt.py:240-269, models/mat_nvdiffrast.py:292-320):

@@ -48,3 +48,28 @@ def _oracle_uses_all_cores():
     except Exception:
         pass                    # oracle library not built: tests that need it fail on their own
     yield
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """the stock fixture, plus: libtexir_hip.so parses its TEXIR_* switches once at load (csrc/env.h), so every change a test makes to such
+    a variable is followed by texir_reload_env() -- and once more after the test's changes have been undone"""
+    from texir_code_amd import _lib
+
+    class Patched:
+        def __getattr__(self, name):
+            return getattr(monkeypatch, name)
+
+        def setenv(self, name, value, prepend=None):
+            monkeypatch.setenv(name, value, prepend)
+            if name.startswith("TEXIR_"):
+                _lib.reload_env()
+
+        def delenv(self, name, raising=True):
+            monkeypatch.delenv(name, raising)
+            if name.startswith("TEXIR_"):
+                _lib.reload_env()
+
+    yield Patched()
+    monkeypatch.undo()
+    _lib.reload_env()

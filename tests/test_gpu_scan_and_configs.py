@@ -241,3 +241,48 @@ def test_material_step_at_4k_textures_fused_vs_reference_forms(tx, monkeypatch):
     assert torch.equal(a_g, a_fus) and torch.equal(r_g, r_fus), (float((a_g - a_fus).abs().max()), float((r_g - r_fus).abs().max()))
     moved = torch.rand(4096, 4096, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(1)) * 0.4 + 0.3
     assert float((a_fus - moved).abs().max()) > 1e-3                   # the steps really changed the textures
+
+
+def test_irt_generate_never_blocks_and_first_call_is_capturable():
+    """the scheduler-weight measurement lives in texir_scene_tune (explicit, blocking, refused under capture); the C-ABI's
+    texir_irt_generate neither measures nor synchronises, so the FIRST long call on a scene can be recorded into a hipGraph, and the replayed
+    texture equals the eager one bit for bit whatever weight the later tune picks"""
+    import ctypes as C
+    from texir_code_amd import _lib, dist_util, synth
+    from texir_code_amd.scene import Scene
+    sc0 = synth.make_scene(20000, seed=666, tex_res=256, style="scan")
+    res, N = 320, 256
+    pos, nrm, valid = synth.make_texel_gbuffer(sc0, res)
+    shift = synth.make_shifts(res * res)
+    sc = Scene(sc0["verts"], sc0["tris"], sc0["tri_uvs"], sc0["hdr"])
+    ids = dist_util.morton_order(torch.nonzero(torch.from_numpy(valid.reshape(-1)) > 0)[:, 0].to(torch.int32), res).cuda()
+    assert ids.numel() >= 65536
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    dpos, dnrm, dsh = d(pos).reshape(-1, 3), d(nrm).reshape(-1, 3), d(shift)
+    L = _lib.lib()
+    out = torch.zeros(res * res, 3, device="cuda")
+    assert sc.info()["sched_weight"] == 0                                  # undecided
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            # tuning under capture is refused loudly and leaves the scene undecided ...
+            rc = L.texir_scene_tune(sc.h, _lib.ptr(dpos), _lib.ptr(dnrm), _lib.ptr(dsh), _lib.ptr(ids), ids.numel(), N, 0, st)
+            assert rc != 0 and b"captured" in L.texir_last_error()
+            # ... and the first generate call of the scene is recorded
+            _lib.check(L.texir_irt_generate(sc.h, _lib.ptr(dpos), _lib.ptr(dnrm), _lib.ptr(dsh), _lib.ptr(ids), ids.numel(), res * res, N, 0,
+                                            _lib.ptr(out), None, st))
+    torch.cuda.current_stream().wait_stream(side)
+    assert sc.info()["sched_weight"] == 0 and float(out.abs().sum()) == 0.0   # recorded, not run
+    g.replay()
+    torch.cuda.synchronize()
+    replayed = out.clone()
+    eager = sc.irt_generate(dpos, dnrm, dsh, N, "uniform", texel_ids=ids)    # the host wrapper tunes first (outside any capture)
+    info = sc.info()
+    assert info["sched_weight"] in (1, 2) and info["node_step_fill"] is not None and 0.2 < info["node_step_fill"] < 1.0
+    assert torch.equal(replayed, eager)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)

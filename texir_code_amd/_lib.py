@@ -43,6 +43,7 @@ def lib():
             "texir_scene_set_texture": [vp, vp, i32, i32, i32, vp],
             "texir_scene_info": [vp, vp],
             "texir_scene_scheduler": [vp, vp],
+            "texir_scene_tune": [vp, vp, vp, vp, vp, i64, i32, i32, vp],
             "texir_trace_shade": [vp, vp, vp, i64, f32, vp, vp, vp, vp, vp],
             "texir_generate_dir": [vp, vp, vp, i64, i32, i32, vp, vp],
             "texir_irt_generate": [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp, vp, vp],
@@ -65,6 +66,8 @@ def lib():
         sig["texir_adam_tick"] = [vp, vp, i32, C.c_uint64, vp]
         sig["texir_adam_step_dev"] = [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, vp]
         sig["texir_adam_step_tex_dev"] = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, f32, f32, f32, f32, f32, vp]
+        L.texir_reload_env.argtypes = []
+        L.texir_reload_env.restype = i32
         L.texir_mip_levels.argtypes = [i32, i32, i32]
         L.texir_mip_levels.restype = i32
         L.texir_mip_elems.argtypes = [i32, i32, i32, i32]
@@ -80,6 +83,12 @@ def lib():
             fn.restype = i32
         _LIB = L
     return _LIB
+
+
+def reload_env():
+    """re-read the library's TEXIR_* switches (parsed once at load, csrc/env.h) after os.environ was changed"""
+    if _LIB is not None:
+        _LIB.texir_reload_env()
 
 
 def check(rc):

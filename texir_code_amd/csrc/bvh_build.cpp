@@ -1,6 +1,7 @@
 // Binned-SAH BVH2 builder (host, multi-threaded over the top subtrees) emitting the 64-byte
 // two-child-box node layout consumed by the gfx950 traversal kernels (see bvh_build.h).
 #include "bvh_build.h"
+#include "env.h"
 #include <cstdlib>
 
 #include <algorithm>
@@ -41,12 +42,7 @@ struct Ctx {
 constexpr int kBins = 32;
 
 // triangles per leaf (leaf codes hold count-1 in 3 bits); TEXIR_MAX_LEAF overrides the default for A/B measurements
-static int max_leaf()
-{
-    static int v = 0;
-    if (!v) { const char* e = getenv("TEXIR_MAX_LEAF"); v = e ? std::min(8, std::max(1, atoi(e))) : kMaxLeaf; }
-    return v;
-}
+static int max_leaf() { const int v = env().max_leaf; return v ? v : kMaxLeaf; }
 
 std::unique_ptr<Tmp> build(const Ctx& c, int first, int count, int depth, int par_levels)
 {
@@ -243,8 +239,7 @@ void build_bvh(const float* verts, int V, const int32_t* tris, int T, const floa
     {   // absolute box slack of this scene (see emit4_fill); TEXIR_BOX_SLACK_LOG2 overrides the exponent for A/B runs (99 = none)
         float M = 0.f;
         for (int64_t i = 0; i < 3 * (int64_t)V; i++) M = std::max(M, std::fabs(verts[i]));
-        const char* e = getenv("TEXIR_BOX_SLACK_LOG2");
-        const int l2 = e ? atoi(e) : -19;
+        const int l2 = env().box_slack_log2;
         slack = l2 == 99 ? 0.f : std::ldexp(M, l2);
     }
     Ctx c{&tb, &cen, &order};

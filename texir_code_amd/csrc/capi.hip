@@ -12,13 +12,14 @@
 
 #include "../../include/texir_hip.h"
 #include "bvh_build.h"
+#include "env.h"
 #include "kernels.h"
 
 using namespace texir;
 
 struct texir_scene {
     int device = 0;
-    mutable SceneDev dev{};              // (mutable: the scheduler weight is decided by the first long launch on the -- otherwise immutable -- scene)
+    SceneDev dev{};
     void* d_nodes4 = nullptr; void* d_nodes4f = nullptr;
     void* d_nodes = nullptr; void* d_tris = nullptr; void* d_uvs = nullptr; float* d_tex = nullptr;
     float* d_tex_tiled = nullptr;        // retiled copy read by the hit shader (texture layouts 1, 2); d_tex stays the row-major master
@@ -33,9 +34,20 @@ struct texir_scene {
     static constexpr int kWorkSlots = 64;
     unsigned long long* d_work = nullptr;
     mutable std::atomic<unsigned> work_next{0};      // (launching on an immutable scene still advances the slot)
-    mutable std::atomic<int> sched_state{0};         // 0: the scheduler weight of this scene has not been decided yet (texir_irt_generate)
-    mutable double node_utilisation = -1.0;          // what that decision measured (texir_scene_info)
+    // phase-scheduler weight of this scene (device_common.h TEXIR_SCHED): decided once by texir_scene_tune, read by every tracing launch
+    mutable std::atomic<int> sched_state{0};         // 0 undecided, 1 being decided, 2 decided
+    mutable std::atomic<int> sched_weight{0};        // 0 = the compile-time default (2)
+    mutable std::atomic<double> node_utilisation{-1.0};   // what the decision measured (texir_scene_scheduler)
 };
+
+// the kernel-argument view of a scene for one launch: the immutable part + the scheduler weight in force now
+static SceneDev dev_of(const texir_scene* s)
+{
+    SceneDev d = s->dev;
+    const int forced = env().sched_weight;
+    d.sched_weight = forced ? forced : s->sched_weight.load(std::memory_order_relaxed);
+    return d;
+}
 
 static thread_local std::string g_err;
 
@@ -80,15 +92,14 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
     hipError_t e;
     // traversal tree: 4-wide quantised by default (TEXIR_BVH_WIDTH=2 keeps the binary tree); falls back to binary when the wide
     // tree's worst-case stack (3 pushes per level) would not fit the traversal stack
-    const char* wenv = getenv("TEXIR_BVH_WIDTH");
-    int want_w = wenv ? atoi(wenv) : 4;
+    const int want_w = env().bvh_width;
     s->width = (want_w == 4 && 3 * h.max_depth4 + 2 <= kStackCap) ? 4 : 2;
     if (s->width == 4) {
         s->n_nodes4 = (int64_t)h.nodes4.size(); s->max_depth = h.max_depth4;
         if ((e = hipMalloc(&s->d_nodes4, h.nodes4.size() * sizeof(GpuNode4))) != hipSuccess) return bail(e, "hipMalloc nodes4");
         if ((e = hipMemcpy(s->d_nodes4, h.nodes4.data(), h.nodes4.size() * sizeof(GpuNode4), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload nodes4");
         // the float form of the same nodes, read by wave-uniform node steps through the scalar cache (TEXIR_UNIFORM_FLOAT=0: A/B switch)
-        if (!(getenv("TEXIR_UNIFORM_FLOAT") && atoi(getenv("TEXIR_UNIFORM_FLOAT")) == 0)) {
+        if (env().uniform_float) {
             if ((e = hipMalloc(&s->d_nodes4f, h.nodes4f.size() * sizeof(GpuNode4F))) != hipSuccess) return bail(e, "hipMalloc nodes4f");
             if ((e = hipMemcpy(s->d_nodes4f, h.nodes4f.data(), h.nodes4f.size() * sizeof(GpuNode4F), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload nodes4f");
         }
@@ -106,8 +117,7 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
     s->dev.nodes = (const float4*)s->d_nodes; s->dev.tris = (const float4*)s->d_tris; s->dev.uvs = (const float4*)s->d_uvs;
     s->dev.tex = s->d_tex; s->dev.Ht = Ht; s->dev.Wt = Wt; s->dev.tex_layout = 0; s->dev.tiles_x = 0; s->dev.sched_weight = 0;
     // hit-shader texture layout: 2 (one 128-byte line per bilinear footprint) by default, TEXIR_TEX_LAYOUT=0|1|2 for A/B runs
-    const char* lenv = getenv("TEXIR_TEX_LAYOUT");
-    const int layout = lenv ? atoi(lenv) : 2;
+    const int layout = env().tex_layout;
     if (layout == 1 || layout == 2) {
         int tx, ty;
         s->tiled_bytes = tex_retile_bytes(Ht, Wt, layout, &tx, &ty);
@@ -158,7 +168,42 @@ int texir_scene_info(const texir_scene* s, int64_t out[8])
 int texir_scene_scheduler(const texir_scene* s, double out[2])
 {
     if (!s || !out) return fail(TEXIR_ERR_INVALID, "texir_scene_scheduler: null argument");
-    out[0] = (double)s->dev.sched_weight; out[1] = s->node_utilisation;
+    out[0] = (double)s->sched_weight.load(); out[1] = s->node_utilisation.load();
+    return TEXIR_OK;
+}
+
+int texir_scene_tune(const texir_scene* s, const float* pos, const float* nrm, const float* shift, const int32_t* texel_ids, int64_t n_ids,
+                     int32_t N, int32_t mode, void* stream)
+{
+    if (!s || !pos || !nrm || !shift) return fail(TEXIR_ERR_INVALID, "texir_scene_tune: null argument");
+    if (mode < 0 || mode > 1) return fail(TEXIR_ERR_INVALID, "texir_scene_tune: mode must be uniform(0) or cosine(1), got %d", mode);
+    // one host thread decides (compare-exchange: 0 undecided -> 1 deciding -> 2 decided); the others return at once and launch with the weight in force
+    int expect = 0;
+    if (!s->sched_state.compare_exchange_strong(expect, 1)) return TEXIR_OK;
+    int w = env().sched_weight;
+    double util = -1.0;
+    if (w == 0 && texel_ids && n_ids >= 65536 && N >= 256 && s->width == 4) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+            s->sched_state.store(0);                 // a blocking measurement cannot be recorded: stay undecided, keep the default weight
+            return fail(TEXIR_ERR_INVALID, "texir_scene_tune: the stream is being captured (tune the scene before recording)");
+        }
+        unsigned long long* work = s->d_work + (size_t)(s->work_next.fetch_add(1) % texir_scene::kWorkSlots) * 8 * kWorkStride;
+        const int64_t count = 16384, first = ((n_ids / 3) / 64) * 64;
+        const hipError_t e = irt_probe_node_utilisation(s->dev, pos, nrm, shift, texel_ids, first, count, N, mode, work, (hipStream_t)stream, &util);
+        if (e != hipSuccess) { s->sched_state.store(0); return fail(TEXIR_ERR_HIP, "texir_scene_tune: %s", hipGetErrorString(e)); }
+        w = (util >= 0.0 && util < 0.60) ? 1 : 2;
+    }
+    if (w == 0) { s->sched_state.store(0); return TEXIR_OK; }       // a short list decides nothing: a later, longer call may
+    s->sched_weight.store(w);
+    s->node_utilisation.store(util);
+    s->sched_state.store(2);
+    return TEXIR_OK;
+}
+
+int texir_reload_env(void)
+{
+    env_reload();
     return TEXIR_OK;
 }
 
@@ -167,7 +212,7 @@ int texir_trace_shade(const texir_scene* s, const float* org, const float* dir, 
 {
     if (!s || !org || !dir || !radiance) return fail(TEXIR_ERR_INVALID, "texir_trace_shade: null argument");
     if (R < 0) return fail(TEXIR_ERR_INVALID, "texir_trace_shade: negative ray count");
-    HIP_TRY(launch_trace_shade(s->dev, org, dir, R, t_min, radiance, t_hit, prim_id, prim_uv, (hipStream_t)stream));
+    HIP_TRY(launch_trace_shade(dev_of(s), org, dir, R, t_min, radiance, t_hit, prim_id, prim_uv, (hipStream_t)stream));
     return TEXIR_OK;
 }
 
@@ -190,23 +235,9 @@ int texir_irt_generate(const texir_scene* s, const float* pos, const float* nrm,
     if (Nt >= (1ll << 31)) return fail(TEXIR_ERR_INVALID, "texir_irt_generate: Nt too large");
     int64_t n = texel_ids ? n_ids : Nt;
     unsigned long long* work = s->d_work + (size_t)(s->work_next.fetch_add(1) % texir_scene::kWorkSlots) * 8 * kWorkStride;
-    // The phase scheduler's weight is a property of the scene (device_common.h, TEXIR_SCHED): the first long launch on a scene measures how full
-    // its node steps run on 16 384 texels from the middle of the list (~2 ms, blocking) and keeps weight 2 (coherent scenes) or picks 1 (cluttered
-    // ones: below 60 %).  Either way every texel gets the same bits; TEXIR_SCHED_WEIGHT = 1 | 2 skips the measurement.
-    if (s->sched_state.load() == 0 && texel_ids && n >= 65536 && N >= 256 && s->width == 4) {
-        int w = 0;
-        if (const char* e = getenv("TEXIR_SCHED_WEIGHT")) w = atoi(e);
-        double util = -1.0;
-        if (w != 1 && w != 2) {
-            const int64_t count = 16384, first = ((n / 3) / 64) * 64;
-            HIP_TRY(irt_probe_node_utilisation(s->dev, pos, nrm, shift, texel_ids, first, count, N, mode, work, (hipStream_t)stream, &util));
-            w = (util >= 0.0 && util < 0.60) ? 1 : 2;
-        }
-        s->dev.sched_weight = w;
-        s->node_utilisation = util;
-        s->sched_state.store(1);
-    }
-    HIP_TRY(launch_irt(s->dev, pos, nrm, shift, texel_ids, n, N, mode, irr, (unsigned long long*)stats, work, (hipStream_t)stream));
+    // (No measurement and no synchronisation in here: the phase scheduler's weight is whatever texir_scene_tune / TEXIR_SCHED_WEIGHT has decided for
+    // the scene, 2 until then.  The texture is the same bits either way.)
+    HIP_TRY(launch_irt(dev_of(s), pos, nrm, shift, texel_ids, n, N, mode, irr, (unsigned long long*)stats, work, (hipStream_t)stream));
     return TEXIR_OK;
 }
 
@@ -225,7 +256,7 @@ int texir_spec_forward(const texir_scene* s, const float* normal, const float* a
     if (ls_given && !Ls_ws) return fail(TEXIR_ERR_INVALID, "texir_spec_forward: ls_given needs the lighting in Ls_ws");
     if (P < 0 || S <= 0 || !(clamp_eps > 0.f)) return fail(TEXIR_ERR_INVALID, "texir_spec_forward: bad sizes P=%lld S=%d clamp_eps=%g", (long long)P, S, (double)clamp_eps);
     SceneDev none{};
-    HIP_TRY(launch_spec_fwd(s ? s->dev : none, normal, albedo, rough, points, irr, cam, shift, P, S, clamp_eps, ls_given ? 1 : 0, rgb, Ls_ws, (hipStream_t)stream));
+    HIP_TRY(launch_spec_fwd(s ? dev_of(s) : none, normal, albedo, rough, points, irr, cam, shift, P, S, clamp_eps, ls_given ? 1 : 0, rgb, Ls_ws, (hipStream_t)stream));
     return TEXIR_OK;
 }
 
@@ -247,7 +278,7 @@ int texir_diffuse_irradiance(const texir_scene* s, const float* pos, const float
     unsigned long long* work = s->d_work + (size_t)(s->work_next.fetch_add(1) % texir_scene::kWorkSlots) * 8 * kWorkStride;
     // uniform: (2 pi / N) sum L n.l -- the IrT estimator; cosine: (pi / N) sum L over cosine-distributed directions
     const int mode = sample_type == 1 ? (1 | 4) : 0;
-    HIP_TRY(launch_irt(s->dev, pos, nrm, shift, nullptr, P, N, mode, irr, nullptr, work, (hipStream_t)stream));
+    HIP_TRY(launch_irt(dev_of(s), pos, nrm, shift, nullptr, P, N, mode, irr, nullptr, work, (hipStream_t)stream));
     return TEXIR_OK;
 }
 
@@ -270,7 +301,7 @@ int texir_gbuffer_cast(const texir_scene* s, const float* mvp, int32_t c, int32_
 {
     if (!s || !mvp || !pos || !nrm || !mask || !uv || !uv_da || !tri_id) return fail(TEXIR_ERR_INVALID, "texir_gbuffer_cast: null argument");
     if (c <= 0 || c > 16384) return fail(TEXIR_ERR_INVALID, "texir_gbuffer_cast: bad cube_res %d", c);
-    HIP_TRY(launch_gbuffer(s->dev, mvp, (const float4*)s->d_cnrm, c, flip_v, pos, nrm, mask, uv, uv_da, tri_id, (hipStream_t)stream));
+    HIP_TRY(launch_gbuffer(dev_of(s), mvp, (const float4*)s->d_cnrm, c, flip_v, pos, nrm, mask, uv, uv_da, tri_id, (hipStream_t)stream));
     return TEXIR_OK;
 }
 

@@ -20,7 +20,7 @@ struct SceneDev {
     int Ht, Wt;
     int tex_layout;        // 0 row-major; 1 = 8x8-texel tiles of 12-byte texels; 2 = overlapping 3x3 tiles at stride 2, one 128-byte line each
     int tiles_x;           // tiles per tile row (layouts 1, 2)
-    int sched_weight;      // phase scheduler of trace_closest: weight of the lanes at inner nodes (2; 1 for scenes whose node steps run less than ~60 % full: texir_irt_generate measures it once per scene)
+    int sched_weight;      // phase scheduler of trace_closest: weight of the lanes at inner nodes (2; 1 for scenes whose node steps run less than ~60 % full: texir_scene_tune measures it once per scene)
 };
 
 constexpr int kBlock = 256;          // 4 waves
@@ -199,7 +199,7 @@ struct Hit { float t, u, v; int slot; };
 //      CPU replay of the kernel's schedule (tools/bvh_sim.cpp): c4_scan 55.3 -> 36.8 (w = 1) / 40.6 (w = 2) wave-level node steps per pass,
 //      c4 19.5 -> 17.6 / 17.8.  Measured (profiles/r03/ab_tables.txt; Grays/s, while-while = 1): w = 1: c4_scan 1.28, c4 0.98 (the leaf
 //      batches get smaller: wave-level triangle steps 5.2 -> 7.1); w = 2: c4_scan 1.24, c4 1.00; w = 3: 1.19, 1.00.
-//      w comes with the scene (SceneDev::sched_weight): kSchedNodeWeight = 2 unless texir_irt_generate has measured that the scene's node steps
+//      w comes with the scene (SceneDev::sched_weight): kSchedNodeWeight = 2 unless texir_scene_tune has measured that the scene's node steps
 //      run less than 60 % full (cluttered scenes), then 1.
 #ifndef TEXIR_SCHED
 #define TEXIR_SCHED 1

@@ -1,0 +1,46 @@
+// The one place where the library reads the process environment (env.h).
+#include "env.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace texir {
+
+static int geti(const char* name, int dflt)
+{
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+
+static Env parse()
+{
+    Env v{};
+    v.bvh_width = geti("TEXIR_BVH_WIDTH", 4);
+    v.uniform_float = geti("TEXIR_UNIFORM_FLOAT", 1) != 0;
+    v.tex_layout = geti("TEXIR_TEX_LAYOUT", 2);
+    const int w = geti("TEXIR_SCHED_WEIGHT", 0);
+    v.sched_weight = (w == 1 || w == 2) ? w : 0;
+    v.mip_per_level = geti("TEXIR_MIP_PER_LEVEL", 0) != 0;
+    v.adam_scalar = getenv("TEXIR_ADAM_SCALAR") != nullptr;          // (presence switches it on, as before)
+    v.adam_grid_y = std::max(0, geti("TEXIR_ADAM_GRID_Y", 0));
+    const int ml = geti("TEXIR_MAX_LEAF", 0);
+    v.max_leaf = ml ? std::min(8, std::max(1, ml)) : 0;
+    v.box_slack_log2 = geti("TEXIR_BOX_SLACK_LOG2", -19);
+    const int pw = geti("TEXIR_IRT_TEXELS_PER_WAVE", 0);
+    v.irt_texels_per_wave = (pw == 1 || pw == 64) ? pw : 0;
+    const int mc = geti("TEXIR_IRT_MIN_PART_CELLS", 8);
+    v.irt_min_part_cells = mc >= 1 ? mc : 8;
+    v.irt_log2parts_cap = getenv("TEXIR_IRT_LOG2PARTS") ? std::max(0, geti("TEXIR_IRT_LOG2PARTS", 0)) : -1;
+    const int gc = geti("TEXIR_SPEC_GRID_CAP", 1 << 16);
+    v.spec_grid_cap = gc >= 1 ? gc : (1 << 16);
+    const int lpp = geti("TEXIR_SPEC_LPP", 0);
+    v.spec_lpp = (lpp >= 1 && lpp <= 64 && (lpp & (lpp - 1)) == 0) ? lpp : 0;
+    return v;
+}
+
+static Env g_env = parse();          // library load
+
+const Env& env() { return g_env; }
+void env_reload() { g_env = parse(); }
+
+}  // namespace texir

@@ -1,0 +1,27 @@
+// Every TEXIR_* run-time switch of the library, parsed ONCE (library load) into one struct: no launch path calls getenv.
+// texir_reload_env() (C-ABI, include/texir_hip.h) re-parses the environment -- the test suite flips switches between launches.
+#pragma once
+
+namespace texir {
+
+struct Env {
+    int bvh_width;             // TEXIR_BVH_WIDTH            4 (default) | 2 = binary tree only
+    int uniform_float;         // TEXIR_UNIFORM_FLOAT        1 (default) | 0 = scenes without the float node copy (every node step per lane)
+    int tex_layout;            // TEXIR_TEX_LAYOUT           2 (default) | 1 | 0: radiance-texture layout read by the hit shader
+    int sched_weight;          // TEXIR_SCHED_WEIGHT         0 (default: measured per scene by texir_scene_tune) | 1 | 2 forced
+    int mip_per_level;         // TEXIR_MIP_PER_LEVEL        0 | 1 = one launch per mip level (reference form kept for the parity tests)
+    int adam_scalar;           // TEXIR_ADAM_SCALAR          0 | 1 = scalar Adam kernel (reference form kept for the parity tests)
+    int adam_grid_y;           // TEXIR_ADAM_GRID_Y          0 = full grid | rows of blocks (probe)
+    int max_leaf;              // TEXIR_MAX_LEAF             0 = builder default | 1..8 triangles per leaf
+    int box_slack_log2;        // TEXIR_BOX_SLACK_LOG2       -19 (default) | 99 = no slack
+    int irt_texels_per_wave;   // TEXIR_IRT_TEXELS_PER_WAVE  0 = automatic | 1 | 64
+    int irt_min_part_cells;    // TEXIR_IRT_MIN_PART_CELLS   8 (default)
+    int irt_log2parts_cap;     // TEXIR_IRT_LOG2PARTS        -1 = no cap
+    int spec_grid_cap;         // TEXIR_SPEC_GRID_CAP        65536 (default)
+    int spec_lpp;              // TEXIR_SPEC_LPP             0 = automatic | forced lanes per pixel (power of two)
+};
+
+const Env& env();          // the current snapshot
+void env_reload();         // re-read the process environment (not thread-safe against concurrent launches: test use only)
+
+}  // namespace texir

@@ -9,6 +9,7 @@
 #include <cstdlib>
 
 #include "device_common.h"
+#include "env.h"
 #include "kernels.h"
 
 namespace texir {
@@ -520,14 +521,8 @@ static int resident_grid(K kernel, int block)
     return cus * per_cu;
 }
 
-// TEXIR_IRT_TEXELS_PER_WAVE = 1 | 64 forces the kernel form (A/B measurements, parity tests of each form); unset or 0 = automatic.
-// Read on every call, so a test can switch it between launches.
-static int irt_forced_texels_per_wave()
-{
-    const char* e = getenv("TEXIR_IRT_TEXELS_PER_WAVE");
-    const int v = e ? atoi(e) : 0;
-    return (v == 1 || v == 64) ? v : 0;
-}
+// TEXIR_IRT_TEXELS_PER_WAVE = 1 | 64 forces the kernel form (A/B measurements, parity tests of each form); unset or 0 = automatic (env.h).
+static int irt_forced_texels_per_wave() { return env().irt_texels_per_wave; }
 
 // Which kernel form a call launches (shared by launch_irt and texir_irt_kernel_name, so that a bench line names what really ran):
 // texels per wave: 64 from 32 768 listed texels up, else 1 (a short list does not fill the chip with 64-texel groups; measured on the
@@ -546,10 +541,9 @@ IrtPlan irt_plan(const SceneDev& sc, int64_t n_ids, int N)
     p.log2parts = 0;
     // parts per texel: up to 32, down to 8 passes per part (N = 2048: 32 parts of 64 passes; N = 64 -- the reference's own configuration -- 8 parts of 8:
     // with 64-pass parts its 3 053 chunks left two thirds of the 8 192 resident waves without work).  A function of N alone.
-    int min_cells = 8;
-    if (const char* e = getenv("TEXIR_IRT_MIN_PART_CELLS")) { const int v = atoi(e); if (v >= 1) min_cells = v; }       // A/B switch (round 2: 64)
+    const int min_cells = env().irt_min_part_cells;                                                                      // A/B switch (default 8; round 2: 64)
     if (sc.nodes4 && p.per_wave == 64 && pow2) { while (p.log2parts < 5 && (N >> (p.log2parts + 1)) >= min_cells) p.log2parts++; }
-    if (const char* cap = getenv("TEXIR_IRT_LOG2PARTS")) { if (p.log2parts > atoi(cap)) p.log2parts = atoi(cap) < 0 ? 0 : atoi(cap); }   // A/B switch
+    if (const int cap = env().irt_log2parts_cap; cap >= 0 && p.log2parts > cap) p.log2parts = cap;                        // A/B switch
     snprintf(p.name, sizeof(p.name), p.per_wave == 64 ? "irt_group_kernel<false, %d, 6>" : "irt_kernel<false, %d>", p.width);
     return p;
 }
@@ -608,7 +602,7 @@ hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, co
 
 // How full do this scene's node steps run?  A counting launch of the 64-texel form over `count` listed texels starting at `first` (min(N, 256) samples,
 // weight 2, partial sums into scratch: the caller's irradiance buffer is not touched) -> lanes taking part per wave-level node step / 64.
-// Blocks until the counters are back (once per scene: texir_irt_generate).
+// Blocks until the counters are back (once per scene: texir_scene_tune -- never from a *_generate / *_forward entry point).
 hipError_t irt_probe_node_utilisation(const SceneDev& sc, const float* pos, const float* nrm, const float* shift, const int32_t* ids, int64_t first, int64_t count,
                                       int N, int mode, unsigned long long* work, hipStream_t st, double* util)
 {
@@ -624,13 +618,15 @@ hipError_t irt_probe_node_utilisation(const SceneDev& sc, const float* pos, cons
     if ((e = hipMemsetAsync(work, 0, sizeof(unsigned long long) * 8 * kWorkStride, st)) != hipSuccess) return e;
     if ((e = hipMallocAsync((void**)&partial, (sizeof(float) * 3 * (size_t)count << log2parts) + 8 * sizeof(unsigned long long), st)) != hipSuccess) return e;
     stats = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(partial) + (sizeof(float) * 3 * (size_t)count << log2parts));
-    if ((e = hipMemsetAsync(stats, 0, 8 * sizeof(unsigned long long), st)) != hipSuccess) return e;
+    auto drop = [&](hipError_t err) { (void)hipFreeAsync(partial, st); return err; };           // (no error path keeps the scratch)
+    if ((e = hipMemsetAsync(stats, 0, 8 * sizeof(unsigned long long), st)) != hipSuccess) return drop(e);
     SceneDev probe = sc;
     probe.sched_weight = kSchedNodeWeight;
     irt_launch(irt_group_kernel<true, 4, 6>, ((count + 63) / 64) << log2parts, probe, pos, nrm, shift, ids + first, count, Nc, l2, mode, (float*)nullptr, stats, work, partial, log2parts, st);
     unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if ((e = hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    if ((e = hipGetLastError()) != hipSuccess) return drop(e);
+    if ((e = hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, st)) != hipSuccess) return drop(e);
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return drop(e);
     if ((e = hipFreeAsync(partial, st)) != hipSuccess) return e;
     if (h[4]) *util = (double)h[1] / (64.0 * (double)h[4]);          // node fetches / (64 x wave-level node steps)
     return hipGetLastError();
@@ -660,8 +656,7 @@ hipError_t launch_gen_dir(const float* normals, const float* rough, const float*
 // static stride over a few long ones.
 static int spec_grid(int64_t pix_per_block, int64_t P)
 {
-    int64_t cap = 1 << 16;
-    if (const char* e = getenv("TEXIR_SPEC_GRID_CAP")) { const int v = atoi(e); if (v >= 1) cap = v; }
+    const int64_t cap = env().spec_grid_cap;
     const int64_t want = (P + pix_per_block - 1) / pix_per_block;
     return (int)(want < 1 ? 1 : (want > cap ? cap : want));
 }
@@ -669,7 +664,7 @@ static int spec_grid(int64_t pix_per_block, int64_t P)
 static int lanes_per_pixel(int S)
 {
     int lpp = (S <= 64 && (S & (S - 1)) == 0) ? S : 64;
-    if (const char* e = getenv("TEXIR_SPEC_LPP")) { const int v = atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0 && v <= lpp) lpp = v; }
+    if (const int v = env().spec_lpp; v >= 1 && v <= lpp) lpp = v;
     return lpp;
 }
 

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "device_common.h"
+#include "env.h"
 #include "kernels.h"
 
 namespace texir {
@@ -519,7 +520,7 @@ static void launch_pyr_down_c(const float* src, float* rest, const MipDesc& d, i
 // builds levels from_level+1 .. levels-1 into `rest`; from_level = 0: from the caller's level-0 texture, = 1: level 1 is already
 // in `rest` (the fused optimiser wrote it while it updated the texture, texir_adam_step_tex)
 // TEXIR_MIP_PER_LEVEL=1 keeps the first implementation (one launch per level) alive: the parity tests run both and demand identical bits
-static bool mip_per_level() { const char* e = getenv("TEXIR_MIP_PER_LEVEL"); return e && atoi(e) != 0; }
+static bool mip_per_level() { return env().mip_per_level != 0; }
 
 hipError_t launch_mip_build(const float* tex, float* rest, int H, int W, int C, int levels, int from_level, hipStream_t st)
 {
@@ -782,10 +783,10 @@ hipError_t launch_adam_tex(float* p, const float* g, const uint32_t* l0_mask, co
         step_size = (float)((double)lr / bc1);
         bc2_sqrt = (float)sqrt(bc2);
     }
-    if ((W * C) % 4 == 0 && !getenv("TEXIR_ADAM_SCALAR")) {
+    if ((W * C) % 4 == 0 && !env().adam_scalar) {
         const int epb = adam_vec_epb(C);
         dim3 gridv((W * C + epb - 1) / epb, (H >> 1) > 2048 ? 2048 : (H >> 1));
-        if (const char* e = getenv("TEXIR_ADAM_GRID_Y")) { const int v = atoi(e); if (v >= 1 && v < (int)gridv.y) gridv.y = v; }      // (probe: fewer, longer blocks leave wave slots to a concurrent kernel)
+        if (const int v = env().adam_grid_y; v >= 1 && v < (int)gridv.y) gridv.y = v;      // (probe: fewer, longer blocks leave wave slots to a concurrent kernel)
         if (C == 1) hipLaunchKernelGGL(adam_tex_vec_kernel<1>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp);
         else if (C == 2) hipLaunchKernelGGL(adam_tex_vec_kernel<2>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp);
         else if (C == 3) hipLaunchKernelGGL(adam_tex_vec_kernel<3>, gridv, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp);

@@ -54,7 +54,9 @@ class GraphedMatStep:
         if record_step:
             # which parameters this graph steps (a stage-1 step leaves the albedo texture without gradient): their host-side step counts
             # advance per replay (FusedAdam.note_replayed_step)
-            self._stepping = [p for p in self.params if p.grad is not None or getattr(p, "_texir_grad_l1", None) is not None]
+            # (every parameter of the optimiser that holds a gradient is stepped by the recorded opt.step, not only self.params)
+            everyone = [q for grp in self.opt.param_groups for q in grp["params"]]
+            self._stepping = [p for p in everyone if p.grad is not None or getattr(p, "_texir_grad_l1", None) is not None]
             self.opt.step(_count_on_host=False)
         return loss
 
@@ -156,8 +158,15 @@ class GraphedMatStep:
         # texture was changed any other way since, rebuild the stack eagerly before replaying
         from .texture import refresh_mips
         for p in self.params:
-            if getattr(p, "_texir_mips", None) is not None and getattr(p, "_texir_mip1_fresh", None) != (p.data_ptr(), p._version):
-                refresh_mips(p)
+            mips = getattr(p, "_texir_mips", None)
+            if mips is None or getattr(p, "_texir_mip1_fresh", None) == (p.data_ptr(), p._version):
+                continue
+            # A texture this stage does not train (roughness in stage 0, albedo in stage 1) is never stepped, so the one-shot flag never
+            # matches -- but nothing changes it either: its stack, built in full by the eager warm-up, stays valid as long as the cache key
+            # (data pointer, version, shape) does.  The same rule texture._mips_for applies to any frozen texture; no build per replay.
+            if not p.requires_grad and mips[0][:2] == (p.data_ptr(), p._version):
+                continue
+            refresh_mips(p)
         if hasattr(self.opt, "prepare"):
             self.opt.prepare()                         # a learning-rate scheduler's change reaches the device record here
         self.graphs[(key, stage)].replay()

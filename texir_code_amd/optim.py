@@ -82,8 +82,32 @@ class FusedAdam(torch.optim.Optimizer):
         return st
 
     def load_state_dict(self, sd):
+        """Captured hipGraphs have the ADDRESSES of the moments and of the device-resident step / learning-rate records baked into their kernel
+        nodes, so loading must not replace those buffers: the loaded values are copied INTO the existing tensors (same shapes), and the device
+        records are overwritten in place from the loaded step counts.  Graphs recorded before the load therefore stay valid and continue from
+        the loaded state."""
+        old = {p: dict(st) for p, st in self.state.items()}
         super().load_state_dict(sd)
-        self._dev, self._rec = {}, {}            # (the device records are rebuilt from the loaded step counts on next use)
+        with torch.no_grad():
+            for p, st in self.state.items():
+                was = old.get(p)
+                if not was:
+                    continue
+                for k in ("exp_avg", "exp_avg_sq"):
+                    a, b = was.get(k), st.get(k)
+                    if torch.is_tensor(a) and torch.is_tensor(b) and a.shape == b.shape and a.device == b.device and a.dtype == b.dtype:
+                        a.copy_(b)
+                        st[k] = a
+            group_of = {id(q): g for g in self.param_groups for q in g["params"]}      # (load_state_dict installs NEW group dicts)
+            for device, d in self._dev.items():
+                d["groups"] = [group_of[id(q)] for q in d["params"]]
+                host = torch.zeros(tuple(d["state"].shape), dtype=torch.float64)
+                for i, (g, p) in enumerate(zip(d["groups"], d["params"])):
+                    st = self.state.get(p) or {}
+                    step = st.get("step", 0)
+                    host[i] = torch.tensor([float(step), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1])], dtype=torch.float64)
+                    d["lr"][i] = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]))
+                d["state"].copy_(host)
 
     def note_replayed_step(self, params):
         """a hipGraph replay has run the recorded step of `params`: advance the host mirrors of what the device did"""

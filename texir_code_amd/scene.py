@@ -130,6 +130,12 @@ class Scene:
             # nothing to do.  (An EMPTY id list must not reach the library: its null data pointer would read as "no list = all texels" --
             # the case of a rank whose shard of a small texel list is empty, dist_util.shard_block_cyclic)
             return (out, st) if stats else out
+        if ids is not None and n_ids >= 65536 and not getattr(self, "_tuned", False) and not torch.cuda.is_current_stream_capturing():
+            # once per scene, before its first long launch: measure how full the scene's node steps run and pick the phase scheduler's weight
+            # (texir_scene_tune: ~2 ms, blocking -- which is why it lives here and not inside the asynchronous texir_irt_generate)
+            _lib.check(_lib.lib().texir_scene_tune(self.h, _lib.ptr(pos), _lib.ptr(nrm), _lib.ptr(shift), _lib.ptr(ids), n_ids, int(n_samples),
+                                                   MODES[mode], _lib.stream_ptr()))
+            self._tuned = int(n_samples) >= 256
         _lib.check(_lib.lib().texir_irt_generate(self.h, _lib.ptr(pos), _lib.ptr(nrm), _lib.ptr(shift), _lib.ptr(ids), n_ids, Nt,
                                                  int(n_samples), MODES[mode], _lib.ptr(out), _lib.ptr(st), _lib.stream_ptr()))
         return (out, st) if stats else out

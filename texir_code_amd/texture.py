@@ -59,7 +59,9 @@ def refresh_mips(param):
         return
     H, W, C = param.shape
     levels = hit[0][5]
-    _lib.check(_lib.lib().texir_mip_build(_lib.ptr(param.detach()), _lib.ptr(hit[1]), H, W, C, levels, 0, _lib.stream_ptr()))
+    t0 = param.detach()
+    _lib.check(_lib.lib().texir_mip_build(_lib.ptr(t0), _lib.ptr(hit[1]), H, W, C, levels, 0, _lib.stream_ptr()))
+    param._texir_mips = ((t0.data_ptr(), t0._version, H, W, C, levels), hit[1])       # the stack now describes THIS version of the texture
     param._texir_mip1_fresh = None
 
 
