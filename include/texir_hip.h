@@ -76,6 +76,10 @@ TEXIR_API int texir_scene_info(const texir_scene* scene, int64_t out[8]);
 TEXIR_API int texir_scene_tune(const texir_scene* scene, const float* pos /*dev*/, const float* nrm /*dev*/, const float* shift /*dev*/,
                                const int32_t* texel_ids /*dev*/, int64_t n_ids, int32_t N, int32_t mode, void* stream);
 TEXIR_API int texir_scene_scheduler(const texir_scene* scene, double out[2]);
+/* Streams the scene's traversal data through the memory hierarchy (what: bit 0 quantised nodes, 1 float nodes, 2 triangles, 3 corner uvs;
+ * blocks = grid size, 0 -> 512): a cache warm-up to launch beside / before a latency-bound tracing kernel that follows a cache-flushing
+ * stream (the material step's fused Adam).  No reference counterpart (a speed hint: results never depend on it). */
+TEXIR_API int texir_scene_prefetch(const texir_scene* scene, int32_t what, int32_t blocks, void* stream);
 
 /* Replaces query_irf (models/tracer_o3d_irt.py:240-269, models/mat_nvdiffrast.py:292-320):
  * closest hit (Embree semantics: t>0, t in units of |dir|), hit mask t>t_min (reference: 1e-4) & finite,

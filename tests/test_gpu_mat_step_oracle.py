@@ -15,6 +15,7 @@ from conftest import rel_l2
 pytestmark = pytest.mark.gpu
 
 LR = 3e-2
+_OGB = {}          # the oracle's rasterised G-buffers (c, view) -> dict: independent of the texture sizes, ~15 s of numpy each
 
 
 def _world(golden, c, ra, rr, seed=11):
@@ -43,6 +44,7 @@ def _world(golden, c, ra, rr, seed=11):
         m.materials_a.copy_(a0.cuda())
         m.materials_r.copy_(r0.cuda())
     oracle = MS.MaterialStepOracle(osc, verts, tris, tri_uvs, cn, irrt, a0, r0, c, 16)
+    oracle._gb = _OGB.setdefault((c, seed), {})
     views = {}
     for key, E in (("v0", cameras.grid_cameras(2)[0]), ("v1", cameras.grid_cameras(2)[3])):
         mvp, cam = cameras.cube_mvps(E)

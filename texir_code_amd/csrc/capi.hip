@@ -165,6 +165,18 @@ int texir_scene_info(const texir_scene* s, int64_t out[8])
     return TEXIR_OK;
 }
 
+int texir_scene_prefetch(const texir_scene* s, int32_t what, int32_t blocks, void* stream)
+{
+    if (!s) return fail(TEXIR_ERR_INVALID, "texir_scene_prefetch: null argument");
+    if (blocks < 1) blocks = 512;
+    uint32_t* sink = reinterpret_cast<uint32_t*>(s->d_work);         // (never written in practice; any device word will do)
+    if ((what & 1) && s->d_nodes4) HIP_TRY(launch_prefetch(s->d_nodes4, (size_t)s->n_nodes4 * sizeof(GpuNode4), blocks, sink, (hipStream_t)stream));
+    if ((what & 2) && s->d_nodes4f) HIP_TRY(launch_prefetch(s->d_nodes4f, (size_t)s->n_nodes4 * sizeof(GpuNode4F), blocks, sink, (hipStream_t)stream));
+    if ((what & 4) && s->d_tris) HIP_TRY(launch_prefetch(s->d_tris, (size_t)s->n_tris * sizeof(GpuTri), blocks, sink, (hipStream_t)stream));
+    if ((what & 8) && s->d_uvs) HIP_TRY(launch_prefetch(s->d_uvs, (size_t)s->n_tris * sizeof(GpuTriUV), blocks, sink, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
 int texir_scene_scheduler(const texir_scene* s, double out[2])
 {
     if (!s || !out) return fail(TEXIR_ERR_INVALID, "texir_scene_scheduler: null argument");

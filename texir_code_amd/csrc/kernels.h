@@ -14,6 +14,7 @@ hipError_t irt_probe_node_utilisation(const SceneDev& sc, const float* pos, cons
                                       int N, int mode, unsigned long long* work, hipStream_t st, double* util);
 struct IrtPlan { int per_wave, log2parts, width; char name[64]; };
 IrtPlan irt_plan(const SceneDev& sc, int64_t n_ids, int N);      // the kernel form launch_irt picks for this call
+hipError_t launch_prefetch(const void* p, size_t bytes, int blocks, uint32_t* sink, hipStream_t st);
 size_t tex_retile_bytes(int Ht, int Wt, int layout, int* tiles_x, int* tiles_y);
 hipError_t launch_tex_retile(const float* src_row_major, float* dst, int Ht, int Wt, int layout, hipStream_t st);
 hipError_t launch_trace_shade(const SceneDev& sc, const float* org, const float* dir, int64_t R, float t_min, float* rad, float* t_hit,

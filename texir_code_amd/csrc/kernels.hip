@@ -289,6 +289,22 @@ __global__ __launch_bounds__(256) void tex_retile_kernel(const float* __restrict
     }
 }
 
+// Streams `n16` 16-byte words through the memory hierarchy and keeps nothing: after a kernel that has flushed the caches (the 1.8 GB stream of the
+// fused Adam), this brings the traversal data back into the memory-side Infinity Cache before the latency-bound specular trace starts.
+__global__ __launch_bounds__(256) void prefetch_kernel(const uint4* __restrict__ p, size_t n16, uint32_t* __restrict__ sink)
+{
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) { const uint4 v = p[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x9E3779B9u && sink) *sink = acc;          // (practically never: keeps the loads alive)
+}
+
+hipError_t launch_prefetch(const void* p, size_t bytes, int blocks, uint32_t* sink, hipStream_t st)
+{
+    if (!p || bytes < 16) return hipSuccess;
+    hipLaunchKernelGGL(prefetch_kernel, dim3(blocks), dim3(256), 0, st, (const uint4*)p, bytes / 16, sink);
+    return hipGetLastError();
+}
+
 size_t tex_retile_bytes(int Ht, int Wt, int layout, int* tiles_x, int* tiles_y)
 {
     if (layout == 2) { *tiles_x = (Wt + 1) / 2; *tiles_y = (Ht + 1) / 2; return (size_t)*tiles_x * *tiles_y * 128; }

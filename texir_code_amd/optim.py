@@ -236,8 +236,10 @@ class FusedAdam(torch.optim.Optimizer):
                     else:
                         # (another fetch of the same parameter also produced a dense gradient in this backward pass: fold the sparse part in)
                         H, W, C = p.shape
-                        bits = ((mask.view(-1, 1).to(torch.int64) >> torch.arange(32, device=p.device)) & 1).bool().reshape(-1)[:H * W].reshape(H, W)
-                        g[bits] += p._texir_g0[bits]
+                        # (elementwise, no boolean indexing: index_put with a mask synchronises and cannot be recorded into a hipGraph -- this is the
+                        # stage-1 step of a view that samples level 0: un-mipmapped fetch = dense gradient, trilinear fetch = sparse part)
+                        bits = ((mask.view(-1, 1) >> torch.arange(32, device=p.device, dtype=torch.int32)) & 1).bool().reshape(-1)[:H * W].reshape(H, W, 1)
+                        g.add_(torch.where(bits, p._texir_g0, torch.zeros((), device=p.device)))
                         mask = None
             if g1 is not None:
                 H, W, C = p.shape
