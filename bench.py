@@ -29,6 +29,7 @@ on this box's host cores on a bounded sample of the same workload.
 import argparse
 import hashlib
 import json
+import math
 import os
 import subprocess
 import sys
@@ -99,9 +100,63 @@ def algorithmic_bytes_per_ray(counters, spp):
     return 32.0 * nodes / rays + 36.0 * tris / rays + (hits / rays) * 72.0 + 45.0 / spp, nodes / rays, tris / rays, hits / rays
 
 
+def host_cpus():
+    """how many host CPUs this process may really use: the scheduler affinity mask, cut by a cgroup CPU quota if one is set"""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:
+            continue
+    return {"os_cpu_count": os.cpu_count(), "affinity": aff, "cgroup_cpus": None if quota is None else round(quota, 2),
+            "usable": max(1, min(aff, int(math.ceil(quota)) if quota else aff))}
+
+
+def open3d_leg(sc0, pos, nrm, valid, shift, spp, budget_s):
+    """BASELINE.md 2's PRIMARY baseline: the reference's own tracer -- Open3D's RaycastingScene (Embree) called in the reference's shape,
+    rays [512, N, 1, 6] per batch (models/tracer_o3d_irt.py:156-173, 242-244).  Returns None when open3d cannot be imported (it is not in this
+    image: the port below is what runs; the attempt is made so that a box that has it reports kind = "reference")."""
+    try:
+        import open3d as o3d
+    except Exception:
+        return None
+    from oracle import oracle as O
+    mesh = o3d.t.geometry.TriangleMesh()
+    mesh.vertex.positions = o3d.core.Tensor(np.ascontiguousarray(sc0["verts"], np.float32))
+    mesh.triangle.indices = o3d.core.Tensor(np.ascontiguousarray(sc0["tris"], np.uint32))
+    scene = o3d.t.geometry.RaycastingScene()
+    scene.add_triangles(mesh)
+    vid = np.argwhere(valid.reshape(-1) > 0)[:, 0]
+    rng = np.random.default_rng(0)
+    rays_done, t_used = 0, 0.0
+    while t_used < 0.6 * budget_s:
+        pick = rng.choice(vid, size=512, replace=False)
+        dirs = O.generate_dir(nrm.reshape(-1, 3)[pick], spp, "uniform", shift[pick])                       # [512, N, 3]
+        org = np.broadcast_to(pos.reshape(-1, 3)[pick][:, None, :], dirs.shape)
+        rays = np.ascontiguousarray(np.concatenate([org, dirs], -1)[:, :, None, :], np.float32)            # [512, N, 1, 6]
+        t0 = time.perf_counter()
+        scene.cast_rays(o3d.core.Tensor(rays))
+        t_used += time.perf_counter() - t0
+        rays_done += 512 * spp
+    hc = host_cpus()
+    return {"value": rays_done / t_used / 1e6, "unit": "Mrays/s", "cores": hc["usable"], "kind": "reference", "host": hc,
+            "sample": "%d rays in batches of [512, %d, 1, 6] through open3d.t.geometry.RaycastingScene.cast_rays (%.1f s), intersection only" % (rays_done, spp, t_used)}
+
+
 def cpu_leg(sc0, pos, nrm, valid, shift, spp, budget_s=15.0, timed=True):
-    """oracle timed on host cores on a bounded sample; also yields the algorithmic bytes/ray.  timed=False (N > 1: the CPU baseline is
-    reported at N = 1 only): just the small counting sample."""
+    """CPU baseline on the host cores, on a bounded sample of the same workload; also yields the algorithmic bytes/ray.  timed=False (N > 1: the CPU
+    baseline is reported at N = 1 only): just the small counting sample.  The reference's own tracer is tried first (open3d_leg); what runs in
+    this image is the port: the C oracle on its canonical BVH2, OpenMP over texels (schedule(dynamic, 1)), with the one-thread rate beside the
+    all-thread rate and the CPU count the process may really use (affinity mask and cgroup quota), so that the line can be judged as a baseline."""
     from oracle import oracle as O
     osc = O.Scene(sc0["verts"], sc0["tris"], sc0["tri_uvs"], sc0["hdr"])
     vid = np.argwhere(valid.reshape(-1) > 0)[:, 0]
@@ -115,17 +170,30 @@ def cpu_leg(sc0, pos, nrm, valid, shift, spp, budget_s=15.0, timed=True):
         osc.irt_generate(pos.reshape(-1, 3)[pick], nrm.reshape(-1, 3)[pick], None, shift[pick], spp, "uniform", tracer="bvh", counters=c)
         return time.perf_counter() - t0, c, pick.size
 
-    O.set_num_threads(os.cpu_count() or 1)       # all host cores (main() pinned torch's own host ops to one thread)
-    cores = O.num_threads()
-    run(cores)                                   # warm the thread pool / page in the BVH
-    dt, c, n = run(max(cores * 8, 64))           # calibration sample (dynamic schedule needs >> cores texels)
+    hc = host_cpus()
+    threads = hc["usable"]
+    O.set_num_threads(threads)                   # (main() pinned torch's own host ops to one thread, which lowers OpenMP's default)
+    run(threads)                                 # warm the thread pool / page in the BVH
+    dt, c, n = run(max(threads * 16, 64))        # calibration sample: >= 16 texels per thread for the dynamic schedule
     if not timed:
         return None, c
+    ref = open3d_leg(sc0, pos, nrm, valid, shift, spp, budget_s)
+    if ref is not None:
+        return ref, c
     rate = n * spp / dt
-    n_big = int(max(n, min(vid.size, 0.6 * budget_s * rate / spp)))
+    # one thread, ~2 s: the per-core rate the all-thread figure should be a multiple of
+    O.set_num_threads(1)
+    n1 = max(4, int(2.0 * (rate / threads) / spp))
+    dt1, _, n1 = run(n1)
+    one = n1 * spp / dt1 / 1e6
+    O.set_num_threads(threads)
+    n_big = int(max(n, threads * 16, min(vid.size, 0.6 * budget_s * rate / spp)))
     dt, c, n = run(n_big)
-    return {"value": n * spp / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "%d random valid texels x %d spp (%.1f s) of the same workload, canonical BVH2 oracle, OpenMP" % (n, spp, dt)}, c
+    val = n * spp / dt / 1e6
+    return {"value": val, "unit": "Mrays/s", "cores": threads, "kind": "port", "one_thread": round(one, 3), "per_thread": round(val / threads, 3),
+            "parallel_efficiency": round(val / (one * threads), 3), "host": hc, "omp_threads": O.num_threads(),
+            "sample": "%d random valid texels x %d spp (%.1f s) of the same workload, canonical BVH2 oracle, OpenMP schedule(dynamic, 1) over texels; "
+                      "one thread: %d texels (%.1f s)" % (n, spp, dt, n1, dt1)}, c
 
 
 def mat_setup(sc, sc0, irr_tex, res, dev, cube=128, S=16, tres=4096, n_views=16, fuse=True):

@@ -492,7 +492,7 @@ TXO_API void txo_irt_generate(const TxoScene *s, const float *pos, const float *
         float *th_ = (float *)malloc(sizeof(float) * (size_t)N);
         uint32_t *pid = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)N);
         float *puv = (float *)malloc(sizeof(float) * 2 * (size_t)N);
-#pragma omp for schedule(dynamic, 4) reduction(+ : tn, tt, tr, th)
+#pragma omp for schedule(dynamic, 1) reduction(+ : tn, tt, tr, th)
         for (int64_t p = 0; p < Nt; p++) {
             if (valid && !valid[p]) { irr[3 * p] = irr[3 * p + 1] = irr[3 * p + 2] = 0.f; continue; }
             const float *n = nrm + 3 * p;

@@ -286,3 +286,28 @@ def test_irt_generate_never_blocks_and_first_call_is_capturable():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, eager)
+
+
+@pytest.mark.parametrize("refill_at", ["32", "8", "63"])
+def test_refill_compaction_kernel_gives_the_same_bits(scan20k, tx, refill_at, monkeypatch):
+    """row g (north_star: "wavefront ballot / prefix-sum ray compaction"): irt_stream_kernel -- idle lanes take their texel's next direction cell
+    as soon as `refill_at` of them have gathered -- traces exactly the rays of the lock-step kernel and adds them in the same per-texel order: the
+    irradiance must be the SAME BITS, every ray counted once, on the hostile scan-style scene (rays of very different lengths in one wave)"""
+    sc0, sc, osc, pos, nrm, valid, shift = scan20k
+    v = np.argwhere(valid > 0)[:, 0]
+    assert v.size >= 40000
+    ids = torch.from_numpy(v[:40000 - 37].astype(np.int32)).cuda()           # ragged: the last wave is partly empty
+    args = (torch.from_numpy(pos), torch.from_numpy(nrm), torch.from_numpy(shift))
+    for N, mode in ((256, "uniform"), (64, "cosine")):
+        base, st0 = sc.irt_generate(*args, N, mode, texel_ids=ids, stats=True)
+        assert "irt_group_kernel" in sc.irt_kernel_name(ids.numel(), N)
+        monkeypatch.setenv("TEXIR_IRT_REFILL", refill_at)
+        assert "irt_stream_kernel" in sc.irt_kernel_name(ids.numel(), N)
+        got, st1 = sc.irt_generate(*args, N, mode, texel_ids=ids, stats=True)
+        plain = sc.irt_generate(*args, N, mode, texel_ids=ids)
+        monkeypatch.delenv("TEXIR_IRT_REFILL")
+        assert torch.equal(got, base) and torch.equal(plain, base)
+        a, b = st0.tolist(), st1.tolist()
+        assert a[0] == b[0] == ids.numel() * N and a[1] == b[1] and a[2] == b[2] and a[3] == b[3]      # rays, node fetches, triangle tests, hits: per-ray work unchanged
+        if refill_at != "63":
+            assert b[4] < a[4]                                                                          # fewer wave-level node steps: the point of it

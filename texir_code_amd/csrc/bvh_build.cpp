@@ -222,6 +222,56 @@ int32_t emit4(const Tmp* t, Emit4Ctx& cx, int depth)
     return idx;
 }
 
+// Memory order of the 4-wide tree (TEXIR_BVH_LAYOUT; the quantised and the float form stay index for index):
+//   0  depth-first as emitted: a node's FIRST child follows it, the other children lie a whole subtree away
+//   1  sibling blocks: the inner children of a node occupy consecutive slots (up to 4 x 64 B = two 128-byte lines), blocks in depth-first order
+//   2 / 3  treelets of 2 / 3 levels below their root, breadth-first inside (1 + 4 + 16 [+ 64] nodes contiguous), treelets in depth-first order
+// Only indices change: every ray visits the same nodes in the same order and finds the same hit.
+static void relayout4(std::vector<GpuNode4>& n4, std::vector<GpuNode4F>& n4f, int mode)
+{
+    const size_t n = n4.size();
+    if (mode <= 0 || n < 2) return;
+    std::vector<int32_t> order; order.reserve(n);
+    if (mode == 1) {
+        std::vector<int32_t> stack{0};
+        order.push_back(0);
+        while (!stack.empty()) {
+            const int32_t v = stack.back(); stack.pop_back();
+            int32_t kids[4]; int nk = 0;
+            for (int k = 0; k < 4; k++) if (n4[v].c[k] >= 0) kids[nk++] = n4[v].c[k];
+            for (int k = 0; k < nk; k++) order.push_back(kids[k]);
+            for (int k = nk - 1; k >= 0; k--) stack.push_back(kids[k]);
+        }
+    } else {
+        const int levels = mode == 2 ? 2 : 3;
+        std::vector<int32_t> roots{0};
+        std::vector<int32_t> cur, nxt;
+        while (!roots.empty()) {
+            const int32_t r = roots.back(); roots.pop_back();
+            cur.assign(1, r);
+            order.push_back(r);
+            for (int l = 0; l <= levels; l++) {
+                nxt.clear();
+                for (int32_t v : cur) for (int k = 0; k < 4; k++) if (n4[v].c[k] >= 0) nxt.push_back(n4[v].c[k]);
+                if (l < levels) for (int32_t v : nxt) order.push_back(v);
+                else for (auto it = nxt.rbegin(); it != nxt.rend(); ++it) roots.push_back(*it);        // next treelets, first child's first
+                cur.swap(nxt);
+            }
+        }
+    }
+    if (order.size() != n) return;                    // (cannot happen: every inner node is reachable exactly once)
+    std::vector<int32_t> where(n);
+    for (size_t i = 0; i < n; i++) where[(size_t)order[i]] = (int32_t)i;
+    std::vector<GpuNode4> a(n); std::vector<GpuNode4F> b(n4f.size());
+    for (size_t i = 0; i < n; i++) {
+        a[i] = n4[(size_t)order[i]];
+        for (int k = 0; k < 4; k++) if (a[i].c[k] >= 0) a[i].c[k] = where[(size_t)a[i].c[k]];
+        if (!n4f.empty()) { b[i] = n4f[(size_t)order[i]]; for (int k = 0; k < 4; k++) b[i].c[k] = a[i].c[k]; }
+    }
+    n4.swap(a);
+    if (!n4f.empty()) n4f.swap(b);
+}
+
 }  // namespace
 
 void build_bvh(const float* verts, int V, const int32_t* tris, int T, const float* tri_uvs, BvhHost& out)
@@ -272,6 +322,7 @@ void build_bvh(const float* verts, int V, const int32_t* tris, int T, const floa
     Emit4Ctx cx{slack, &out.nodes4, &out.nodes4f, ~(int32_t)(((uint32_t)T << 3) | 0u), 0};
     emit4(root.get(), cx, 1);
     out.max_depth4 = cx.max_depth;
+    relayout4(out.nodes4, out.nodes4f, env().bvh_layout);
     out.tris.resize((size_t)T + 1);
     std::memset(&out.tris[T], 0, sizeof(GpuTri));
     out.tris[T].prim = 0xFFFFFFFFu;

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "bvh_build.h"
 
 namespace texir {
@@ -204,6 +206,10 @@ struct Hit { float t, u, v; int slot; };
 #ifndef TEXIR_SCHED
 #define TEXIR_SCHED 1
 #endif
+// leaf steps specialised for the wave's common dominant ray axis (A/B switch; 0 = every leaf step selects the components per lane)
+#ifndef TEXIR_LEAF_UNIFORM_KZ
+#define TEXIR_LEAF_UNIFORM_KZ 1
+#endif
 #ifndef TEXIR_SCHED_NODE_WEIGHT
 #define TEXIR_SCHED_NODE_WEIGHT 2
 #endif
@@ -216,43 +222,79 @@ constexpr int kSchedNodeWeight = TEXIR_SCHED_NODE_WEIGHT;
 template <bool CULL> struct StackEntry { typedef int type; };
 template <> struct StackEntry<true> { typedef int2 type; };
 
-// closest hit of one ray per lane, run to completion (all lanes of the wave enter and leave together).  One instance per kernel: it
-// owns the LDS part of the stacks.  STATS: n_nodes / n_tris count this lane's node fetches and triangle tests; wave_iters[0/1] (if
-// given) count, on the first active lane, how many times the wave executed the node-step and the triangle-test bodies.
-template <bool STATS, int LSTK = kLdsStack, int WIDTH = 2, bool CULL = false>
-__device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float oy, float oz, float dx, float dy, float dz,
-                                             uint32_t& n_nodes, uint32_t& n_tris, uint32_t* wave_iters = nullptr)
+// trace_core is the traversal; trace_closest (one ray per lane, run to completion) and trace_stream (lanes take their NEXT ray while the others
+// are still under way: compaction by refill, see there) are its two drivers.
+struct NoNext { };
+template <bool STATS, int LSTK, int WIDTH, bool CULL, bool STREAM, typename Next>
+__device__ __forceinline__ Hit trace_core(const SceneDev& sc, float ox, float oy, float oz, float dx, float dy, float dz,
+                                          uint32_t& n_nodes, uint32_t& n_tris, uint32_t* wave_iters, int refill_at, Next&& next)
 {
     typedef typename StackEntry<CULL>::type Entry;
-    const float ooeps = 8.271806e-25f;  // 2^-80
-    const float idx = __builtin_amdgcn_rcpf(fabsf(dx) > ooeps ? dx : copysignf(ooeps, dx));
-    const float idy = __builtin_amdgcn_rcpf(fabsf(dy) > ooeps ? dy : copysignf(ooeps, dy));
-    const float idz = __builtin_amdgcn_rcpf(fabsf(dz) > ooeps ? dz : copysignf(ooeps, dz));
-    const float oodx = ox * idx, oody = oy * idy, oodz = oz * idz;
+    // what the traversal keeps of a ray (set by begin_ray; a streamed lane overwrites them when it takes its next ray)
+    float idx, idy, idz, oodx, oody, oodz;
+    uint32_t lon;
 #if TEXIR_TRI_WATERTIGHT
-    // rows of the ray-space shear: x' = A . mx, y' = A . my, z' = A . mz (A = vertex - origin).  kz = dominant axis of the direction,
-    // (kx, ky) the other two in an order that keeps the winding; the shear maps d to (0, 0, 1)
-    float mx[3], my[3], mz[3];
-    {
-        const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
-        const int kz = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
-        const float dkz = kz == 0 ? dx : (kz == 1 ? dy : dz);
-        const bool neg = dkz < 0.f;
-        const int k1 = kz == 2 ? 0 : kz + 1, k2 = k1 == 2 ? 0 : k1 + 1;
-        const int kx = neg ? k2 : k1, ky = neg ? k1 : k2;
-        const float dkx = kx == 0 ? dx : (kx == 1 ? dy : dz), dky = ky == 0 ? dx : (ky == 1 ? dy : dz);
-        const float Sz = __builtin_amdgcn_rcpf(dkz), Sx = dkx * Sz, Sy = dky * Sz;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            mx[c] = c == kx ? 1.f : (c == kz ? -Sx : 0.f);
-            my[c] = c == ky ? 1.f : (c == kz ? -Sy : 0.f);
-            mz[c] = c == kz ? Sz : 0.f;
-        }
-    }
+    // The ray-space shear of the watertight test: kz = dominant axis of the direction, (k1, k2) = the two axes that follow it cyclically;
+    // a vertex A (relative to the origin) maps to x' = A[k1] - Sx A[kz], y' = A[k2] - Sy A[kz], z' = Sz A[kz], which sends d to (0, 0, 1).
+    // (Woop et al. swap k1 / k2 for d[kz] < 0 to keep the winding: that negates U, V, W and their sum EXACTLY and changes neither the accept test --
+    // no two signs differ -- nor t, u, v; it is left out.)  What a ray carries into the leaf steps is (kz, Sx, Sy, Sz): 4 registers instead of the
+    // 9 of three general matrix rows.  When the rays of the wave share kz (one ~3-degree direction cell: they do unless the cell straddles a
+    // |dx| = |dy|-like plane) the leaf step runs a body specialised for that axis -- 3 sub + 2 fma + 1 mul per vertex, no component selects; the
+    // per-lane body selects the components and then evaluates the SAME expressions, so a ray's hit does not depend on its wave's company.
+    int kz; float Sx, Sy, Sz;
 #endif
+    auto begin_ray = [&]() __attribute__((always_inline)) {
+        const float ooeps = 8.271806e-25f;  // 2^-80
+        idx = __builtin_amdgcn_rcpf(fabsf(dx) > ooeps ? dx : copysignf(ooeps, dx));
+        idy = __builtin_amdgcn_rcpf(fabsf(dy) > ooeps ? dy : copysignf(ooeps, dy));
+        idz = __builtin_amdgcn_rcpf(fabsf(dz) > ooeps ? dz : copysignf(ooeps, dz));
+        oodx = ox * idx; oody = oy * idy; oodz = oz * idz;
+        // byte offsets of the NEAR plane array of each axis inside a 128-byte float node (far = offset ^ 16), wave-uniform when the rays' signs agree
+        lon = (idx < 0.f ? 16u : 0u) | ((idy < 0.f ? 48u : 32u) << 8) | ((idz < 0.f ? 80u : 64u) << 16);
+#if TEXIR_TRI_WATERTIGHT
+        const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
+        kz = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+        const float dkz = kz == 0 ? dx : (kz == 1 ? dy : dz);
+        const float dk1 = kz == 0 ? dy : (kz == 1 ? dz : dx), dk2 = kz == 0 ? dz : (kz == 1 ? dx : dy);
+        Sz = __builtin_amdgcn_rcpf(dkz); Sx = dk1 * Sz; Sy = dk2 * Sz;
+#endif
+    };
+    if constexpr (!STREAM) begin_ray();
+    else { idx = idy = idz = oodx = oody = oodz = 0.f; lon = 0u;
+#if TEXIR_TRI_WATERTIGHT
+           kz = 0; Sx = Sy = Sz = 0.f;
+#endif
+    }
+    // what the lanes of the wave agree on (decided per ray batch; a streamed wave decides again after every refill, over the lanes that hold a ray)
+    uint32_t son; bool signs_uniform; uint32_t son0, son1, son2;
+#if TEXIR_TRI_WATERTIGHT
+    int kz0; [[maybe_unused]] bool kz_uniform;
+#endif
+    // (`has`: this lane holds a ray under way -- always, except in a streamed wave)
+    auto agree = [&](bool has) __attribute__((always_inline)) {
+        if constexpr (STREAM) {
+            const unsigned long long m = __ballot(has);
+            const int src = m ? __ffsll((long long)m) - 1 : 0;
+            son = (uint32_t)__builtin_amdgcn_readlane((int)lon, src);
+            signs_uniform = WIDTH == 4 && sc.nodes4f != nullptr && !__any(has && lon != son);
+#if TEXIR_TRI_WATERTIGHT
+            kz0 = __builtin_amdgcn_readlane(kz, src);
+            kz_uniform = !__any(has && kz != kz0);
+#endif
+        } else {
+            son = (uint32_t)__builtin_amdgcn_readfirstlane((int)lon);
+            signs_uniform = WIDTH == 4 && sc.nodes4f != nullptr && !__any(lon != son);
+#if TEXIR_TRI_WATERTIGHT
+            kz0 = __builtin_amdgcn_readfirstlane(kz);
+            kz_uniform = !__any(kz != kz0);
+#endif
+        }
+        son0 = son & 255u; son1 = (son >> 8) & 255u; son2 = son >> 16;
+    };
+    agree(true);
     Hit h;
     h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f; h.slot = -1;
-    int node = 0;
+    int node = STREAM ? kSentinel : 0;                       // (a streamed lane gets its first ray from `next` like every later one)
     auto first_active = [&]() -> bool { unsigned long long m = __ballot(1); return (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1; };
     // the traversal stack: LSTK entries per lane in LDS ([entry][thread]), deeper ones private.  The stack pointer is kept as
     // the LDS address of the next free entry (push = ds_write + one add, no index scaling in the node step).
@@ -261,11 +303,6 @@ __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float
     Entry* const base = lds_all + threadIdx.x;
     Entry* const lim = base + LSTK * kBlock;
     Entry* top = base;
-    // byte offsets of the NEAR plane array of each axis inside a 128-byte float node (far = offset ^ 16), wave-uniform when the rays' signs agree
-    const uint32_t lon = (idx < 0.f ? 16u : 0u) | ((idy < 0.f ? 48u : 32u) << 8) | ((idz < 0.f ? 80u : 64u) << 16);
-    const uint32_t son = (uint32_t)__builtin_amdgcn_readfirstlane((int)lon);
-    const bool signs_uniform = WIDTH == 4 && sc.nodes4f != nullptr && !__any(lon != son);
-    const uint32_t son0 = son & 255u, son1 = (son >> 8) & 255u, son2 = son >> 16;
     auto make = [](int code, float tn) -> Entry { if constexpr (CULL) return make_int2(code, __float_as_int(tn)); else return code; };
     // LDS part and private overflow are kept in separate, wave-uniformly guarded code paths: the overflow is almost never
     // touched (depth > LSTK), and hipcc must not merge the two address spaces into one flat access
@@ -393,7 +430,9 @@ __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float
     };
 
     // ---- one leaf: test its triangles, then pop (the pop drops what this leaf's hit has just put out of reach) ----
-    auto leaf_step = [&]() __attribute__((always_inline)) {
+    // KZ = std::integral_constant<int, 0 | 1 | 2>: the wave's common dominant axis; -1: per lane
+    auto leaf_body = [&](auto KZ) __attribute__((always_inline)) {
+        constexpr int kzc = decltype(KZ)::value;
         const uint32_t code = ~(uint32_t)node;
         const int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
         for (int i = first; i < first + cnt; i++) {
@@ -402,19 +441,21 @@ __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float
             if (STATS) { n_tris++; if (wave_iters && first_active()) wave_iters[1]++; }
 #if TEXIR_TRI_WATERTIGHT
             // (tp[1], tp[2] hold the vertices v1, v2 here, not edges.)  Shear the three vertices into ray space ...
-            const float a0 = v0.x - ox, a1 = v0.y - oy, a2 = v0.z - oz;
-            const float b0 = e1.x - ox, b1 = e1.y - oy, b2 = e1.z - oz;
-            const float c0 = e2.x - ox, c1 = e2.y - oy, c2 = e2.z - oz;
-            const float Ax = __builtin_fmaf(a2, mx[2], __builtin_fmaf(a1, mx[1], a0 * mx[0])), Ay = __builtin_fmaf(a2, my[2], __builtin_fmaf(a1, my[1], a0 * my[0]));
-            const float Bx = __builtin_fmaf(b2, mx[2], __builtin_fmaf(b1, mx[1], b0 * mx[0])), By = __builtin_fmaf(b2, my[2], __builtin_fmaf(b1, my[1], b0 * my[0]));
-            const float Cx = __builtin_fmaf(c2, mx[2], __builtin_fmaf(c1, mx[1], c0 * mx[0])), Cy = __builtin_fmaf(c2, my[2], __builtin_fmaf(c1, my[1], c0 * my[0]));
+            auto shear = [&](float p0, float p1, float p2, float& X, float& Y, float& Z) __attribute__((always_inline)) {
+                const float q0 = p0 - ox, q1 = p1 - oy, q2 = p2 - oz;
+                float qz, qx, qy;
+                if constexpr (kzc == 0) { qz = q0; qx = q1; qy = q2; }
+                else if constexpr (kzc == 1) { qz = q1; qx = q2; qy = q0; }
+                else if constexpr (kzc == 2) { qz = q2; qx = q0; qy = q1; }
+                else { qz = kz == 0 ? q0 : (kz == 1 ? q1 : q2); qx = kz == 0 ? q1 : (kz == 1 ? q2 : q0); qy = kz == 0 ? q2 : (kz == 1 ? q0 : q1); }
+                X = __builtin_fmaf(-Sx, qz, qx); Y = __builtin_fmaf(-Sy, qz, qy); Z = Sz * qz;
+            };
+            float Ax, Ay, Az, Bx, By, Bz, Cx, Cy, Cz;
+            shear(v0.x, v0.y, v0.z, Ax, Ay, Az); shear(e1.x, e1.y, e1.z, Bx, By, Bz); shear(e2.x, e2.y, e2.z, Cx, Cy, Cz);
             // ... 2D edge functions with exact signs (edge2_exact): U, V, W = unnormalised weights of v0, v1, v2
             const float U = edge2_exact(Bx, By, Cx, Cy), V = edge2_exact(Cx, Cy, Ax, Ay), W = edge2_exact(Ax, Ay, Bx, By);
             const float mn = fminf(fminf(U, V), W), mxw = fmaxf(fmaxf(U, V), W);
             const float det = U + V + W;
-            const float Az = __builtin_fmaf(a2, mz[2], __builtin_fmaf(a1, mz[1], a0 * mz[0]));
-            const float Bz = __builtin_fmaf(b2, mz[2], __builtin_fmaf(b1, mz[1], b0 * mz[0]));
-            const float Cz = __builtin_fmaf(c2, mz[2], __builtin_fmaf(c1, mz[1], c0 * mz[0]));
             const float inv = __builtin_amdgcn_rcpf(det);
             const float t = (U * Az + V * Bz + W * Cz) * inv;
             const float u = V * inv, v = W * inv;
@@ -436,10 +477,50 @@ __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float
         }
         node = pop();
     };
+    auto leaf_step = [&]() __attribute__((always_inline)) {
+#if TEXIR_TRI_WATERTIGHT && TEXIR_LEAF_UNIFORM_KZ
+        if (kz_uniform) {
+            if (kz0 == 0) leaf_body(std::integral_constant<int, 0>{});
+            else if (kz0 == 1) leaf_body(std::integral_constant<int, 1>{});
+            else leaf_body(std::integral_constant<int, 2>{});
+        } else
+#endif
+        leaf_body(std::integral_constant<int, -1>{});
+    };
     auto node_step = [&]() __attribute__((always_inline)) { if constexpr (WIDTH == 4) node_step4(); else node_step2(); };
 
-#if TEXIR_SCHED
     const int sched_w = sc.sched_weight > 0 ? sc.sched_weight : kSchedNodeWeight;      // (wave-uniform: an SGPR)
+    if constexpr (STREAM) {
+        // Compaction by refill (SURVEY / north_star: "wavefront ballot / prefix-sum ray compaction").  A lane whose ray is finished does not wait for
+        // the slowest ray of the batch: once `refill_at` lanes of the wave are idle (ballot + s_bcnt1) they hand their hit to `next`, which shades and
+        // accumulates it and gives the lane its NEXT ray (the caller's next direction cell of the same texel) -- the wave stays full while rays of
+        // very different lengths pass through it.  next(finished, h, dx, dy, dz) -> true if the lane has a new ray in (dx, dy, dz).
+        // Every ray still performs exactly the same node visits and triangle tests, and a lane accumulates its samples in its own cell order: the
+        // sums are the same bits as the lock-step kernel's.
+        bool holds = false;                                  // this lane holds a finished ray that has not been handed over yet
+        bool more = true;                                    // `next` may still have rays for this lane
+        for (;;) {
+            const bool at_node = (uint32_t)node < (uint32_t)kSentinel;
+            const unsigned long long m_node = __ballot(at_node), m_leaf = __ballot(node < 0);
+            const bool idle = node == kSentinel && (holds || more);
+            const unsigned long long m_idle = __ballot(idle);
+            const bool drained = !(m_node | m_leaf);
+            if (drained && !m_idle) break;
+            if (drained || __popcll(m_idle) >= refill_at) {
+                if (idle) {
+                    const bool got = next(holds, h, dx, dy, dz);
+                    holds = got; more = got;
+                    if (got) { begin_ray(); h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f; h.slot = -1; node = 0; top = base; }
+                }
+                agree(node != kSentinel);                    // (over the lanes that hold a ray now; lanes without one take part in no step)
+                continue;
+            }
+            if (sched_w * __popcll(m_node) >= __popcll(m_leaf)) { if (at_node) node_step(); }
+            else if (node < 0) leaf_step();
+        }
+        return h;
+    } else {
+#if TEXIR_SCHED
     for (;;) {
         const bool at_node = (uint32_t)node < (uint32_t)kSentinel;        // an inner node (>= 0 and not the sentinel)
         const unsigned long long m_node = __ballot(at_node), m_leaf = __ballot(node < 0);
@@ -454,6 +535,27 @@ __device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float
     }
 #endif
     return h;
+    }
+}
+
+// closest hit of one ray per lane, run to completion (all lanes of the wave enter and leave together).  One instance per kernel: it
+// owns the LDS part of the stacks.  STATS: n_nodes / n_tris count this lane's node fetches and triangle tests; wave_iters[0/1] (if
+// given) count, on the first active lane, how many times the wave executed the node-step and the triangle-test bodies.
+template <bool STATS, int LSTK = kLdsStack, int WIDTH = 2, bool CULL = false>
+__device__ __forceinline__ Hit trace_closest(const SceneDev& sc, float ox, float oy, float oz, float dx, float dy, float dz,
+                                             uint32_t& n_nodes, uint32_t& n_tris, uint32_t* wave_iters = nullptr)
+{
+    return trace_core<STATS, LSTK, WIDTH, CULL, false>(sc, ox, oy, oz, dx, dy, dz, n_nodes, n_tris, wave_iters, 64, NoNext{});
+}
+
+// Streamed form: every ray of the lane, the first one included, comes from `next`, which is called for the idle lanes once `refill_at` of them have
+// gathered (or the wave has run dry): next(finished, hit, dx, dy, dz) first consumes the finished ray's hit (finished = false on a lane's first call),
+// then returns true with the lane's next direction, or false when the lane has no ray left.
+template <bool STATS, int LSTK, int WIDTH, bool CULL, typename Next>
+__device__ __forceinline__ void trace_stream(const SceneDev& sc, float ox, float oy, float oz, uint32_t& n_nodes, uint32_t& n_tris, uint32_t* wave_iters,
+                                             int refill_at, Next&& next)
+{
+    (void)trace_core<STATS, LSTK, WIDTH, CULL, true>(sc, ox, oy, oz, 0.f, 0.f, 0.f, n_nodes, n_tris, wave_iters, refill_at, next);
 }
 
 __device__ __forceinline__ float wave_sum(float x)

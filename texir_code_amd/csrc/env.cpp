@@ -16,6 +16,7 @@ static Env parse()
 {
     Env v{};
     v.bvh_width = geti("TEXIR_BVH_WIDTH", 4);
+    v.bvh_layout = std::min(3, std::max(0, geti("TEXIR_BVH_LAYOUT", 0)));
     v.uniform_float = geti("TEXIR_UNIFORM_FLOAT", 1) != 0;
     v.tex_layout = geti("TEXIR_TEX_LAYOUT", 2);
     const int w = geti("TEXIR_SCHED_WEIGHT", 0);
@@ -28,6 +29,8 @@ static Env parse()
     v.box_slack_log2 = geti("TEXIR_BOX_SLACK_LOG2", -19);
     const int pw = geti("TEXIR_IRT_TEXELS_PER_WAVE", 0);
     v.irt_texels_per_wave = (pw == 1 || pw == 64) ? pw : 0;
+    const int rf = geti("TEXIR_IRT_REFILL", 0);
+    v.irt_refill = (rf >= 1 && rf <= 63) ? rf : 0;
     const int mc = geti("TEXIR_IRT_MIN_PART_CELLS", 8);
     v.irt_min_part_cells = mc >= 1 ? mc : 8;
     v.irt_log2parts_cap = getenv("TEXIR_IRT_LOG2PARTS") ? std::max(0, geti("TEXIR_IRT_LOG2PARTS", 0)) : -1;

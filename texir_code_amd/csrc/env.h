@@ -6,6 +6,7 @@ namespace texir {
 
 struct Env {
     int bvh_width;             // TEXIR_BVH_WIDTH            4 (default) | 2 = binary tree only
+    int bvh_layout;            // TEXIR_BVH_LAYOUT           0 depth-first | 1 sibling blocks | 2, 3 treelets (bvh_build.cpp relayout4)
     int uniform_float;         // TEXIR_UNIFORM_FLOAT        1 (default) | 0 = scenes without the float node copy (every node step per lane)
     int tex_layout;            // TEXIR_TEX_LAYOUT           2 (default) | 1 | 0: radiance-texture layout read by the hit shader
     int sched_weight;          // TEXIR_SCHED_WEIGHT         0 (default: measured per scene by texir_scene_tune) | 1 | 2 forced
@@ -15,6 +16,7 @@ struct Env {
     int max_leaf;              // TEXIR_MAX_LEAF             0 = builder default | 1..8 triangles per leaf
     int box_slack_log2;        // TEXIR_BOX_SLACK_LOG2       -19 (default) | 99 = no slack
     int irt_texels_per_wave;   // TEXIR_IRT_TEXELS_PER_WAVE  0 = automatic | 1 | 64
+    int irt_refill;            // TEXIR_IRT_REFILL           0 = lock-step passes (default) | 1..63: refill idle lanes once this many have gathered (irt_stream_kernel)
     int irt_min_part_cells;    // TEXIR_IRT_MIN_PART_CELLS   8 (default)
     int irt_log2parts_cap;     // TEXIR_IRT_LOG2PARTS        -1 = no cap
     int spec_grid_cap;         // TEXIR_SPEC_GRID_CAP        65536 (default)

@@ -243,6 +243,81 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
     if (STATS) irt_stats_flush(stats, lane, c_rays, cn, ct, c_hits, wi[0], wi[1]);
 }
 
+// irt_group_kernel with compaction by refill (device_common.h trace_core<STREAM>): same chunks, same hand-out, same per-lane sample order and
+// partial sums; a lane whose ray has ended takes its texel's next direction cell as soon as `refill_at` lanes of the wave are idle instead of
+// waiting for the slowest ray of the pass.  Launched when TEXIR_IRT_REFILL = 1..63 (A/B switch); power-of-two N only.
+template <bool STATS, int WIDTH>
+__global__ __launch_bounds__(kBlock, kGroupWaves) void irt_stream_kernel(SceneDev sc, const float* __restrict__ pos, const float* __restrict__ nrm,
+                                                            const float* __restrict__ shift, const int32_t* __restrict__ ids, int64_t n_ids,
+                                                            int N, int log2N, int mode, float* __restrict__ irr,
+                                                            unsigned long long* __restrict__ stats, unsigned long long* __restrict__ work,
+                                                            float* __restrict__ partial, int log2parts, int refill_at)
+{
+    constexpr int GRP = 64;
+    const int lane = threadIdx.x & 63;
+    const int n_cells = N;
+    uint32_t cn = 0, ct = 0, c_rays = 0, c_hits = 0, wi[2] = {0, 0};
+    const bool cosw = (mode & kEstimatorCosine) != 0;
+    mode &= 3;
+    const int part_cells = n_cells >> log2parts;
+    const int bphi = (log2N + 1) >> 1, bth = log2N - bphi;
+    const int n_own = (TEXIR_XCD_SCHED && log2parts >= 3) ? 8 : 1;
+    const int log2ppo = log2parts - (n_own == 8 ? 3 : 0);
+    const int64_t n_groups = (n_ids + GRP - 1) / GRP;
+    int owner = n_own == 8 ? (__builtin_amdgcn_s_getreg(6164 /* hwreg(HW_REG_XCC_ID, 0, 4) */) & 7) : 0;
+    int dry = 0;
+    for (;;) {
+        unsigned long long chunk = 0;
+        if (lane == 0) chunk = atomicAdd(work + owner * kWorkStride, 1ull);
+        chunk = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(chunk >> 32)) << 32) |
+                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)chunk);
+        if ((int64_t)(chunk >> log2ppo) >= n_groups) {
+            if (++dry >= n_own) break;
+            owner = (owner + 1) & (n_own - 1);
+            continue;
+        }
+        dry = 0;
+        const int part = (owner << log2ppo) | (int)(chunk & ((1ull << log2ppo) - 1ull));
+        const int64_t k = (int64_t)(chunk >> log2ppo) * GRP + lane;
+        const bool live = k < n_ids;
+        const int64_t t = live ? (ids ? (int64_t)ids[k] : k) : 0;
+        const float px = pos[3 * t], py = pos[3 * t + 1], pz = pos[3 * t + 2];
+        const float nx = nrm[3 * t], ny = nrm[3 * t + 1], nz = nrm[3 * t + 2];
+        const float sh0 = shift[2 * t], sh1 = shift[2 * t + 1];
+        const Frame f = make_frame(nx, ny, nz);
+        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+        if (live) {
+            int Lc = part * part_cells;
+            const int Lend = Lc + part_cells;
+            float ndl = 0.f;
+            auto next = [&](bool finished, const Hit& h, float& dx, float& dy, float& dz) -> bool {
+                if (finished && h.slot >= 0 && h.t > 1e-4f) {          // tracer_o3d_irt.py:248
+                    float L[3];
+                    shade_hit(sc, h.slot, h.u, h.v, L);
+                    acc0 += L[0] * ndl; acc1 += L[1] * ndl; acc2 += L[2] * ndl;
+                    if (STATS) c_hits++;
+                }
+                if (Lc >= Lend) return false;
+                const int J = TEXIR_PART_WEDGE ? (((Lc & ((1 << bth) - 1)) << bphi) | (Lc >> bth)) : Lc;
+                Lc++;
+                const uint32_t i = sample_index_m(cell_to_pass_m((uint32_t)J, sh0, sh1, log2N, 0), 0u, log2N, 0);
+                const float s0 = shift_wrap_clamp(ham0(i, (uint32_t)N), sh0);
+                const float s1 = shift_wrap_clamp(ham1(i), sh1);
+                float d[3];
+                sample_dir<TEXIR_IRT_FAST_SINCOS != 0>(mode, s0, s1, 0.f, f, d);
+                ndl = cosw ? 1.f : fminf(fmaxf(nx * d[0] + ny * d[1] + nz * d[2], 0.f), 1.f);       // :170, RAW normal
+                dx = d[0]; dy = d[1]; dz = d[2];
+                if (STATS) c_rays++;
+                return true;
+            };
+            trace_stream<STATS, kGroupLstk, WIDTH, kCull>(sc, px, py, pz, cn, ct, STATS ? wi : nullptr, refill_at, next);
+            float* o = partial + ((int64_t)part * n_ids + k) * 3;
+            o[0] = acc0; o[1] = acc1; o[2] = acc2;
+        }
+    }
+    if (STATS) irt_stats_flush(stats, lane, c_rays, cn, ct, c_hits, wi[0], wi[1]);
+}
+
 // irr[t] = (2 pi / N) * (partial sums of the texel's pass ranges, added in part order)          (tracer_o3d_irt.py:171)
 __global__ __launch_bounds__(256) void irt_combine_kernel(const float* __restrict__ partial, const int32_t* __restrict__ ids, int64_t n_ids,
                                                           int parts, int N, float two, float* __restrict__ irr)
@@ -560,7 +635,9 @@ IrtPlan irt_plan(const SceneDev& sc, int64_t n_ids, int N)
     const int min_cells = env().irt_min_part_cells;                                                                      // A/B switch (default 8; round 2: 64)
     if (sc.nodes4 && p.per_wave == 64 && pow2) { while (p.log2parts < 5 && (N >> (p.log2parts + 1)) >= min_cells) p.log2parts++; }
     if (const int cap = env().irt_log2parts_cap; cap >= 0 && p.log2parts > cap) p.log2parts = cap;                        // A/B switch
-    snprintf(p.name, sizeof(p.name), p.per_wave == 64 ? "irt_group_kernel<false, %d, 6>" : "irt_kernel<false, %d>", p.width);
+    const bool stream = p.per_wave == 64 && env().irt_refill && pow2 && p.log2parts > 0;
+    if (stream) snprintf(p.name, sizeof(p.name), "irt_stream_kernel<false, %d>", p.width);
+    else snprintf(p.name, sizeof(p.name), p.per_wave == 64 ? "irt_group_kernel<false, %d, 6>" : "irt_kernel<false, %d>", p.width);
     return p;
 }
 
@@ -607,6 +684,18 @@ hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, co
     }
     if (!sc.nodes4) TEXIR_IRT(n_ids, l2, irt_kernel, 2)                                        // deep binary tree (capi.hip fallback)
     else if (per_wave == 1) TEXIR_IRT(n_ids, l2, irt_kernel, 4)
+    else if (env().irt_refill && pow2 && log2parts > 0) {
+        // compaction by refill (A/B switch TEXIR_IRT_REFILL = lanes that must be idle before a refill)
+        const int64_t waves = ((n_ids + 63) / 64) << log2parts;
+        const int64_t want = (waves + (kBlock / 64) - 1) / (kBlock / 64);
+        if (stats) {
+            int grid = resident_grid(irt_stream_kernel<true, 4>, kBlock); if (want < grid) grid = (int)want;
+            hipLaunchKernelGGL((irt_stream_kernel<true, 4>), dim3(grid), dim3(kBlock), 0, st, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, irr, stats, work, partial, log2parts, env().irt_refill);
+        } else {
+            int grid = resident_grid(irt_stream_kernel<false, 4>, kBlock); if (want < grid) grid = (int)want;
+            hipLaunchKernelGGL((irt_stream_kernel<false, 4>), dim3(grid), dim3(kBlock), 0, st, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, irr, stats, work, partial, log2parts, env().irt_refill);
+        }
+    }
     else TEXIR_IRT(((n_ids + 63) / 64) << log2parts, pow2 ? l2 : -1, irt_group_kernel, 4, 6)   // any N (natural sample order if not 2^k)
 #undef TEXIR_IRT
     if (log2parts) {
