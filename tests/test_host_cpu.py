@@ -288,3 +288,78 @@ def test_png_adaptive_filters_palette_and_rle_hdr(tmp_path):
     IO.write_png(str(d / "roomSegs_uchar_f0.png"), col)
     room = D.parse_roomseg(str(d))[-1]
     assert room.shape == (1, 1, 6, 8) and float(room.unique()) == 30.0
+
+
+def test_png_decoder_against_pillow_encoded_files(tmp_path):
+    """an INDEPENDENT encoder.  Pillow (libpng-compatible zlib streams, its own adaptive filter choice) writes 8-bit RGB / RGBA / grey and
+    16-bit grey images; io_formats.read_png must return the arrays that went in (and what Pillow itself decodes), and the files must together
+    exercise the filter types Pillow's heuristic produces"""
+    import zlib
+    from PIL import Image
+    from texir_code_amd import io_formats as IO
+    rng = np.random.default_rng(12)
+    H, W = 61, 83
+    yy, xx = np.mgrid[0:H, 0:W]
+    seen = set()
+
+    def filters_of(path, stride):
+        data = open(path, "rb").read()
+        pos, idat = 8, b""
+        while pos < len(data):
+            n, tag = int.from_bytes(data[pos:pos + 4], "big"), data[pos + 4:pos + 8]
+            if tag == b"IDAT":
+                idat += data[pos + 8:pos + 8 + n]
+            pos += 12 + n
+        raw = zlib.decompress(idat)
+        return {raw[y * (stride + 1)] for y in range(H)}
+
+    cases = []
+    smooth = ((xx * 3 + yy * 2) % 256).astype(np.uint8)
+    noise = rng.integers(0, 256, (H, W)).astype(np.uint8)
+    cases.append(("rgb_smooth", np.stack([smooth, smooth[::-1], (xx * yy % 251).astype(np.uint8)], -1), "RGB"))
+    cases.append(("rgb_noise", rng.integers(0, 256, (H, W, 3)).astype(np.uint8), "RGB"))
+    cases.append(("rgba_mixed", np.stack([smooth, noise, (yy * 4 % 256).astype(np.uint8), np.where(xx > 40, 255, 7).astype(np.uint8)], -1), "RGBA"))
+    cases.append(("grey_rows", np.repeat((yy[:, :1] * 4 % 256).astype(np.uint8), W, 1), "L"))
+    cases.append(("grey16_ramp", (xx * 700 + yy * 13).astype(np.uint16), "I;16"))
+    cases.append(("grey16_noise", rng.integers(0, 65536, (H, W)).astype(np.uint16), "I;16"))
+    avg = rng.integers(0, 256, (H, W)).astype(np.int64)   # two pixels in three = floor(mean(left, above)), the third random: only the Average filter predicts it
+    for y in range(1, H):
+        for x in range(1, W):
+            if x % 3:
+                avg[y, x] = (avg[y, x - 1] + avg[y - 1, x]) // 2
+    cases.append(("grey_average", avg.astype(np.uint8), "L"))
+    for name, arr, mode in cases:
+        for level in (1, 9):
+            p = str(tmp_path / ("%s_%d.png" % (name, level)))
+            (Image.fromarray(arr) if mode != "I;16" else Image.fromarray(arr, mode)).save(p, compress_level=level)
+            got = IO.read_png(p)
+            want = arr if arr.ndim == 3 else arr[..., None]
+            assert got.dtype == want.dtype and np.array_equal(got, want), name
+            back = np.asarray(Image.open(p))
+            assert np.array_equal(got.reshape(back.shape), back.astype(got.dtype)), name
+            seen |= filters_of(p, want.shape[1] * want.shape[2] * want.dtype.itemsize)
+    # None, Sub, Up and Paeth scanlines all occur in Pillow's output (its heuristic never picks Average on these images: that filter type is covered by the
+    # hand-filtered files of test_png_adaptive_filters_palette_and_rle_hdr)
+    assert seen >= {0, 1, 2, 4}, seen
+
+
+def test_rle_hdr_decoder_on_a_hand_assembled_byte_string(tmp_path):
+    """a new-style RLE Radiance file written out byte by byte (no encoder of this repo involved) against its closed-form content:
+    runs, literals, a run crossing nothing (per-channel planes), cv2's decoding rule value = mantissa * 2^(e - 136) (no + 0.5)"""
+    from texir_code_amd import io_formats as IO
+    W = 8
+    line0 = bytes([2, 2, 0, W]) + bytes([128 + 8, 128]) + bytes([128 + 8, 64]) + bytes([128 + 8, 32]) + bytes([128 + 8, 129])
+    # second scanline: R = literal 1..8; G = run of 3 x 200 then literal of 5; B = two runs of 4; E = 128 everywhere except a literal tail
+    line1 = (bytes([2, 2, 0, W]) + bytes([8, 1, 2, 3, 4, 5, 6, 7, 8]) + bytes([128 + 3, 200, 5, 10, 20, 30, 40, 50])
+             + bytes([128 + 4, 16, 128 + 4, 255]) + bytes([128 + 6, 128, 2, 130, 0]))
+    p = str(tmp_path / "hand.hdr")
+    with open(p, "wb") as f:
+        f.write(b"#?RADIANCE\n# hand-assembled\nFORMAT=32-bit_rle_rgbe\n\n-Y 2 +X 8\n" + line0 + line1)
+    img = IO.read_hdr(p)
+    assert img.shape == (2, 8, 3) and img.dtype == np.float32
+    assert np.array_equal(img[0], np.tile(np.array([1.0, 0.5, 0.25], np.float32), (8, 1)))
+    R = np.arange(1, 9, dtype=np.float32)
+    G = np.array([200, 200, 200, 10, 20, 30, 40, 50], np.float32)
+    B = np.array([16, 16, 16, 16, 255, 255, 255, 255], np.float32)
+    scale = np.array([2.0 ** -8] * 6 + [2.0 ** -6, 0.0], np.float32)            # e = 128 -> 2^-8; 130 -> 2^-6; e = 0 -> the pixel is black
+    assert np.array_equal(img[1], np.stack([R, G, B], -1) * scale[:, None])

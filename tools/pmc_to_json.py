@@ -21,7 +21,7 @@ res = {"workload": wl, "kernel": kernel, "kernel_src_sha": bench.kernel_src_sha(
        "counters": dict(c), "kernel_ms_under_pmc": dur}
 rd = c.get("TCC_EA0_RDREQ_sum", 0.0)
 if rd:
-    # every read request of this kernel is a 128-byte line (TCC_EA0_RDREQ_128B == RDREQ, profiles/r01_calib); WRITE_SIZE is in KB
+    # every read request of this kernel is a 128-byte line (TCC_EA0_RDREQ_128B == RDREQ, profiles/r01/calib); WRITE_SIZE is in KB
     res["fabric_bytes_per_launch"] = rd * 128.0 + c.get("WRITE_SIZE", 0.0) * 1024.0
 if c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0) > 0:
     res["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
