@@ -94,6 +94,16 @@ def make_workload(name, cache=None):
     return sc0, pos, nrm, valid, shift, res, spp
 
 
+def irt_plan_parts(spp):
+    """parts per texel of the 64-texels-per-wave IrT form (kernels.hip irt_plan: a function of N alone; up to 32 parts of at least 8 passes)"""
+    if spp & (spp - 1):
+        return 1
+    lp = 0
+    while lp < 5 and (spp >> (lp + 1)) >= 8:
+        lp += 1
+    return 1 << lp
+
+
 def algorithmic_bytes_per_ray(counters, spp):
     """32*n + 36*t + p_hit*(24 + 48) + (24 + 8 + 1 + 12)/N   (canonical BVH2 of the oracle)"""
     nodes, tris, rays, hits = (float(x) for x in counters)
@@ -238,12 +248,12 @@ def mat_setup(sc, sc0, irr_tex, res, dev, cube=128, S=16, tres=4096, n_views=16,
     return model, views, data, loss_fn, opt
 
 
-def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5):
+def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5, cube=128, tres=4096):
     """material-estimation step latency (BASELINE.json: "material-step ms at 4k tex"): stage-2 (joint) optimiser step =
     4 texture fetches (4k albedo x3 / 4k roughness x1 / irradiance, mip stacks rebuilt) + GGX-importance specular trace
     (P = 6*128^2 pixels x 16 spp) + fused RenderLoss/SegLoss + backward + (gradient all-reduce) + fused Adam over 67.1 M texels."""
     from texir_code_amd import dist_util
-    cube, S, tres = 128, 16, 4096
+    S = 16                 # (cube = 128, tres = 4096: BASELINE.json's "material-step ms at 4k tex"; --mat-res / --mat-cube shrink it for the plumbing tests)
     model, views, data, loss_fn, opt = mat_setup(sc, sc0, irr_tex, res, dev, cube, S, tres)
     if world > 1:
         import torch.distributed as dist
@@ -431,6 +441,10 @@ def main():
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-mat", action="store_true")
+    ap.add_argument("--mat", action="store_true", help="run the material-step leg on workloads other than c4 too (plumbing tests)")
+    ap.add_argument("--mat-steps", type=int, default=50)
+    ap.add_argument("--mat-res", type=int, default=4096, help="albedo / roughness texture size of the material leg (4096 = BASELINE.json's)")
+    ap.add_argument("--mat-cube", type=int, default=128)
     ap.add_argument("--extra", default=None, help="comma-separated extra workloads timed after the headline (IrT only), reported under extra_workloads; "
                     "default: c4_scan (the hostile sibling) next to the full c4 headline line, nothing otherwise or with --no-cpu / --no-mat; `none` switches it off")
     args = ap.parse_args()
@@ -499,12 +513,13 @@ def main():
         if os.environ.get("TEXIR_TEXEL_ORDER", "morton") == "morton":
             ids_all = dist_util.morton_order(ids_all, res)
         ids = dist_util.shard_block_cyclic(ids_all, rank, world, BLOCK).to(dev)
+        plan = dist_util.shard_plan(ids_all, world, BLOCK, dev) if world > 1 else None
         irr = torch.zeros((res * res, 3), device=dev)
         for _ in range(warmup):
             irr.zero_()
             sc.irt_generate(d_pos, d_nrm, d_shift, spp, "uniform", texel_ids=ids, out=irr)
             if world > 1:
-                dist.all_reduce(irr)
+                dist_util.assemble_shards(irr, ids_all, BLOCK, plan=plan)     # one all_gather of every rank's own texel values (12 B per valid texel)
         barrier()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         t0 = time.perf_counter()
@@ -514,7 +529,7 @@ def main():
             sc.irt_generate(d_pos, d_nrm, d_shift, spp, "uniform", texel_ids=ids, out=irr)
             ev[k][1].record()
             if world > 1:
-                dist.all_reduce(irr)
+                dist_util.assemble_shards(irr, ids_all, BLOCK, plan=plan)     # one all_gather of every rank's own texel values (12 B per valid texel)
         barrier()
         dt = time.perf_counter() - t0
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -537,8 +552,14 @@ def main():
                 sc.irt_generate(d_pos, d_nrm, d_shift, spp, "uniform", texel_ids=sample, out=alone)
                 ok = bool(torch.equal(alone[sample.long()], irr[sample.long()]))
                 del alone
-            ranks = {"kernel_ms_min": round(min(km), 3), "kernel_ms_max": round(max(km), 3), "kernel_ms": [round(x, 3) for x in km],
-                     "assembled_ok": ok, "assembled_check": "rank 0 alone re-traced every 100th %d-texel block of the list; bit-equal to the all-reduced texture" % BLOCK}
+            info = sc.info()
+            scene_bytes = info["node_bytes"] + info["tri_bytes"] + info["uv_bytes"] + info["tex_bytes"] + sc0["hdr"].nbytes
+            plan_i = irt_plan_parts(spp)
+            ranks = {"footprint_per_rank": {"replicated_scene_bytes": int(scene_bytes), "texel_gbuffers_bytes": int(pos.nbytes + nrm.nbytes + shift.nbytes),
+                                            "irt_scratch_bytes": int(12 * plan_i * ids.numel()), "irradiance_bytes": int(irr.numel() * 4),
+                                            "note": "everything read-only is replicated; the IrT partial-sum scratch (12 B x %d parts per LISTED texel) scales with the rank's own shard" % plan_i},
+                     "kernel_ms_min": round(min(km), 3), "kernel_ms_max": round(max(km), 3), "kernel_ms": [round(x, 3) for x in km],
+                     "assembled_ok": ok, "assembled_check": "rank 0 alone re-traced every 100th %d-texel block of the list; bit-equal to the assembled (all-gathered) texture" % BLOCK}
         T, _, tex_res, _, style = WORKLOADS[name]
         n_valid = int(ids_all.numel())
         return {"sc": sc, "sc0": sc0, "pos": pos, "nrm": nrm, "valid": valid, "shift": shift, "res": res, "spp": spp, "irr": irr, "ids": ids,
@@ -549,10 +570,11 @@ def main():
 
     r = run_irt(args.workload, args.steps, args.warmup)
     mat = None
-    if not args.no_mat and args.workload == "c4":
+    if not args.no_mat and (args.workload == "c4" or args.mat):
         import contextlib
         with contextlib.redirect_stdout(sys.stderr):          # (constructors print like the reference's; stdout carries the JSON line only)
-            mat = mat_leg(r["sc"], r["sc0"], r["irr"], r["res"], dev, rank, world)
+            mat = mat_leg(r["sc"], r["sc0"], r["irr"], r["res"], dev, rank, world, steps=args.mat_steps, warmup=min(5, args.mat_steps),
+                          cube=args.mat_cube, tres=args.mat_res)
 
     out = None
     if rank == 0:
@@ -561,7 +583,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(r["dt"] / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": r["desc"],
-                       "parallelism": "texel-sharded x%d (block-cyclic %d) + RCCL all_reduce" % (world, BLOCK) if world > 1 else "single GPU",
+                       "parallelism": "texel-sharded x%d (block-cyclic %d) + RCCL all_gather of the compacted texel values" % (world, BLOCK) if world > 1 else "single GPU",
                        "bvh_build_s": round(r["build_s"], 2), "scene": r["sc"].info()},
         }
         if mat is not None:

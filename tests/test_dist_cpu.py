@@ -28,6 +28,14 @@ def _worker(rank, world, port, n):
     ref = torch.zeros(3 * n, 3)
     ref[ids.long()] = ids.float().unsqueeze(-1) * torch.tensor([1.0, 2.0, 3.0])
     assert torch.equal(full, ref)
+    # the compacted form the product uses: every rank sends only its own texels' values (all_gather), ragged last block included
+    full2 = torch.zeros(3 * n, 3)
+    full2[mine.long()] = mine.float().unsqueeze(-1) * torch.tensor([1.0, 2.0, 3.0])
+    full2[1] = 7.0                                                  # a seam texel nobody lists stays untouched
+    dist_util.assemble_shards(full2, ids, block=64)
+    ref2 = ref.clone()
+    ref2[1] = 7.0
+    assert torch.equal(full2, ref2)
     # shares are disjoint and complete
     cnt = torch.zeros(3 * n)
     cnt[mine.long()] = 1

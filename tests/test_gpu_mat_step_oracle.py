@@ -6,6 +6,8 @@ models/mat_nvdiffrast.py:107-190,201-279 + models/loss.py:81-115,214-295 + train
 to the reference's own outputs and autograd gradients on the CPU (tests/test_mat_step_oracle.py).
 
 Tolerances: north_star's 1e-3 relative L2 on gradients asserted, with the tighter observed bound next to it."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -16,6 +18,19 @@ pytestmark = pytest.mark.gpu
 
 LR = 3e-2
 _OGB = {}          # the oracle's rasterised G-buffers (c, view) -> dict: independent of the texture sizes, ~15 s of numpy each
+
+
+@pytest.fixture(autouse=True)
+def _bounded_host_threads():
+    """the oracle side is hundreds of small torch-CPU ops and small OpenMP regions of the C oracle: on a 256-thread host two full-width thread pools
+    (torch's OpenMP runtime and the oracle library's) spin against each other and the test takes minutes instead of seconds"""
+    from oracle import oracle as O
+    before = torch.get_num_threads()
+    n = max(1, min(16, os.cpu_count() or 1))
+    torch.set_num_threads(n)
+    O.set_num_threads(n)
+    yield
+    torch.set_num_threads(before)
 
 
 def _world(golden, c, ra, rr, seed=11):

@@ -64,7 +64,8 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     """the N > 1 bench path end to end (block-cyclic shards, all_reduce assembly, max-over-ranks timing, one JSON line from rank 0) with
     two ranks sharing this GPU over gloo; the assembled texture's throughput line must carry n_gpus: 2"""
     r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
-              "bench.py", "--gpus", "2", "--workload", "tiny", "--steps", "1", "--warmup", "1", "--no-cpu", "--no-mat"],
+              "bench.py", "--gpus", "2", "--workload", "tiny", "--steps", "1", "--warmup", "1", "--no-cpu",
+              "--mat", "--mat-steps", "4", "--mat-res", "512", "--mat-cube", "32"],
              env={"TEXIR_DIST_BACKEND": "gloo"})
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -72,7 +73,12 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     # rank 0 re-traced a sample of both ranks' texel blocks alone: the all-reduced texture must hold exactly those values
-    assert d["assembled_ok"] is True and len(d["ranks"]["kernel_ms"]) == 2 and d["ranks"]["kernel_ms_max"] >= d["ranks"]["kernel_ms_min"] > 0
+    assert d["ranks"]["assembled_ok"] is True and len(d["ranks"]["kernel_ms"]) == 2 and d["ranks"]["kernel_ms_max"] >= d["ranks"]["kernel_ms_min"] > 0
+    fp = d["ranks"]["footprint_per_rank"]
+    assert fp["replicated_scene_bytes"] > 0 and fp["irt_scratch_bytes"] >= 0 and fp["texel_gbuffers_bytes"] > 0
+    # the material leg of the N > 1 line: one view per rank per optimiser step, texture gradients summed over the ranks
+    m = d["material_step"]
+    assert m["views_per_step"] == 2 and m["ms"] > 0 and m["ms_per_view"] == round(m["ms"] / 2, 3)
 
 
 @pytest.fixture(scope="module")

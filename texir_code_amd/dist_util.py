@@ -1,5 +1,6 @@
 """Multi-GPU sharding of the hot path: one process per GPU, texels / pixels partitioned across ranks,
-BVH + radiance texture replicated, one RCCL all_reduce(SUM) to assemble (IrT) or to sum gradients (Mat)."""
+BVH + radiance texture replicated; IrT: one RCCL all_gather of the ranks' compacted texel values assembles the texture; Mat: all_reduce(SUM) of
+the texture gradients."""
 import torch
 
 
@@ -24,6 +25,43 @@ def assemble_sum(t):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t)
     return t
+
+
+def shard_plan(ids_all, world, block=4096, device=None):
+    """the per-rank row lists of assemble_shards, computed once (a bench / trainer that assembles every step keeps it)"""
+    if device is not None:
+        ids_all = ids_all.to(device)
+    return [shard_block_cyclic(ids_all, r, world, block).long() for r in range(world)]
+
+
+def assemble_shards(tex, ids_all, block=4096, plan=None):
+    """Assemble the irradiance texture `tex` [Nt, C] whose rows ids_all[shard r] were computed by rank r (shard_block_cyclic(ids_all, r, world, block)):
+    every rank contributes only ITS texels' values, compacted ([n_r, C]: 12 bytes per valid texel instead of a dense all_reduce over the whole
+    texture, seams and other ranks' zeros included), one all_gather moves them, and each rank scatters the others' rows into its copy.  Supports
+    are disjoint, so this is bit-identical to the SUM all-reduce it replaces.  `ids_all` must be the same list on every rank (`plan` =
+    shard_plan(ids_all, world, block, tex.device) skips recomputing the row lists).  No-op for one rank."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return tex
+    rank, world = dist.get_rank(), dist.get_world_size()
+    shards = plan if plan is not None else shard_plan(ids_all, world, block, tex.device)
+    mx = max(int(s_.numel()) for s_ in shards)
+    if mx == 0:
+        return tex
+    C = tex.shape[1]
+    mine = torch.zeros((mx, C), device=tex.device, dtype=tex.dtype)
+    mine[: shards[rank].numel()] = tex[shards[rank]]
+    out = torch.empty((world * mx, C), device=tex.device, dtype=tex.dtype)
+    try:
+        dist.all_gather_into_tensor(out, mine)
+    except (RuntimeError, NotImplementedError):          # a backend without the flat form
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        out = torch.cat(parts, 0)
+    for r in range(world):
+        if r != rank and shards[r].numel():
+            tex[shards[r]] = out[r * mx: r * mx + shards[r].numel()]
+    return tex
 
 
 def reduce_texture_grads(params):

@@ -146,10 +146,11 @@ class TracerO3d(nn.Module):
         seam = torch.from_numpy((self.index_texture.astype(np.int64).sum(-1) == 0).reshape(-1)).to(self.device)
         ids = dist_util.morton_order(torch.nonzero(~seam)[:, 0].to(torch.int32), W)
         rank, world, _ = dist_util.world_info()
-        ids = dist_util.shard_block_cyclic(ids, rank, world)
+        ids_all = ids
+        ids = dist_util.shard_block_cyclic(ids_all, rank, world)
         irr = torch.zeros((nt, 3), device=self.device)
         self.scene.irt_generate(pos, nrm, shift, int(self.sample_l[0]), self.sample_type[0], texel_ids=ids, out=irr)
-        dist_util.assemble_sum(irr)
+        dist_util.assemble_shards(irr, ids_all)             # (one all_gather of the ranks' own texel values; no-op for one rank)
         self.ir_texture = irr.reshape(H, W, 3)
         return self.ir_texture
 
