@@ -284,9 +284,17 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_stream_kernel(SceneDe
         const float px = pos[3 * t], py = pos[3 * t + 1], pz = pos[3 * t + 2];
         const float nx = nrm[3 * t], ny = nrm[3 * t + 1], nz = nrm[3 * t + 2];
         const float sh0 = shift[2 * t], sh1 = shift[2 * t + 1];
-        const Frame f = make_frame(nx, ny, nz);
         float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
         if (live) {
+            // What a refill needs of the texel (frame, raw normal, shifts: 14 floats) is PARKED in private memory for the whole chunk and read back only
+            // inside `next`: held in registers across the traversal loop it pushes the loop's own temporaries into scratch (first build of this kernel:
+            // spills in every node step, 4x slower than the lock-step kernel).  volatile = the compiler keeps the array in memory.
+            volatile float keep[14];
+            {
+                const Frame f = make_frame(nx, ny, nz);
+                for (int a = 0; a < 3; a++) { keep[a] = f.n[a]; keep[3 + a] = f.U[a]; keep[6 + a] = f.V[a]; }
+                keep[9] = nx; keep[10] = ny; keep[11] = nz; keep[12] = sh0; keep[13] = sh1;
+            }
             int Lc = part * part_cells;
             const int Lend = Lc + part_cells;
             float ndl = 0.f;
@@ -300,12 +308,15 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_stream_kernel(SceneDe
                 if (Lc >= Lend) return false;
                 const int J = TEXIR_PART_WEDGE ? (((Lc & ((1 << bth) - 1)) << bphi) | (Lc >> bth)) : Lc;
                 Lc++;
-                const uint32_t i = sample_index_m(cell_to_pass_m((uint32_t)J, sh0, sh1, log2N, 0), 0u, log2N, 0);
-                const float s0 = shift_wrap_clamp(ham0(i, (uint32_t)N), sh0);
-                const float s1 = shift_wrap_clamp(ham1(i), sh1);
+                Frame f;
+                for (int a = 0; a < 3; a++) { f.n[a] = keep[a]; f.U[a] = keep[3 + a]; f.V[a] = keep[6 + a]; }
+                const float rnx = keep[9], rny = keep[10], rnz = keep[11], rs0 = keep[12], rs1 = keep[13];
+                const uint32_t i = sample_index_m(cell_to_pass_m((uint32_t)J, rs0, rs1, log2N, 0), 0u, log2N, 0);
+                const float s0 = shift_wrap_clamp(ham0(i, (uint32_t)N), rs0);
+                const float s1 = shift_wrap_clamp(ham1(i), rs1);
                 float d[3];
                 sample_dir<TEXIR_IRT_FAST_SINCOS != 0>(mode, s0, s1, 0.f, f, d);
-                ndl = cosw ? 1.f : fminf(fmaxf(nx * d[0] + ny * d[1] + nz * d[2], 0.f), 1.f);       // :170, RAW normal
+                ndl = cosw ? 1.f : fminf(fmaxf(rnx * d[0] + rny * d[1] + rnz * d[2], 0.f), 1.f);       // :170, RAW normal
                 dx = d[0]; dy = d[1]; dz = d[2];
                 if (STATS) c_rays++;
                 return true;

@@ -15,7 +15,7 @@ run() {  # label, lib, layout, refill, bench args
   echo "$1 $v" | tee -a $out/ab.txt
 }
 A=$R/texir_code_amd/libtexir_hip.so; B=$R/build_ab/libtexir_kz0.so
-for rep in 1 2; do
+for rep in 1; do
 for cfg in "c4|--workload c4 --steps 3 --warmup 1" "c2|--workload c2 --steps 5 --warmup 1" "c4_scan|--workload c4_scan --steps 2 --warmup 1"; do
   label=${cfg%%|*}; args=${cfg#*|}
   run "$label kz0_layout0" $B 0 0 "$args"
