@@ -597,6 +597,17 @@ def main():
             cpu, counters = cpu_leg(r["sc0"], r["pos"], r["nrm"], r["valid"], r["shift"], r["spp"], timed=world == 1)
             alg = algorithmic_bytes_per_ray(counters, r["spp"])
         out["roofline"] = roofline(args.workload, r["kernel"], r["kern_ms"], rays_this_rank, world, alg)
+        # what one launch MUST move through HBM at least once: the scene it reads (tree in both forms, triangles, corner uvs, the hit shader's texture copy),
+        # the texel G-buffers + id list, and the texture it writes -- everything beyond this in `traffic` is re-reading (cache misses), everything in
+        # `algorithmic` beyond `traffic` was served by L1 / L2 / LDS / the scalar cache
+        info = r["sc"].info()
+        comp = (info["node_bytes"] + info["tri_bytes"] + info["uv_bytes"] + info["tex_bytes"]
+                + int(r["ids"].numel()) * (12 + 12 + 8 + 4) + int(r["ids"].numel()) * 12)
+        out["roofline"]["compulsory_bytes"] = int(comp)
+        out["roofline"]["reading"] = ("top-level achieved / peak / frac / traffic = the FABRIC side of L2 (requests to the Infinity Cache and HBM together: Infinity-Cache hits are "
+                                      "included, so HBM proper carries less) -- measured, and NOT what bounds this kernel: see `binding` and `waves` (a dependent fetch -> box test -> sort "
+                                      "-> push chain at 8 waves per SIMD); compulsory_bytes / traffic = %.4f of the fabric traffic is first-touch, the rest is re-read"
+                                      % (comp / out["roofline"]["traffic"] if out["roofline"].get("traffic") else float("nan")))
         if cpu is not None:
             out["cpu_baseline"] = cpu
     # further workloads (IrT only), never the headline

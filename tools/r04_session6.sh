@@ -11,6 +11,7 @@ run() {  # label, lib, max_leaf, bench args
   echo "$1 $v" | tee -a $out/ab.txt
 }
 A=$R/texir_code_amd/libtexir_hip.so; B=$R/build_ab/libtexir_fastsincos.so
+timeout 300 python tools/graph_branch_probe.py 2>&1 | tail -6 | tee $out/graph_branch.txt
 for cfg in "c4|--workload c4 --steps 3 --warmup 1" "c2|--workload c2 --steps 5 --warmup 1" "c4_scan|--workload c4_scan --steps 2 --warmup 1"; do
   label=${cfg%%|*}; args=${cfg#*|}
   for ml in 2 3 4; do run "$label leaf$ml" $A $ml "$args"; done
