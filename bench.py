@@ -56,7 +56,7 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0
 SIMDS, CLOCK_HZ = 1024, 2.4e9                  # 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles
 BLOCK = 4096  # texels per block of the block-cyclic rank partition
-KERNEL_SOURCES = ["kernels.hip", "device_common.h", "kernels.h", "bvh_build.cpp", "bvh_build.h", "capi.hip", "Makefile"]
+KERNEL_SOURCES = ["kernels.hip", "device_common.h", "kernels.h", "bvh_build.cpp", "bvh_build.h", "capi.hip", "env.h", "env.cpp", "Makefile"]
 
 
 def kernel_src_sha():

@@ -246,8 +246,11 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
 // irt_group_kernel with compaction by refill (device_common.h trace_core<STREAM>): same chunks, same hand-out, same per-lane sample order and
 // partial sums; a lane whose ray has ended takes its texel's next direction cell as soon as `refill_at` lanes of the wave are idle instead of
 // waiting for the slowest ray of the pass.  Launched when TEXIR_IRT_REFILL = 1..63 (A/B switch); power-of-two N only.
+#ifndef TEXIR_STREAM_WAVES
+#define TEXIR_STREAM_WAVES TEXIR_GROUP_WAVES          // waves per SIMD the stream kernel is compiled for (A/B: fewer waves = more registers, fewer spills)
+#endif
 template <bool STATS, int WIDTH>
-__global__ __launch_bounds__(kBlock, kGroupWaves) void irt_stream_kernel(SceneDev sc, const float* __restrict__ pos, const float* __restrict__ nrm,
+__global__ __launch_bounds__(kBlock, TEXIR_STREAM_WAVES) void irt_stream_kernel(SceneDev sc, const float* __restrict__ pos, const float* __restrict__ nrm,
                                                             const float* __restrict__ shift, const int32_t* __restrict__ ids, int64_t n_ids,
                                                             int N, int log2N, int mode, float* __restrict__ irr,
                                                             unsigned long long* __restrict__ stats, unsigned long long* __restrict__ work,

@@ -9,7 +9,7 @@ run() { name=$1; shift
   f=$(find /tmp/pmc_$name -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && python - "$f" "$R/gpurun_out/$out/pmc_$name.csv" <<'PY'
 import csv,sys
-rows=[r for r in csv.DictReader(open(sys.argv[1])) if 'irt_group_kernel<false' in r['Kernel_Name'] or 'irt_kernel<false' in r['Kernel_Name']]
+rows=[r for r in csv.DictReader(open(sys.argv[1])) if 'irt_group_kernel<false' in r['Kernel_Name'] or 'irt_kernel<false' in r['Kernel_Name'] or 'irt_stream_kernel<false' in r['Kernel_Name']]
 w=csv.DictWriter(open(sys.argv[2],'w'),fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
 import collections
 d=collections.defaultdict(float)

@@ -15,7 +15,7 @@ run() { wl=$1; name=$2; shift 2
   f=$(find /tmp/pmc_$name -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && python - "$f" "$out/$wl/pmc_$name.csv" <<'PY'
 import csv,sys,collections
-rows=[r for r in csv.DictReader(open(sys.argv[1])) if 'irt_group_kernel<false' in r['Kernel_Name'] or 'irt_kernel<false' in r['Kernel_Name']]
+rows=[r for r in csv.DictReader(open(sys.argv[1])) if 'irt_group_kernel<false' in r['Kernel_Name'] or 'irt_kernel<false' in r['Kernel_Name'] or 'irt_stream_kernel<false' in r['Kernel_Name']]
 w=csv.DictWriter(open(sys.argv[2],'w'),fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
 d=collections.defaultdict(float)
 for r in rows: d[r['Counter_Name']]+=float(r['Counter_Value'])
