@@ -81,6 +81,35 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert m["views_per_step"] == 2 and m["ms"] > 0 and m["ms_per_view"] == round(m["ms"] / 2, 3)
 
 
+def test_pixel_sharded_material_step_is_the_single_gpu_step_bit_for_bit(tmp_path):
+    """VERDICT r3 #7a / weak #8.  train.mat_shard = pixel on several ranks (sharded_step.ShardedMatStep: the specular trace and its backward split by
+    pixels, the texture side replicated, two small all_gathers per step, three hipGraphs per step) against the single-GPU recorded step
+    (graph_step.GraphedMatStep): stages 1 and 2, five steps each over two views at 1024^2 textures -- the textures must be IDENTICAL BITS, for one
+    rank, for two ranks (gloo, sharing this GPU), through hipGraphs and eagerly; and the graph path must really have been active"""
+    w = os.path.join(ROOT, "tests", "sharded_worker.py")
+    env = {"TEXIR_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    runs = {"single": [sys.executable, w, "single", str(tmp_path / "single.npz")],
+            "sharded1": [sys.executable, w, "sharded", str(tmp_path / "sharded1.npz")],
+            "sharded2": [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+                         w, "sharded", str(tmp_path / "sharded2.npz")],
+            "sharded2_eager": [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29549",
+                               w, "sharded", str(tmp_path / "sharded2_eager.npz"), "eager"]}
+    out = {}
+    for name, cmd in runs.items():
+        r = _run(cmd, timeout=900, env=env)
+        assert r.returncode == 0, (name, r.stderr[-3000:])
+        out[name] = np.load(str(tmp_path / ("%s.npz" % name)))
+    ref = out["single"]
+    assert float(np.abs(ref["a2"] - ref["a1"]).max()) > 1e-3 and float(np.abs(ref["r1"] - 0.35).max()) > 0          # the steps moved the textures
+    for name in ("sharded1", "sharded2", "sharded2_eager"):
+        o = out[name]
+        assert int(o["world"][0]) == (1 if name == "sharded1" else 2)
+        assert int(o["graphs"][0]) == 1, name                      # (graphs recorded in the graph runs, none in the eager run: the worker checks both)
+        for k in ("a1", "r1", "a2", "r2"):
+            assert np.array_equal(o[k], ref[k]), (name, k, float(np.abs(o[k] - ref[k]).max()))
+        assert np.array_equal(o["losses"], ref["losses"]), name
+
+
 @pytest.fixture(scope="module")
 def c4_workload():
     """BASELINE.json configs[3] at full size: 1 M triangles, 4096^2 texels, 4096^2 radiance texture"""

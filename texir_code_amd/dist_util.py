@@ -132,31 +132,3 @@ def pixel_range(n_pixels, rank, world):
     base, rem = divmod(n_pixels, world)
     p0 = rank * base + min(rank, rem)
     return p0, p0 + base + (1 if rank < rem else 0)
-
-
-class _GatherPixels(torch.autograd.Function):
-    """all_gather of per-rank pixel slices [Ps,k] into the full view [P,k].  Every rank then evaluates the (cheap) loss on the
-    full view, so the backward is simply this rank's slice of the full-view gradient -- no reduction needed here; the texture
-    gradients of the slices are summed by the all_reduce that precedes the optimiser step."""
-
-    @staticmethod
-    def forward(ctx, x, n_pixels):
-        import torch.distributed as dist
-        rank, world = dist.get_rank(), dist.get_world_size()
-        sizes = [pixel_range(n_pixels, r, world) for r in range(world)]
-        mx = max(b - a for a, b in sizes)
-        pad = torch.zeros((mx,) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
-        pad[: x.shape[0]] = x
-        parts = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(parts, pad)
-        ctx.range = sizes[rank]
-        return torch.cat([parts[r][: b - a] for r, (a, b) in enumerate(sizes)], 0)
-
-    @staticmethod
-    def backward(ctx, g):
-        a, b = ctx.range
-        return g[a:b].contiguous(), None
-
-
-def gather_pixels(x, n_pixels):
-    return _GatherPixels.apply(x.contiguous(), n_pixels)

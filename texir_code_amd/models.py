@@ -232,33 +232,18 @@ class MaterialModel(nn.Module):
                 gb["_irr"], gb["_irr_version"] = irr.detach(), self.irrt._version
         return albedo, roughness_womipmap, roughness, irr
 
-    def _gbuffer_slice(self, mvp, view_id, pixel_range):
-        """this rank's pixels of the view's G-buffer as [1,1,Ps,k] tensors (multi-GPU parity mode: pixels of ONE view are split
-        across ranks)"""
-        key = (str(view_id), pixel_range)
-        gb = self._gb_cache.get(key)
-        if gb is None:
-            full = self._gbuffer(mvp, view_id)
-            p0, p1 = pixel_range
-            gb = {}
-            for k, v in full.items():
-                if k.startswith("_"):
-                    continue                     # per-view derived caches are rebuilt for the slice
-                flat = v.reshape(v.shape[0] * v.shape[1] * v.shape[2], -1)[p0:p1]
-                gb[k] = flat.reshape(1, 1, p1 - p0, -1).contiguous() if k != "tri_id" else flat.reshape(1, 1, p1 - p0).contiguous()
-            self._gb_cache[key] = gb
+    @staticmethod
+    def _view_consts(gb):
+        """per-view constants kept with the cached G-buffer: the offset ray origins (mat_nvdiffrast.py:179,182) and the position the render reports"""
+        if "_points" not in gb:
+            gb["_points"] = gb["position"] + 1e-2 * gb["normal"]
+            gb["_position_out"] = (gb["_points"] + 2e-2 * gb["normal"]).detach()
         return gb
 
-    def forward(self, mvp, id, cam_position, stage=1, pixel_range=None):
-        gb = self._gbuffer(mvp, id) if pixel_range is None else self._gbuffer_slice(mvp, id, pixel_range)
-        self._pixel_range = pixel_range
-        if pixel_range is not None:
-            self._view_pixels = 6 * self.cube_res * self.cube_res
+    def forward(self, mvp, id, cam_position, stage=1):
+        gb = self._gbuffer(mvp, id)
         pos, nrm, mask = gb["position"], gb["normal"], gb["mask"]
-        if "_points" not in gb:
-            # per-view constants: the offset ray origins (mat_nvdiffrast.py:179,182) and the position the render reports
-            gb["_points"] = pos + 1e-2 * nrm
-            gb["_position_out"] = (gb["_points"] + 2e-2 * nrm).detach()
+        self._view_consts(gb)
         # `lean_outputs` (set by the trainers' optimisation step): res["roughness_womipmap"] is None in the stages whose loss does not read it
         albedo, roughness_womipmap, roughness, irr = self._fetch_materials(gb, womipmap=(stage == 1 or not getattr(self, "lean_outputs", False)))
         cam_position = cam_position.to(self.device)
@@ -290,14 +275,8 @@ class MaterialModel(nn.Module):
         if self.sample_type[1] != "importance":
             raise NotImplementedError("specular sample_type %r: the reference path uses 'importance'" % (self.sample_type[1],))
         static = getattr(self, "_static_shift", None)
-        pr = getattr(self, "_pixel_range", None)
         if static is not None:
             shift = static                      # hipGraph replay: the caller refreshes this buffer from the CPU generator each step
-        elif pr is not None:
-            # pixel-sharded view: every rank draws the WHOLE view's shifts (same seed, same call order => same stream as the
-            # single-GPU run) and keeps its slice
-            full = torch.rand(self._view_pixels, 1, 2).reshape(self._view_pixels, 2)
-            shift = full[pr[0]:pr[1]].to(self.device)
         else:
             shift = torch.rand(P, 1, 2).reshape(P, 2).to(self.device)           # sample_util.py:102 (CPU generator)
         rgb = spec_render(self.scene, normal.reshape(P, 3), albedo.reshape(P, 3), roughness.reshape(P), points.reshape(P, 3),

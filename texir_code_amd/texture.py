@@ -192,7 +192,10 @@ class _TexFetch(torch.autograd.Function):
         # parameter that is never cleared; the view's bit mask (one bit per texel) tells the fused optimiser where to read it.  No
         # 4*H*W*C-byte fill and no dense read per step, nothing allocated per step or per captured graph; autograd gets None.
         import torch.distributed as dist
-        sparse_l0 = bool(defer and ctx.taps is not None and owner.grad is None and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1))
+        # (several ranks: the gradient parts are summed across ranks as dense tensors, dist_util.reduce_texture_grads -- unless the texture side of the step
+        # is REPLICATED on every rank, sharded_step.ShardedMatStep: then nothing is reduced and the single-process form applies)
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and not getattr(owner, "_texir_replicated_grads", False)
+        sparse_l0 = bool(defer and ctx.taps is not None and owner.grad is None and not multi)
         if sparse_l0:
             d_tex = None
             if ctx.taps[5]:

@@ -80,29 +80,59 @@ class MatTrainRunner(RunnerBase):
         self.cur_iter = 0
         self.log = []
 
-    def _graph_step(self, gt_item, stage):
-        """train.hipgraph = true: forward + loss + backward of a (view, stage) pair replayed as one hipGraph (graph_step.py)"""
+    def _view_inputs(self, gt_item, vid0):
+        """device-resident, long-lived inputs of a view (what a recorded step reads)"""
+        self._gs_inputs = getattr(self, "_gs_inputs", {})
+        if vid0 not in self._gs_inputs:
+            gt = gt_item["color"].float().cuda()
+            h, w, c = gt.shape[-3:]
+            mvp = gt_item["cam_to_world"].float()
+            cam = gt_item["cam_position"].float().cuda()
+            self._gs_inputs[vid0] = (mvp[0] if mvp.dim() == 4 else mvp, (cam[0] if cam.dim() == 2 else cam).contiguous(),
+                                     gt.reshape(-1, h, w, c).contiguous(), gt_item["mask"].float().cuda().reshape(-1, h, w, 1).contiguous())
+        return self._gs_inputs[vid0]
+
+    def _sharded_step(self, gt_item, stage):
+        """several ranks, train.mat_shard = pixel, stages 1 / 2: the view's pixels are split across the ranks for the specular trace and its backward,
+        the texture side is replicated (sharded_step.ShardedMatStep): the single-GPU trajectory bit for bit, two small all_gathers per step"""
+        from ..sharded_step import ShardedMatStep
+        vid = gt_item["id"]
+        vid0 = vid[0] if isinstance(vid, (list, tuple)) else vid
+        if getattr(self, "_ss", None) is None or self._ss.opt is not self.mat_optimizer:
+            self.mat_loss.lazy_item = True
+            self.mat_loss.unit_upstream = True
+            self._ss = ShardedMatStep(self.model, self.mat_loss, self.mat_optimizer, [self.model.materials_a, self.model.materials_r],
+                                      use_graph=getattr(self, "use_graph", False))
+        if (vid0, stage) not in self._ss.views:
+            mvp, cam, gt, gmask = self._view_inputs(gt_item, vid0)
+            self._ss.capture(vid0, mvp, cam, gt, gmask, self.seg_mask[str(vid0)], self.floor_max_mask[str(vid0)],
+                             self.room_seg_mask[str(vid0)] if stage == 2 else None, stage)
+        self._ss.step(vid0, stage)
+        out = self._ss.views[(vid0, stage)]["out"]
+        return out[0], out[1]
+
+    def _graph_step(self, gt_item, stage, replicated=False):
+        """train.hipgraph = true: forward + loss + backward of a (view, stage) pair replayed as one hipGraph (graph_step.py).
+        replicated: several ranks run the IDENTICAL full step (stage 0 of the pixel-sharded mode: no specular term, nothing to split): the optimiser
+        step stays inside the graph and nothing is reduced"""
         from ..graph_step import GraphedMatStep
         vid = gt_item["id"]
         vid0 = vid[0] if isinstance(vid, (list, tuple)) else vid
         if getattr(self, "_gs", None) is None or self._gs.opt is not self.mat_optimizer:
             self.mat_loss.lazy_item = True
             self.mat_loss.unit_upstream = True        # train_step back-propagates the loss itself (loss.backward())
-            self._gs = GraphedMatStep(self.model, self.mat_loss, self.mat_optimizer, [self.model.materials_a, self.model.materials_r])
+            if replicated:
+                for p in (self.model.materials_a, self.model.materials_r):
+                    p._texir_replicated_grads = True
+            self._gs = GraphedMatStep(self.model, self.mat_loss, self.mat_optimizer, [self.model.materials_a, self.model.materials_r],
+                                      step_in_graph=True if replicated else None)
             self._gs_inputs = getattr(self, "_gs_inputs", {})
         if (vid0, stage) not in self._gs.graphs:
             # a captured (view, stage) graph owns no gradient memory (the stacks live in the optimiser's arena, shared by all graphs); the cap
             # on their number (TEXIR_MAX_GRAPHS, default 1024; beyond it further views run the eager step) is a safety valve only
             if len(self._gs.graphs) >= int(os.environ.get("TEXIR_MAX_GRAPHS", "1024")):
                 return None
-            if vid0 not in self._gs_inputs:
-                gt = gt_item["color"].float().cuda()
-                h, w, c = gt.shape[-3:]
-                mvp = gt_item["cam_to_world"].float()
-                cam = gt_item["cam_position"].float().cuda()
-                self._gs_inputs[vid0] = (mvp[0] if mvp.dim() == 4 else mvp, (cam[0] if cam.dim() == 2 else cam).contiguous(),
-                                         gt.reshape(-1, h, w, c).contiguous(), gt_item["mask"].float().cuda().reshape(-1, h, w, 1).contiguous())
-            mvp, cam, gt, gmask = self._gs_inputs[vid0]
+            mvp, cam, gt, gmask = self._view_inputs(gt_item, vid0)
             try:
                 self._gs.capture(vid0, mvp, cam, gt, gmask, self.seg_mask[str(vid0)], self.floor_max_mask[str(vid0)],
                                  self.room_seg_mask[str(vid0)] if stage == 2 else None, stage)
@@ -112,7 +142,7 @@ class MatTrainRunner(RunnerBase):
                 self.model._static_shift = None
                 return None
         world = dist_util.world_info()[1]
-        self._gs.step(vid0, stage, reduce_grads=dist_util.reduce_texture_grads if world > 1 else None)
+        self._gs.step(vid0, stage, reduce_grads=dist_util.reduce_texture_grads if (world > 1 and not replicated) else None)
         out = self._gs.outs[(vid0, stage)]
         return out[0], out[1]
 
@@ -153,8 +183,14 @@ class MatTrainRunner(RunnerBase):
 
     def train_step(self, gt_item, stage):
         """one optimiser step (train_material.py:424-458 / 486-525 / 552-593)"""
-        if getattr(self, "use_graph", False) and not (dist_util.world_info()[1] > 1 and getattr(self, "mat_shard", "pixel") == "pixel"):
-            res = self._graph_step(gt_item, stage)
+        rank, world, _ = dist_util.world_info()
+        pixel = world > 1 and getattr(self, "mat_shard", "pixel") == "pixel"
+        if pixel and stage > 0:
+            # parity mode (SURVEY.md 8e(i)): the pixels of this ONE view are split across the ranks for the specular trace; everything on the texture
+            # side is replicated -- the optimisation trajectory is the single-GPU one bit for bit (sharded_step.py)
+            return self._sharded_step(gt_item, stage)
+        if getattr(self, "use_graph", False):
+            res = self._graph_step(gt_item, stage, replicated=pixel)
             if res is not None:
                 return res
         gt_color = gt_item["color"].float().cuda()
@@ -166,23 +202,15 @@ class MatTrainRunner(RunnerBase):
         vid0 = vid[0] if isinstance(vid, (list, tuple)) else vid
         cam = gt_item["cam_position"].float().cuda()
         fm, seg = self.floor_max_mask[str(vid0)], self.seg_mask[str(vid0)]
-        rank, world, _ = dist_util.world_info()
-        if world > 1 and self.mat_shard == "pixel":
-            # parity mode: the P pixels of this ONE view are split across ranks; the rendered slices are
-            # all-gathered, every rank evaluates the (cheap, non-separable) loss on the full view, back-propagates its own slice,
-            # and the texture gradients are summed -- the optimisation trajectory is the single-GPU one
-            P = gt_color.shape[0] * h * w
-            pr = dist_util.pixel_range(P, rank, world)
-            local = self.model(mvp[0] if mvp.dim() == 4 else mvp, vid0, cam[0] if cam.dim() == 2 else cam, stage, pixel_range=pr)
-            preds = {k: None if local[k] is None else dist_util.gather_pixels(local[k].reshape(pr[1] - pr[0], -1), P).reshape(gt_color.shape[0], h, w, -1)
-                     for k in ("rgb", "albedo", "roughness", "roughness_womipmap", "empty_mask")}
-        else:
-            preds = self.model(mvp[0] if mvp.dim() == 4 else mvp, vid0, cam[0] if cam.dim() == 2 else cam, stage)
+        if pixel:
+            for p in (self.model.materials_a, self.model.materials_r):
+                p._texir_replicated_grads = True             # (stage 0 of the pixel mode: every rank runs the identical Lambertian step)
+        preds = self.model(mvp[0] if mvp.dim() == 4 else mvp, vid0, cam[0] if cam.dim() == 2 else cam, stage)
         out = self.mat_loss(gt_color, preds, gt_mask, fm, seg, stage=stage, room_seg_mask=self.room_seg_mask[str(vid0)] if stage == 2 else None)
         loss = out[0]
         self.mat_optimizer.zero_grad()
         loss.backward()
-        if dist_util.world_info()[1] > 1:
+        if world > 1 and not pixel:
             dist_util.reduce_texture_grads([self.model.materials_a, self.model.materials_r])
         self.mat_optimizer.step()
         return loss, out[1]
