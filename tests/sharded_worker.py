@@ -51,7 +51,7 @@ def main():
         views[key] = (mvp, cam.cuda(), gt, gmask, seg, fm, room)
     loss_fn = RenderLoss("L1", 1, lazy_item=True, unit_upstream=True)
     snaps, losses, graphs_used = {}, [], True
-    for stage in (1, 2):
+    for stage in tuple(int(x) for x in os.environ.get("SW_STAGES", "1,2").split(",")):
         m.materials_a.data = torch.clamp(m.materials_a.data, 0.0)
         m.materials_a.requires_grad = stage == 2
         m.materials_r.requires_grad = True
@@ -66,7 +66,7 @@ def main():
         if mode == "sharded":
             graphs_used = graphs_used and all(("graphs" in st) == (not eager) for st in step.views.values())
         torch.manual_seed(100 + stage)                             # the CPU-generator stream of the steps (identical on every rank)
-        for key in ("v0", "v1", "v0", "v1", "v0"):
+        for key in os.environ.get("SW_ORDER", "v0,v1,v0,v1,v0").split(","):
             P = 6 * c * c
             shift = torch.rand(P, 1, 2).reshape(P, 2)
             loss = step.step(key, stage, shift=shift)

@@ -752,3 +752,40 @@ def test_full_size_c3_material_pixels_vs_oracle(tx):
     d = (gb["position"].reshape(P, 3) - cam.cuda()).cpu().numpy()
     t_ref, _, _ = osc.cast_rays(np.tile(cam.numpy(), (4096, 1)), d[::24][:4096], tracer="bvh")
     assert np.abs(t_ref - 1.0).max() < 1e-3
+
+
+@pytest.mark.parametrize("stage", [0, 1, 2])
+def test_fused_loss_recorded_alone_replays_identically(golden, tx, stage):
+    """the loss's workspace must be cleared by every replay of a recorded graph (round 4: cleared by hipMemsetAsync, the stage-1 graph faulted on its
+    second replay -- the memset node stopped taking effect and the scatter cursors ran past the workspace; the clear is a kernel now)"""
+    from texir_code_amd.loss import RenderLoss
+    g = golden("render_loss.npz")
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    L = RenderLoss(loss_type="L1", w_gradient=1, lazy_item=True)
+    gt, gm, fm, seg, room, empty = t("gt"), t("gt_mask"), t("floor_max_mask"), t("seg_mask"), t("room_seg_mask"), t("empty_mask")
+    src = {k: t(k) for k in ("rgb", "albedo", "roughness", "roughness_womipmap")}
+    hold = {}
+
+    def body():
+        leaves = {k: v.clone().requires_grad_(True) for k, v in src.items()}
+        out = L(gt, dict(leaves, empty_mask=empty), gm, fm, seg, stage, room)
+        got = torch.autograd.grad(out[0], list(leaves.values()), torch.ones((), device="cuda"), allow_unused=True)
+        hold["loss"], hold["grads"] = out[0].detach(), [x for x in got if x is not None]
+
+    body()
+    torch.cuda.synchronize()
+    want = (float(hold["loss"]), [x.clone() for x in hold["grads"]])
+    assert abs(want[0] - float(g["L1_s%d_loss" % stage])) < 1e-5 * max(1.0, abs(float(g["L1_s%d_loss" % stage])))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(gr, stream=side):
+            body()
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(4):
+        gr.replay()
+        torch.cuda.synchronize()
+        assert float(hold["loss"]) == want[0]
+        for a, b in zip(hold["grads"], want[1]):
+            assert torch.equal(a, b)

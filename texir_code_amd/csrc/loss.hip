@@ -289,6 +289,11 @@ __global__ void loss_final_kernel(LossArgs a, LossWs ws, float* out /* [2]: tota
     loss_final(a, ws, out);
 }
 
+__global__ __launch_bounds__(kLB) void loss_clear_kernel(uint32_t* __restrict__ w, int n)
+{
+    for (int i = threadIdx.x; i < n; i += kLB) w[i] = 0u;
+}
+
 size_t loss_workspace_bytes(int64_t P, int C, int R)
 {
     size_t rc = (size_t)(R > 0 ? R : 1) * C;
@@ -315,7 +320,10 @@ hipError_t launch_loss(int stage, int l2, const float* gt, const float* rgb, con
     size_t head = (size_t)(w - (char*)workspace);
     head = (head + 255) & ~(size_t)255;
     ws.hval = (float*)((char*)workspace + head);
-    hipError_t e = hipMemsetAsync(workspace, 0, head, st);
+    // (a kernel, not hipMemsetAsync: as a memset NODE of a recorded hipGraph the clear was observed not to take effect from the second replay on --
+    // stage 1's scatter cursors then ran past the workspace; tools/_dbg_loss.py)
+    hipLaunchKernelGGL(loss_clear_kernel, dim3(1), dim3(kLB), 0, st, (uint32_t*)workspace, (int)(head / 4));
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     int64_t nb = (P + kLB - 1) / kLB;
     int grid = (int)(nb > 2048 ? 2048 : (nb < 1 ? 1 : nb));

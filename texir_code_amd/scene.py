@@ -156,19 +156,38 @@ def generate_dir(normals, num_sample_dir, shift, mode="uniform", roughness=None)
     return L
 
 
+def spec_forward_raw(scene, normal, albedo, rough, points, irr, cam, shift, S, clamp_eps=1e-14, lighting=None):
+    """texir_spec_forward on contiguous float32 tensors (no autograd): -> (rgb [P,3], Ls [P,S,3] = the traced -- or given -- lighting the backward needs)"""
+    P = normal.shape[0]
+    rgb = torch.empty((P, 3), device=normal.device, dtype=torch.float32)
+    # lighting given: specular_reflectance on the caller's radiance (no tracing); else traced and kept for the backward
+    Ls = torch.empty((P, S, 3), device=normal.device, dtype=torch.float32) if lighting is None else lighting
+    if P > 0:
+        _lib.check(_lib.lib().texir_spec_forward(None if scene is None else scene.h, _lib.ptr(normal), _lib.ptr(albedo), _lib.ptr(rough), _lib.ptr(points),
+                                                 _lib.ptr(irr), _lib.ptr(cam), _lib.ptr(shift), P, S, float(clamp_eps), 0 if lighting is None else 1,
+                                                 _lib.ptr(rgb), _lib.ptr(Ls), _lib.stream_ptr()))
+    return rgb, Ls
+
+
+def spec_backward_raw(normal, rough, points, irr, cam, shift, Ls, d_rgb, S, clamp_eps=1e-14, need_albedo=True, need_rough=True):
+    """texir_spec_backward (no autograd): d rgb -> (d albedo [P,3] | None, d roughness [P] | None)"""
+    P = normal.shape[0]
+    d_rgb = d_rgb.contiguous()
+    d_a = torch.empty((P, 3), device=normal.device, dtype=torch.float32) if need_albedo else None
+    d_r = torch.empty((P,), device=normal.device, dtype=torch.float32) if need_rough else None
+    if P > 0 and (need_albedo or need_rough):
+        _lib.check(_lib.lib().texir_spec_backward(_lib.ptr(normal), _lib.ptr(rough), _lib.ptr(points), _lib.ptr(irr), _lib.ptr(cam),
+                                                  _lib.ptr(shift), _lib.ptr(Ls), _lib.ptr(d_rgb), P, S, float(clamp_eps), _lib.ptr(d_a), _lib.ptr(d_r),
+                                                  _lib.stream_ptr()))
+    return d_a, d_r
+
+
 class _SpecRender(torch.autograd.Function):
     """render + specular_reflectance (mat_nvdiffrast.py:201-249,260-279) with its analytic backward."""
 
     @staticmethod
     def forward(ctx, scene, normal, albedo, rough, points, irr, cam, shift, S, clamp_eps=1e-14, lighting=None):
-        P = normal.shape[0]
-        rgb = torch.empty((P, 3), device=normal.device, dtype=torch.float32)
-        # lighting given: specular_reflectance on the caller's radiance (no tracing); else traced and kept for the backward
-        Ls = torch.empty((P, S, 3), device=normal.device, dtype=torch.float32) if lighting is None else lighting
-        if P > 0:
-            _lib.check(_lib.lib().texir_spec_forward(None if scene is None else scene.h, _lib.ptr(normal), _lib.ptr(albedo), _lib.ptr(rough), _lib.ptr(points),
-                                                     _lib.ptr(irr), _lib.ptr(cam), _lib.ptr(shift), P, S, float(clamp_eps), 0 if lighting is None else 1,
-                                                     _lib.ptr(rgb), _lib.ptr(Ls), _lib.stream_ptr()))
+        rgb, Ls = spec_forward_raw(scene, normal, albedo, rough, points, irr, cam, shift, S, clamp_eps, lighting)
         ctx.save_for_backward(normal, rough, points, irr, cam, shift, Ls)
         ctx.S, ctx.clamp_eps = S, float(clamp_eps)
         return rgb
@@ -176,16 +195,16 @@ class _SpecRender(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_rgb):
         normal, rough, points, irr, cam, shift, Ls = ctx.saved_tensors
-        P = normal.shape[0]
-        d_rgb = d_rgb.contiguous()
-        need_a, need_r = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
-        d_a = torch.empty((P, 3), device=normal.device, dtype=torch.float32) if need_a else None
-        d_r = torch.empty((P,), device=normal.device, dtype=torch.float32) if need_r else None
-        if P > 0:
-            _lib.check(_lib.lib().texir_spec_backward(_lib.ptr(normal), _lib.ptr(rough), _lib.ptr(points), _lib.ptr(irr), _lib.ptr(cam),
-                                                      _lib.ptr(shift), _lib.ptr(Ls), _lib.ptr(d_rgb), P, ctx.S, ctx.clamp_eps, _lib.ptr(d_a), _lib.ptr(d_r),
-                                                      _lib.stream_ptr()))
+        d_a, d_r = spec_backward_raw(normal, rough, points, irr, cam, shift, Ls, d_rgb, ctx.S, ctx.clamp_eps, ctx.needs_input_grad[2], ctx.needs_input_grad[3])
         return None, None, d_a, d_r, None, None, None, None, None, None, None
+
+
+def spec_shift_arg(shift, P, dev):
+    """the `shift` argument of the specular kernels: a PINNED host tensor is handed over as it is (pinned allocations are mapped into the device's address
+    space: a recorded hipGraph reads each step's freshly drawn shifts without a staging copy); anything else becomes a float32 device tensor"""
+    if torch.is_tensor(shift) and shift.device.type == "cpu" and shift.is_pinned() and shift.dtype == torch.float32 and shift.is_contiguous() and shift.numel() == 2 * P:
+        return shift.reshape(P, 2)
+    return shift.to(device=dev, dtype=torch.float32).reshape(P, 2).contiguous()
 
 
 def spec_render(scene, normal, albedo, roughness, points, irr, cam_position, shift, num_samples, clamp_eps=1e-14, lighting=None):
@@ -196,12 +215,7 @@ def spec_render(scene, normal, albedo, roughness, points, irr, cam_position, shi
     P = normal.reshape(-1, 3).shape[0]
     f = lambda t, s: t.to(device=dev, dtype=torch.float32).reshape(*s).contiguous()
     S = int(num_samples)
-    # a PINNED host tensor as `shift` is handed to the kernels as it is: pinned allocations are mapped into the device's address space, and a
-    # recorded hipGraph (graph_step.py) can then read each step's freshly drawn shifts without a staging copy
-    if torch.is_tensor(shift) and shift.device.type == "cpu" and shift.is_pinned() and shift.dtype == torch.float32 and shift.is_contiguous() and shift.numel() == 2 * P:
-        sh = shift.reshape(P, 2)
-    else:
-        sh = f(shift, (P, 2))
+    sh = spec_shift_arg(shift, P, dev)
     return _SpecRender.apply(scene, f(normal, (P, 3)), f(albedo, (P, 3)), f(roughness, (P,)), f(points, (P, 3)), f(irr, (P, 3)),
                              f(cam_position, (3,)), sh, S, float(clamp_eps), None if lighting is None else f(lighting, (P, S, 3)))
 

@@ -15,13 +15,14 @@ single-GPU trajectory BIT FOR BIT, for any world size (tests/test_gpu_scale.py).
 runs as the plain replicated GraphedMatStep.
 
 The three phases between the collectives are hipGraphs (use_graph=True): P1 = zero_grad, mip builds, fetches, specular forward of the slice; P2 = loss
-on the gathered view + backward down to the slice's specular inputs; P3 = fetch backward of the full view + optimiser step.  use_graph=False runs the
+on the gathered view, its gradient, specular backward of the slice; P3 = the view's fetches again under autograd (mip stacks reused) with the total
+gradients -> gathers, folds -> optimiser step.  use_graph=False runs the
 same three phases eagerly."""
 import numpy as np
 import torch
 
 from . import dist_util
-from .scene import spec_render
+from .scene import spec_backward_raw, spec_forward_raw, spec_shift_arg
 
 
 class ShardedMatStep:
@@ -38,32 +39,34 @@ class ShardedMatStep:
         self._seed = None
 
     # ---- the three phases -------------------------------------------------------------------------------------------------------------------
+    # Every phase is self-contained for autograd: no graph made in one phase is walked in another (each phase is its own hipGraph recording, and an
+    # autograd graph carries the stream and the allocations of the recording that made it).  P1 and P2 call the specular kernels directly; P3
+    # fetches once more under autograd (the mip stacks P1 built are reused: 2-3 short fetch launches per step) and walks that graph itself.
     def _p1(self, st):
         m, stage = self.model, st["stage"]
         self.opt.zero_grad(set_to_none=True)
         gb = m._view_consts(m._gbuffer(st["mvp"], st["key"]))
-        albedo, rw, rough, irr = m._fetch_materials(gb, womipmap=(stage == 1))
-        st["fetch"] = {"albedo": albedo, "roughness": rough, "roughness_womipmap": rw}
+        with torch.no_grad():
+            albedo, rw, rough, irr = m._fetch_materials(gb, womipmap=(stage == 1))
         P, (p0, p1) = st["P"], st["range"]
         flat = lambda t, k: t.reshape(P, k)
-        # the slice's specular inputs are LEAVES: the backward of P2 stops here, the total gradient reaches the fetches in P3
-        a_src = flat(albedo.detach(), 3)[p0:p1]
-        st["a_in"] = a_src.clone().requires_grad_(stage == 2 and albedo.requires_grad)
+        st["vals"] = {"albedo": albedo, "roughness": rough, "roughness_womipmap": rw}
         r_full = rw if stage == 1 else rough
-        st["r_in"] = flat(r_full.detach(), 1)[p0:p1].reshape(-1).clone().requires_grad_(bool(r_full.requires_grad))
-        shift = st["shift"][p0:p1]
-        st["rgb_slice"] = spec_render(m.scene, flat(gb["normal"], 3)[p0:p1], st["a_in"], st["r_in"], flat(gb["_points"], 3)[p0:p1], flat(irr, 3)[p0:p1],
-                                      st["cam"], shift, int(m.sample_l[1]))
-        st["send1"][: p1 - p0].copy_(st["rgb_slice"].detach())
+        sl = {"normal": flat(gb["normal"], 3)[p0:p1].contiguous(), "albedo": flat(albedo, 3)[p0:p1].contiguous(),
+              "rough": flat(r_full, 1)[p0:p1].reshape(-1).contiguous(), "points": flat(gb["_points"], 3)[p0:p1].contiguous(),
+              "irr": flat(irr, 3)[p0:p1].contiguous(), "cam": st["cam"].to(torch.float32).reshape(3).contiguous(),
+              "shift": spec_shift_arg(st["shift"][p0:p1], p1 - p0, st["gt"].device)}
+        rgb_slice, sl["Ls"] = spec_forward_raw(m.scene, sl["normal"], sl["albedo"], sl["rough"], sl["points"], sl["irr"], sl["cam"], sl["shift"], int(m.sample_l[1]))
+        st["slice"] = sl
+        st["send1"][: p1 - p0].copy_(rgb_slice)
 
     def _p2(self, st):
         m, stage = self.model, st["stage"]
         P, c, (p0, p1) = st["P"], st["c"], st["range"]
         gb = m._gbuffer(st["mvp"], st["key"])
         rgb = torch.cat([st["recv1"][r][: b - a] for r, (a, b) in enumerate(st["ranges"])], 0).requires_grad_(True)
-        leaves = {}
-        for k, t in st["fetch"].items():
-            leaves[k] = None if t is None else t.detach().requires_grad_(bool(t.requires_grad))
+        train = {"albedo": m.materials_a.requires_grad, "roughness": m.materials_r.requires_grad, "roughness_womipmap": m.materials_r.requires_grad}
+        leaves = {k: (None if t is None else t.detach().requires_grad_(bool(train[k]))) for k, t in st["vals"].items()}
         sh = lambda t, k: None if t is None else t.reshape(6, c, c, k)
         preds = {"rgb": sh(rgb, 3), "albedo": sh(leaves["albedo"], 3), "roughness": sh(leaves["roughness"], 1),
                  "roughness_womipmap": sh(leaves["roughness_womipmap"], 1), "empty_mask": gb["mask"]}
@@ -71,30 +74,42 @@ class ShardedMatStep:
         st["out"] = (out[0].detach(),) + tuple(o.detach() if torch.is_tensor(o) else o for o in out[1:])
         if self._seed is None or self._seed.device != out[0].device:
             self._seed = torch.ones((), device=out[0].device)
-        torch.autograd.backward(out[0], self._seed)
-        st["leaves"] = leaves
-        # backward of the slice's specular term
-        torch.autograd.backward(st["rgb_slice"], rgb.grad[p0:p1].contiguous())
+        names = [k for k, t in leaves.items() if t is not None and t.requires_grad]
+        got = torch.autograd.grad(out[0], [rgb] + [leaves[k] for k in names], self._seed, allow_unused=True)
+        st["d_leaf"] = dict(zip(names, got[1:]))
+        # backward of the slice's specular term (stage 1 renders on the detached albedo: no albedo gradient)
+        sl = st["slice"]
+        d_a, d_r = spec_backward_raw(sl["normal"], sl["rough"], sl["points"], sl["irr"], sl["cam"], sl["shift"], sl["Ls"], got[0][p0:p1], int(m.sample_l[1]),
+                                     need_albedo=(stage == 2 and m.materials_a.requires_grad), need_rough=m.materials_r.requires_grad)
         s2 = st["send2"]
         s2.zero_()
-        if st["a_in"].grad is not None:
-            s2[: p1 - p0, 0:3].copy_(st["a_in"].grad)
-        if st["r_in"].grad is not None:
-            s2[: p1 - p0, 3].copy_(st["r_in"].grad)
+        if d_a is not None:
+            s2[: p1 - p0, 0:3].copy_(d_a)
+        if d_r is not None:
+            s2[: p1 - p0, 3].copy_(d_r)
 
     def _p3(self, st, step):
         """step: "none" (warm-up: fetch backward only), "eager", or "record" (the call is being recorded: host step counts advance per replay)"""
-        stage, P = st["stage"], st["P"]
+        m, stage, P = self.model, st["stage"], st["P"]
         full = torch.cat([st["recv2"][r][: b - a] for r, (a, b) in enumerate(st["ranges"])], 0)       # [P, 4]: d albedo (3), d roughness (1) of the specular term
         d_spec_a, d_spec_r = full[:, 0:3], full[:, 3:4]
+        # the view's fetches under autograd (same kernels, same values as in P1; the mip stacks of this step are reused)
+        gb = m._gbuffer(st["mvp"], st["key"])
+        for p in self.params:
+            p._texir_reuse_mips = True
+        try:
+            albedo, rw, rough, _ = m._fetch_materials(gb, womipmap=(stage == 1))
+        finally:
+            for p in self.params:
+                p._texir_reuse_mips = False
+        f, dl = {"albedo": albedo, "roughness": rough, "roughness_womipmap": rw}, st["d_leaf"]
         outs, grads = [], []
-        f, lv = st["fetch"], st["leaves"]
 
-        def add(t, leaf, extra):
+        def add(t, d_direct, extra):
             """total gradient of a fetch output = what the loss sent straight into it (+) what came through the specular term"""
             if t is None or not t.requires_grad:
                 return
-            g = None if leaf is None or leaf.grad is None else leaf.grad.reshape(t.shape)
+            g = None if d_direct is None else d_direct.reshape(t.shape)
             if extra is not None:
                 e = extra.reshape(t.shape)
                 g = e if g is None else g + e
@@ -102,10 +117,21 @@ class ShardedMatStep:
                 outs.append(t)
                 grads.append(g.contiguous())
 
-        add(f["albedo"], lv["albedo"], d_spec_a if stage == 2 else None)
-        add(f["roughness"], lv["roughness"], d_spec_r if stage == 2 else None)
-        add(f["roughness_womipmap"], lv["roughness_womipmap"], d_spec_r if stage == 1 else None)
-        torch.autograd.backward(outs, grads)
+        add(f["albedo"], dl.get("albedo"), d_spec_a if stage == 2 else None)
+        add(f["roughness"], dl.get("roughness"), d_spec_r if stage == 2 else None)
+        add(f["roughness_womipmap"], dl.get("roughness_womipmap"), d_spec_r if stage == 1 else None)
+        # the fetch backward of the full view: gathers over the view's tap lists, folds, parked stacks -- the gradient lands on the parameters exactly as in
+        # the single-process step.  One fetch at a time, the trilinear fetch of a texture before its un-mipmapped one (the order the single-process
+        # backward runs them; texture.py asks `owner.grad is None` to decide between the sparse and the dense level-0 form)
+        train = [p for p in self.params if p.requires_grad]
+        total = {id(p): None for p in train}
+        for t, g in zip(outs, grads):
+            part = torch.autograd.grad([t], train, [g], allow_unused=True)
+            for p, d in zip(train, part):
+                if d is not None:
+                    total[id(p)] = d if total[id(p)] is None else total[id(p)] + d
+            for p in train:
+                p.grad = total[id(p)]
         if step == "record":
             everyone = [q for grp in self.opt.param_groups for q in grp["params"]]
             st["stepping"] = [p for p in everyone if p.grad is not None or getattr(p, "_texir_grad_l1", None) is not None]
@@ -148,6 +174,11 @@ class ShardedMatStep:
         self._gather(st["recv2"], st["send2"])
         self._p3(st, "none")
         self.opt.zero_grad(set_to_none=True)
+        # nothing of the warm-up's autograd graph may outlive it: the parameters' AccumulateGrad nodes would be kept alive with the warm-up's stream and
+        # the recorded backward would synchronise with a stream that is not being captured
+        if self.use_graph:
+            for k in ("vals", "slice", "d_leaf", "out"):
+                st.pop(k, None)
         if hasattr(self.opt, "prepare"):
             self.opt.prepare()                         # moments + device-resident step records exist before a capture
         if not self.use_graph:

@@ -25,6 +25,10 @@ def _mips_for(owner, t0, levels):
     # hipGraph capture the build kernels must be part of the captured sequence)
     if hit is not None and hit[0] == key and not owner.requires_grad:
         return hit[1]
+    # one-shot promise of the caller (sharded_step.ShardedMatStep: the forward of a step fetches in one recorded phase, its backward re-fetches under
+    # autograd in another): the stack built earlier in THIS step is still valid, do not build it again
+    if getattr(owner, "_texir_reuse_mips", False) and hit is not None and hit[1].numel() == n and hit[1].device == t0.device:
+        return hit[1]
     if hit is not None and hit[1].numel() == n and hit[1].device == t0.device:
         rest = hit[1]
     else:
