@@ -117,6 +117,13 @@ TEXIR_API int texir_irt_generate(const texir_scene* scene, const float* pos /*de
                        int64_t Nt, int32_t N, int32_t mode, float* irr /*dev*/, uint64_t* stats /*dev, nullable*/,
                        void* stream);
 
+/* Recording texir_irt_generate into a hipGraph: a long list's partial-sum scratch cannot be allocated stream-ordered inside a recorded graph (ROCm 7.2:
+ * some replays then read wrong partial sums), so a launch on a CAPTURING stream uses scratch reserved on the scene beforehand and fails with a clear
+ * message if there is not enough: call this once, outside any capture, with the largest (n_ids, N) that will be recorded (384 bytes per listed texel at
+ * N >= 2048; nothing for lists < 32 768 texels).  One recorded launch per scene at a time may be in flight (they share the scratch).  Eager launches are
+ * unaffected.  No reference counterpart. */
+TEXIR_API int texir_scene_reserve_scratch(texir_scene* scene, int64_t n_ids, int32_t N);
+
 /* name of the kernel form ONE texir_irt_generate call over n_ids listed texels at N samples launches on this scene
  * ("irt_group_kernel<false, 4, 6>": 64 texels per wave; "irt_kernel<false, 4|2>": one texel per wave) -- the launcher's own
  * decision, so that bench.py's roofline names the kernel that really ran.  buf receives a NUL-terminated string. */

@@ -264,6 +264,15 @@ def test_irt_generate_never_blocks_and_first_call_is_capturable():
     assert sc.info()["sched_weight"] == 0                                  # undecided
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
+    g0 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g0, stream=side):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            rc = L.texir_irt_generate(sc.h, _lib.ptr(dpos), _lib.ptr(dnrm), _lib.ptr(dsh), _lib.ptr(ids), ids.numel(), res * res, N, 0, _lib.ptr(out), None, st)
+            assert rc != 0 and b"texir_scene_reserve_scratch" in L.texir_last_error()       # a recorded launch never allocates
+    torch.cuda.current_stream().wait_stream(side)
+    sc.reserve_irt_scratch(ids.numel(), N)
+    side.wait_stream(torch.cuda.current_stream())
     g = torch.cuda.CUDAGraph()
     with torch.cuda.stream(side):
         with torch.cuda.graph(g, stream=side):
@@ -271,7 +280,7 @@ def test_irt_generate_never_blocks_and_first_call_is_capturable():
             # tuning under capture is refused loudly and leaves the scene undecided ...
             rc = L.texir_scene_tune(sc.h, _lib.ptr(dpos), _lib.ptr(dnrm), _lib.ptr(dsh), _lib.ptr(ids), ids.numel(), N, 0, st)
             assert rc != 0 and b"captured" in L.texir_last_error()
-            # ... and the first generate call of the scene is recorded
+            # ... and the first generate call of the scene is recorded (on the scratch reserved for it; without a reservation the call says so)
             _lib.check(L.texir_irt_generate(sc.h, _lib.ptr(dpos), _lib.ptr(dnrm), _lib.ptr(dsh), _lib.ptr(ids), ids.numel(), res * res, N, 0,
                                             _lib.ptr(out), None, st))
     torch.cuda.current_stream().wait_stream(side)
@@ -283,7 +292,7 @@ def test_irt_generate_never_blocks_and_first_call_is_capturable():
     info = sc.info()
     assert info["sched_weight"] in (1, 2) and info["node_step_fill"] is not None and 0.2 < info["node_step_fill"] < 1.0
     assert torch.equal(replayed, eager)
-    for _ in range(3):                        # (the chunk counters must be cleared by EVERY replay: start from a wiped texture each time)
+    for _ in range(6):                        # (every replay must do the whole work again: start from a wiped texture each time)
         out.zero_()
         g.replay()
         torch.cuda.synchronize()

@@ -45,6 +45,7 @@ def lib():
             "texir_scene_scheduler": [vp, vp],
             "texir_scene_tune": [vp, vp, vp, vp, vp, i64, i32, i32, vp],
             "texir_scene_prefetch": [vp, i32, i32, vp],
+            "texir_scene_reserve_scratch": [vp, i64, i32],
             "texir_trace_shade": [vp, vp, vp, i64, f32, vp, vp, vp, vp, vp],
             "texir_generate_dir": [vp, vp, vp, i64, i32, i32, vp, vp],
             "texir_irt_generate": [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp, vp, vp],

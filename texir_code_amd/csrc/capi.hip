@@ -29,6 +29,8 @@ struct texir_scene {
     size_t tex_bytes = 0;
     std::vector<uint32_t> slot_prim;     // leaf slot -> primitive id (host copy, for per-corner attribute uploads)
     void* d_cnrm = nullptr;              // leaf-ordered corner normals, 3 x float4 per triangle
+    float* d_scratch = nullptr;          // texir_scene_reserve_scratch: the IrT partial-sum scratch of RECORDED launches (eager launches allocate stream-ordered)
+    size_t scratch_bytes = 0;
     // chunk counters of the persistent IrT kernel: one slot per launch, handed out round-robin so that launches of one scene that
     // overlap on different streams do not share a counter (kWorkSlots launches would have to be in flight at once)
     static constexpr int kWorkSlots = 64;
@@ -142,6 +144,7 @@ int texir_scene_destroy(texir_scene* s)
     if (s->d_tex) (void)hipFree(s->d_tex);
     if (s->d_tex_tiled) (void)hipFree(s->d_tex_tiled);
     if (s->d_cnrm) (void)hipFree(s->d_cnrm);
+    if (s->d_scratch) (void)hipFree(s->d_scratch);
     if (s->d_work) (void)hipFree(s->d_work);
     delete s;
     return TEXIR_OK;
@@ -249,7 +252,30 @@ int texir_irt_generate(const texir_scene* s, const float* pos, const float* nrm,
     unsigned long long* work = s->d_work + (size_t)(s->work_next.fetch_add(1) % texir_scene::kWorkSlots) * 8 * kWorkStride;
     // (No measurement and no synchronisation in here: the phase scheduler's weight is whatever texir_scene_tune / TEXIR_SCHED_WEIGHT has decided for
     // the scene, 2 until then.  The texture is the same bits either way.)
-    HIP_TRY(launch_irt(dev_of(s), pos, nrm, shift, texel_ids, n, N, mode, irr, (unsigned long long*)stats, work, (hipStream_t)stream));
+    // A launch that is being RECORDED into a hipGraph must not allocate: stream-ordered allocations inside a recorded graph gave wrong partial sums in
+    // some replays on this stack (ROCm 7.2: profiles/r04, graph replay probe).  It uses the scratch the caller reserved on the scene beforehand.
+    float* scratch = nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        const size_t need = irt_scratch_bytes(s->dev, n, N);
+        if (need > s->scratch_bytes)
+            return fail(TEXIR_ERR_INVALID, "texir_irt_generate: the stream is being captured and the launch needs %zu bytes of scratch, %zu reserved -- call "
+                                           "texir_scene_reserve_scratch(scene, n_ids, N) before recording", need, s->scratch_bytes);
+        scratch = need ? s->d_scratch : nullptr;
+    }
+    HIP_TRY(launch_irt(dev_of(s), pos, nrm, shift, texel_ids, n, N, mode, irr, (unsigned long long*)stats, work, (hipStream_t)stream, scratch));
+    return TEXIR_OK;
+}
+
+int texir_scene_reserve_scratch(texir_scene* s, int64_t n_ids, int32_t N)
+{
+    if (!s || n_ids < 0 || N <= 0) return fail(TEXIR_ERR_INVALID, "texir_scene_reserve_scratch: bad argument");
+    const size_t need = irt_scratch_bytes(s->dev, n_ids, N);
+    if (need <= s->scratch_bytes) return TEXIR_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    if (s->d_scratch) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(s->d_scratch); s->d_scratch = nullptr; s->scratch_bytes = 0; }
+    HIP_TRY(hipMalloc((void**)&s->d_scratch, need));
+    s->scratch_bytes = need;
     return TEXIR_OK;
 }
 

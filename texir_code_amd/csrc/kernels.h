@@ -8,7 +8,8 @@
 namespace texir {
 hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, const float* shift, const int32_t* ids, int64_t n_ids,
                       int N, int mode, float* irr, unsigned long long* stats, unsigned long long* work /*dev: 8 * kWorkStride chunk counters of this launch*/,
-                      hipStream_t st);
+                      hipStream_t st, float* scratch = nullptr /*dev: caller-owned partial-sum scratch of >= irt_scratch_bytes(), else stream-ordered*/);
+size_t irt_scratch_bytes(const SceneDev& sc, int64_t n_ids, int N);      // bytes of partial-sum scratch one launch_irt call over n_ids listed texels needs (0: none)
 constexpr int kWorkStride = 16;              // unsigned long longs between the per-XCD chunk counters of one launch (a 128-byte line each)
 hipError_t irt_probe_node_utilisation(const SceneDev& sc, const float* pos, const float* nrm, const float* shift, const int32_t* ids, int64_t first, int64_t count,
                                       int N, int mode, unsigned long long* work, hipStream_t st, double* util);

@@ -332,6 +332,11 @@ __global__ __launch_bounds__(kBlock, TEXIR_STREAM_WAVES) void irt_stream_kernel(
     if (STATS) irt_stats_flush(stats, lane, c_rays, cn, ct, c_hits, wi[0], wi[1]);
 }
 
+__global__ __launch_bounds__(128) void clear_u64_kernel(unsigned long long* __restrict__ p, int n)
+{
+    for (int i = threadIdx.x; i < n; i += 128) p[i] = 0ull;
+}
+
 // irr[t] = (2 pi / N) * (partial sums of the texel's pass ranges, added in part order)          (tracer_o3d_irt.py:171)
 __global__ __launch_bounds__(256) void irt_combine_kernel(const float* __restrict__ partial, const int32_t* __restrict__ ids, int64_t n_ids,
                                                           int parts, int N, float two, float* __restrict__ irr)
@@ -667,11 +672,21 @@ static void irt_launch(K kernel, int64_t waves_wanted, const SceneDev& sc, const
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, irr, stats, work, partial, log2parts);
 }
 
+size_t irt_scratch_bytes(const SceneDev& sc, int64_t n_ids, int N)
+{
+    if (n_ids <= 0) return 0;
+    const IrtPlan plan = irt_plan(sc, n_ids, N);
+    return plan.log2parts ? (sizeof(float) * 3 * (size_t)n_ids << plan.log2parts) : 0;
+}
+
 hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, const float* shift, const int32_t* ids, int64_t n_ids,
-                      int N, int mode, float* irr, unsigned long long* stats, unsigned long long* work, hipStream_t st)
+                      int N, int mode, float* irr, unsigned long long* stats, unsigned long long* work, hipStream_t st, float* scratch)
 {
     if (n_ids <= 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(work, 0, sizeof(unsigned long long) * 8 * kWorkStride, st);       // the chunk counters of this launch (one per XCD)
+    // the chunk counters of this launch (one per XCD), cleared by a KERNEL: recorded into a hipGraph, a hipMemsetAsync node was observed to stop taking
+    // effect from the second replay on (tools/graph_memset_probe.py; every later replay of texir_irt_generate then found its queues exhausted)
+    hipLaunchKernelGGL(clear_u64_kernel, dim3(1), dim3(128), 0, st, work, 8 * kWorkStride);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const bool pow2 = (N & (N - 1)) == 0;
     const int l2 = ilog2_exact(N);
@@ -694,7 +709,8 @@ hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, co
             }
             pool_set = true;
         }
-        if ((e = hipMallocAsync((void**)&partial, bytes, st)) != hipSuccess) return e;
+        if (scratch) partial = scratch;                  // (caller-owned: the form a recorded hipGraph uses -- texir_scene_reserve_scratch)
+        else if ((e = hipMallocAsync((void**)&partial, bytes, st)) != hipSuccess) return e;
     }
     if (!sc.nodes4) TEXIR_IRT(n_ids, l2, irt_kernel, 2)                                        // deep binary tree (capi.hip fallback)
     else if (per_wave == 1) TEXIR_IRT(n_ids, l2, irt_kernel, 4)
@@ -714,7 +730,7 @@ hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, co
 #undef TEXIR_IRT
     if (log2parts) {
         hipLaunchKernelGGL(irt_combine_kernel, dim3(grid_for(256, 3 * n_ids)), dim3(256), 0, st, partial, ids, n_ids, 1 << log2parts, N, (mode & kEstimatorCosine) ? 1.f : 2.f, irr);
-        if ((e = hipFreeAsync(partial, st)) != hipSuccess) return e;
+        if (!scratch && (e = hipFreeAsync(partial, st)) != hipSuccess) return e;
     }
     return hipGetLastError();
 }
@@ -734,11 +750,13 @@ hipError_t irt_probe_node_utilisation(const SceneDev& sc, const float* pos, cons
     if (!log2parts) return hipSuccess;
     hipError_t e;
     float* partial = nullptr; unsigned long long* stats = nullptr;
-    if ((e = hipMemsetAsync(work, 0, sizeof(unsigned long long) * 8 * kWorkStride, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(clear_u64_kernel, dim3(1), dim3(128), 0, st, work, 8 * kWorkStride);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = hipMallocAsync((void**)&partial, (sizeof(float) * 3 * (size_t)count << log2parts) + 8 * sizeof(unsigned long long), st)) != hipSuccess) return e;
     stats = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(partial) + (sizeof(float) * 3 * (size_t)count << log2parts));
     auto drop = [&](hipError_t err) { (void)hipFreeAsync(partial, st); return err; };           // (no error path keeps the scratch)
-    if ((e = hipMemsetAsync(stats, 0, 8 * sizeof(unsigned long long), st)) != hipSuccess) return drop(e);
+    hipLaunchKernelGGL(clear_u64_kernel, dim3(1), dim3(128), 0, st, stats, 8);
+    if ((e = hipGetLastError()) != hipSuccess) return drop(e);
     SceneDev probe = sc;
     probe.sched_weight = kSchedNodeWeight;
     irt_launch(irt_group_kernel<true, 4, 6>, ((count + 63) / 64) << log2parts, probe, pos, nrm, shift, ids + first, count, Nc, l2, mode, (float*)nullptr, stats, work, partial, log2parts, st);

@@ -79,6 +79,11 @@ class Scene:
         d["sched_weight"], d["node_step_fill"] = int(sch[0]), (None if sch[1] < 0 else round(float(sch[1]), 4))
         return d
 
+    def reserve_irt_scratch(self, n_ids, n_samples):
+        """before RECORDING irt_generate over n_ids listed texels into a hipGraph: reserve the partial-sum scratch the recorded launch will use (a recorded
+        graph must not allocate; include/texir_hip.h texir_scene_reserve_scratch).  Eager calls need nothing."""
+        _lib.check(_lib.lib().texir_scene_reserve_scratch(self.h, int(n_ids), int(n_samples)))
+
     def irt_kernel_name(self, n_ids, n_samples):
         """the kernel form one irt_generate call over n_ids listed texels launches (the launcher's own decision)"""
         buf = C.create_string_buffer(96)
