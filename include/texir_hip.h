@@ -141,6 +141,15 @@ TEXIR_API int texir_spec_forward(const texir_scene* scene /*nullable when ls_giv
                        const float* points, const float* irr, const float* cam, const float* shift, int64_t P,
                        int32_t S, float clamp_eps, int32_t ls_given, float* rgb /*dev [P,3]*/, float* Ls_ws /*dev, nullable*/, void* stream);
 
+/* The training form of the pair (round 4): the forward also writes dw_ws [P,S] = d w_i / d roughness (its dual-number sample chain yields them next to the
+ * weights), and the backward is a stream over what the forward kept -- d_rough[p] = (1/S) sum_i (Ls_i . d_rgb[p]) dw_i, d_albedo = d_rgb*irr/pi -- instead of
+ * texir_spec_backward's recomputation of the whole sample chain.  Same values as the pair above (tests/test_gpu_parity.py). */
+TEXIR_API int texir_spec_forward_train(const texir_scene* scene /*nullable when ls_given*/, const float* normal, const float* albedo, const float* rough,
+                       const float* points, const float* irr, const float* cam, const float* shift, int64_t P,
+                       int32_t S, float clamp_eps, int32_t ls_given, float* rgb /*dev [P,3]*/, float* Ls_ws /*dev [P,S,3]*/, float* dw_ws /*dev [P,S]*/, void* stream);
+TEXIR_API int texir_spec_backward_ws(const float* irr, const float* Ls_ws, const float* dw_ws, const float* d_rgb, int64_t P, int32_t S,
+                       float* d_albedo /*dev [P,3], nullable*/, float* d_rough /*dev [P], nullable*/, void* stream);
+
 /* Analytic backward of the above (what autograd computes in the reference): given d_rgb [P,3],
  *   d_albedo [P,3] = d_rgb*irr/pi ;  d_rough [P] = sum_c d_rgb_c * (1/S) sum_i Ls_ic * dw_i/dr
  * (gradient through a=r^2 -> cos/sin theta -> h -> vdh -> l -> ndl, ndh and through k=(r+1)^2/8; Ls constant,

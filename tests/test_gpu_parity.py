@@ -789,3 +789,31 @@ def test_fused_loss_recorded_alone_replays_identically(golden, tx, stage):
         assert float(hold["loss"]) == want[0]
         for a, b in zip(hold["grads"], want[1]):
             assert torch.equal(a, b)
+
+
+def test_spec_backward_on_kept_derivatives_equals_the_recomputing_backward(room, tx):
+    """round 4: the training forward keeps d w_i / d roughness (texir_spec_forward_train) and the backward streams over (Ls, dw, d rgb)
+    (texir_spec_backward_ws) instead of recomputing the GGX sample chain (texir_spec_backward): same rgb bits, same gradients"""
+    from texir_code_amd import scene as S
+    g, sc, _ = room
+    rng = np.random.default_rng(31)
+    v = np.argwhere(g["valid"].reshape(-1) > 0)[:, 0][:3001]
+    P = v.size
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    nrm, pts = t(g["nrm"].reshape(-1, 3)[v]), t(g["pos"].reshape(-1, 3)[v])
+    alb0, r0 = t(rng.uniform(0, 1, (P, 3))), t(rng.uniform(0.02, 0.7, P))
+    irr, sh, G = t(rng.uniform(0, 2, (P, 3))), t(rng.uniform(0, 1, (P, 2))), t(rng.normal(size=(P, 3)))
+    cam = torch.tensor([4.0, 1.5, 3.0], device="cuda")
+    out = {}
+    for form in (True, False):
+        S._TRAIN_FORM[0] = form
+        try:
+            a, r = alb0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+            rgb = S.spec_render(sc, nrm, a, r, pts, irr, cam, sh, 16)
+            (rgb * G).sum().backward()
+            out[form] = (rgb.detach().clone(), a.grad.clone(), r.grad.clone())
+        finally:
+            S._TRAIN_FORM[0] = True
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+    assert float(out[False][2].abs().max()) > 0
+    assert rel_l2(out[True][2].cpu().numpy(), out[False][2].cpu().numpy()) < 1e-6

@@ -51,6 +51,8 @@ def lib():
             "texir_irt_generate": [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp, vp, vp],
             "texir_spec_forward": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp, vp, vp],
             "texir_spec_backward": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp, vp, vp],
+            "texir_spec_forward_train": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp, vp, vp, vp],
+            "texir_spec_backward_ws": [vp, vp, vp, vp, i64, i32, vp, vp, vp],
             "texir_diffuse_irradiance": [vp, vp, vp, vp, i64, i32, i32, vp, vp],
         }
         sig["texir_irt_kernel_name"] = [vp, i64, i32, C.c_char_p, i32]

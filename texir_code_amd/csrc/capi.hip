@@ -298,6 +298,26 @@ int texir_spec_forward(const texir_scene* s, const float* normal, const float* a
     return TEXIR_OK;
 }
 
+int texir_spec_forward_train(const texir_scene* s, const float* normal, const float* albedo, const float* rough, const float* points, const float* irr,
+                             const float* cam, const float* shift, int64_t P, int32_t S, float clamp_eps, int32_t ls_given, float* rgb, float* Ls_ws, float* dw_ws,
+                             void* stream)
+{
+    if ((!s && !ls_given) || !normal || !albedo || !rough || !points || !irr || !cam || !shift || !rgb || !Ls_ws || !dw_ws)
+        return fail(TEXIR_ERR_INVALID, "texir_spec_forward_train: null argument");
+    if (P < 0 || S <= 0 || !(clamp_eps > 0.f)) return fail(TEXIR_ERR_INVALID, "texir_spec_forward_train: bad sizes P=%lld S=%d clamp_eps=%g", (long long)P, S, (double)clamp_eps);
+    SceneDev none{};
+    HIP_TRY(launch_spec_fwd(s ? dev_of(s) : none, normal, albedo, rough, points, irr, cam, shift, P, S, clamp_eps, ls_given ? 1 : 0, rgb, Ls_ws, (hipStream_t)stream, dw_ws));
+    return TEXIR_OK;
+}
+
+int texir_spec_backward_ws(const float* irr, const float* Ls_ws, const float* dw_ws, const float* d_rgb, int64_t P, int32_t S, float* d_albedo, float* d_rough, void* stream)
+{
+    if (!irr || !Ls_ws || !dw_ws || !d_rgb) return fail(TEXIR_ERR_INVALID, "texir_spec_backward_ws: null argument");
+    if (P < 0 || S <= 0) return fail(TEXIR_ERR_INVALID, "texir_spec_backward_ws: bad sizes P=%lld S=%d", (long long)P, S);
+    HIP_TRY(launch_spec_bwd_ws(irr, Ls_ws, dw_ws, d_rgb, P, S, d_albedo, d_rough, (hipStream_t)stream));
+    return TEXIR_OK;
+}
+
 int texir_spec_backward(const float* normal, const float* rough, const float* points, const float* irr, const float* cam, const float* shift,
                         const float* Ls_ws, const float* d_rgb, int64_t P, int32_t S, float clamp_eps, float* d_albedo, float* d_rough, void* stream)
 {

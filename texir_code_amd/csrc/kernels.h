@@ -23,7 +23,9 @@ hipError_t launch_trace_shade(const SceneDev& sc, const float* org, const float*
 hipError_t launch_gen_dir(const float* normals, const float* rough, const float* shift, int64_t b, int N, int mode, float* L, hipStream_t st);
 hipError_t launch_spec_fwd(const SceneDev& sc, const float* normal, const float* albedo, const float* rough, const float* points,
                            const float* irr, const float* cam, const float* shift, int64_t P, int S, float clamp_eps, int ls_given, float* rgb, float* Ls_ws,
-                           hipStream_t st);
+                           hipStream_t st, float* dw_ws = nullptr /*dev [P,S], nullable: d w_i / d roughness for launch_spec_bwd_ws*/);
+hipError_t launch_spec_bwd_ws(const float* irr, const float* Ls_ws, const float* dw_ws, const float* d_rgb, int64_t P, int S, float* d_albedo, float* d_rough,
+                              hipStream_t st);
 hipError_t launch_spec_bwd(const float* normal, const float* rough, const float* points, const float* irr, const float* cam,
                            const float* shift, const float* Ls_ws, const float* d_rgb, int64_t P, int S, float clamp_eps, float* d_albedo, float* d_rough,
                            hipStream_t st);

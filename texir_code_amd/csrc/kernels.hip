@@ -522,7 +522,10 @@ __device__ __forceinline__ SpecSample spec_sample(const Frame& f, float nx, floa
 #define TEXIR_SPEC_LSTK (TEXIR_SPEC_WAVES >= 7 && TEXIR_CULL ? (TEXIR_SPEC_WAVES >= 8 ? 10 : 11) : kLstk)
 #endif
 constexpr int kSpecLstk = TEXIR_SPEC_LSTK;
-template <bool BWD, int WIDTH>
+// DW (forward only): the sample weights' derivatives d w_i / d roughness -- which the dual-number chain yields next to the weights at no extra fetch, in a
+// kernel that waits on memory with two thirds of its issue slots free -- are written to dw_ws [P,S]; the backward is then spec_bwd_ws_kernel, a stream over
+// (Ls, dw, d rgb), instead of this kernel's BWD form recomputing the whole sample chain (38 us of the material step: round 4).
+template <bool BWD, int WIDTH, bool DW = false>
 __global__
 #if TEXIR_SPEC_WAVES
 __launch_bounds__(kBlock, TEXIR_SPEC_WAVES)
@@ -535,7 +538,7 @@ void spec_kernel(SceneDev sc, const float* __restrict__ normal, const float* __r
                                                       const float* __restrict__ shift, int64_t P, int S, int lpp,
                                                       float* __restrict__ rgb, float* __restrict__ Ls_ws,
                                                       const float* __restrict__ d_rgb, float* __restrict__ d_albedo, float* __restrict__ d_rough, float ceps,
-                                                      int ls_given)
+                                                      int ls_given, float* __restrict__ dw_ws = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const int ppw = 64 / lpp;                              // pixels per wave
@@ -569,6 +572,7 @@ void spec_kernel(SceneDev sc, const float* __restrict__ normal, const float* __r
                 float s0 = shift_wrap_clamp(ham0((uint32_t)i, (uint32_t)S), sh0);
                 float s1 = shift_wrap_clamp(ham1((uint32_t)i), sh1);
                 SpecSample ss = spec_sample(f, nx, ny, nz, vx, vy, vz, r, s0, s1, ceps);
+                if constexpr (DW) dw_ws[(size_t)p * S + i] = ss.w.d;          // (before the trace: the derivative does not stay live across the traversal)
                 float L[3] = {0.f, 0.f, 0.f};
                 if (BWD) {
                     const float* lp = Ls_ws + 3 * ((size_t)p * S + i);
@@ -603,6 +607,38 @@ void spec_kernel(SceneDev sc, const float* __restrict__ normal, const float* __r
             } else {
                 for (int c = 0; c < 3; c++) rgb[3 * p + c] = irr[3 * p + c] * albedo[3 * p + c] / pi + acc[c] / (float)S;
             }
+        }
+    }
+}
+
+// Backward of the specular term on what the forward kept: d roughness[p] = (1/S) sum_i (Ls_i . d rgb[p]) * dw_i, d albedo[p] = d rgb[p] * irr[p] / pi.  Same lane
+// assignment, same expression and same reduction order as spec_kernel<BWD>.
+__global__ __launch_bounds__(kBlock) void spec_bwd_ws_kernel(const float* __restrict__ irr, const float* __restrict__ Ls_ws, const float* __restrict__ dw_ws,
+                                                            const float* __restrict__ d_rgb, int64_t P, int S, int lpp,
+                                                            float* __restrict__ d_albedo, float* __restrict__ d_rough)
+{
+    const int lane = threadIdx.x & 63;
+    const int ppw = 64 / lpp;
+    const int sub = lane / lpp, sl = lane % lpp;
+    const int64_t gw = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * kBlock) >> 6;
+    const int passes = (S + lpp - 1) / lpp;
+    for (int64_t base = gw * ppw; base < P; base += nw * ppw) {
+        const int64_t p = base + sub;
+        const bool live = p < P;
+        float dacc = 0.f, g0 = 0, g1 = 0, g2 = 0;
+        if (live) { g0 = d_rgb[3 * p]; g1 = d_rgb[3 * p + 1]; g2 = d_rgb[3 * p + 2]; }
+        for (int q = 0; q < passes; q++) {
+            const int i = q * lpp + sl;
+            if (live && i < S) {
+                const float* lp = Ls_ws + 3 * ((size_t)p * S + i);
+                dacc += (lp[0] * g0 + lp[1] * g1 + lp[2] * g2) * dw_ws[(size_t)p * S + i];
+            }
+        }
+        for (int o = lpp >> 1; o > 0; o >>= 1) dacc += __shfl_xor(dacc, o, 64);
+        if (live && sl == 0) {
+            const float pi = 3.141592653589793f;
+            if (d_rough) d_rough[p] = dacc / (float)S;
+            if (d_albedo) { d_albedo[3 * p] = g0 * irr[3 * p] / pi; d_albedo[3 * p + 1] = g1 * irr[3 * p + 1] / pi; d_albedo[3 * p + 2] = g2 * irr[3 * p + 2] / pi; }
         }
     }
 }
@@ -807,17 +843,27 @@ static int lanes_per_pixel(int S)
 
 hipError_t launch_spec_fwd(const SceneDev& sc, const float* normal, const float* albedo, const float* rough, const float* points,
                            const float* irr, const float* cam, const float* shift, int64_t P, int S, float clamp_eps, int ls_given, float* rgb, float* Ls_ws,
-                           hipStream_t st)
+                           hipStream_t st, float* dw_ws)
 {
     if (P <= 0) return hipSuccess;
     int lpp = lanes_per_pixel(S);
     int64_t pix_per_block = (int64_t)(kBlock / 64) * (64 / lpp);
-    if (sc.nodes4 || ls_given)
-        hipLaunchKernelGGL((spec_kernel<false, 4>), dim3(spec_grid(pix_per_block, P)), dim3(kBlock), 0, st, sc, normal, albedo, rough, points, irr, cam,
-                           shift, P, S, lpp, rgb, Ls_ws, (const float*)nullptr, (float*)nullptr, (float*)nullptr, clamp_eps, ls_given);
-    else
-        hipLaunchKernelGGL((spec_kernel<false, 2>), dim3(spec_grid(pix_per_block, P)), dim3(kBlock), 0, st, sc, normal, albedo, rough, points, irr, cam,
-                           shift, P, S, lpp, rgb, Ls_ws, (const float*)nullptr, (float*)nullptr, (float*)nullptr, clamp_eps, ls_given);
+    const dim3 grid(spec_grid(pix_per_block, P));
+#define TEXIR_SPEC_FWD(W, DW) hipLaunchKernelGGL((spec_kernel<false, W, DW>), grid, dim3(kBlock), 0, st, sc, normal, albedo, rough, points, irr, cam, shift, P, S, lpp, rgb, Ls_ws, \
+                                                 (const float*)nullptr, (float*)nullptr, (float*)nullptr, clamp_eps, ls_given, dw_ws)
+    if (sc.nodes4 || ls_given) { if (dw_ws) TEXIR_SPEC_FWD(4, true); else TEXIR_SPEC_FWD(4, false); }
+    else { if (dw_ws) TEXIR_SPEC_FWD(2, true); else TEXIR_SPEC_FWD(2, false); }
+#undef TEXIR_SPEC_FWD
+    return hipGetLastError();
+}
+
+hipError_t launch_spec_bwd_ws(const float* irr, const float* Ls_ws, const float* dw_ws, const float* d_rgb, int64_t P, int S, float* d_albedo, float* d_rough,
+                              hipStream_t st)
+{
+    if (P <= 0) return hipSuccess;
+    int lpp = lanes_per_pixel(S);
+    int64_t pix_per_block = (int64_t)(kBlock / 64) * (64 / lpp);
+    hipLaunchKernelGGL(spec_bwd_ws_kernel, dim3(spec_grid(pix_per_block, P)), dim3(kBlock), 0, st, irr, Ls_ws, dw_ws, d_rgb, P, S, lpp, d_albedo, d_rough);
     return hipGetLastError();
 }
 

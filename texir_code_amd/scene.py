@@ -161,29 +161,39 @@ def generate_dir(normals, num_sample_dir, shift, mode="uniform", roughness=None)
     return L
 
 
-def spec_forward_raw(scene, normal, albedo, rough, points, irr, cam, shift, S, clamp_eps=1e-14, lighting=None):
-    """texir_spec_forward on contiguous float32 tensors (no autograd): -> (rgb [P,3], Ls [P,S,3] = the traced -- or given -- lighting the backward needs)"""
+def spec_forward_raw(scene, normal, albedo, rough, points, irr, cam, shift, S, clamp_eps=1e-14, lighting=None, want_dw=False):
+    """texir_spec_forward on contiguous float32 tensors (no autograd): -> (rgb [P,3], Ls [P,S,3] = the traced -- or given -- lighting the backward needs,
+    dw [P,S] | None = the sample weights' derivatives wrt roughness when want_dw: the training form, texir_spec_forward_train)"""
     P = normal.shape[0]
     rgb = torch.empty((P, 3), device=normal.device, dtype=torch.float32)
     # lighting given: specular_reflectance on the caller's radiance (no tracing); else traced and kept for the backward
     Ls = torch.empty((P, S, 3), device=normal.device, dtype=torch.float32) if lighting is None else lighting
+    dw = torch.empty((P, S), device=normal.device, dtype=torch.float32) if want_dw else None
     if P > 0:
-        _lib.check(_lib.lib().texir_spec_forward(None if scene is None else scene.h, _lib.ptr(normal), _lib.ptr(albedo), _lib.ptr(rough), _lib.ptr(points),
-                                                 _lib.ptr(irr), _lib.ptr(cam), _lib.ptr(shift), P, S, float(clamp_eps), 0 if lighting is None else 1,
-                                                 _lib.ptr(rgb), _lib.ptr(Ls), _lib.stream_ptr()))
-    return rgb, Ls
+        L = _lib.lib()
+        head = (None if scene is None else scene.h, _lib.ptr(normal), _lib.ptr(albedo), _lib.ptr(rough), _lib.ptr(points), _lib.ptr(irr), _lib.ptr(cam), _lib.ptr(shift),
+                P, S, float(clamp_eps), 0 if lighting is None else 1, _lib.ptr(rgb), _lib.ptr(Ls))
+        if want_dw:
+            _lib.check(L.texir_spec_forward_train(*head, _lib.ptr(dw), _lib.stream_ptr()))
+        else:
+            _lib.check(L.texir_spec_forward(*head, _lib.stream_ptr()))
+    return rgb, Ls, dw
 
 
-def spec_backward_raw(normal, rough, points, irr, cam, shift, Ls, d_rgb, S, clamp_eps=1e-14, need_albedo=True, need_rough=True):
-    """texir_spec_backward (no autograd): d rgb -> (d albedo [P,3] | None, d roughness [P] | None)"""
+def spec_backward_raw(normal, rough, points, irr, cam, shift, Ls, d_rgb, S, clamp_eps=1e-14, need_albedo=True, need_rough=True, dw=None):
+    """d rgb -> (d albedo [P,3] | None, d roughness [P] | None), no autograd.  dw (from spec_forward_raw(want_dw=True)): texir_spec_backward_ws, a stream over
+    what the forward kept; else texir_spec_backward, which recomputes the sample chain"""
     P = normal.shape[0]
     d_rgb = d_rgb.contiguous()
     d_a = torch.empty((P, 3), device=normal.device, dtype=torch.float32) if need_albedo else None
     d_r = torch.empty((P,), device=normal.device, dtype=torch.float32) if need_rough else None
     if P > 0 and (need_albedo or need_rough):
-        _lib.check(_lib.lib().texir_spec_backward(_lib.ptr(normal), _lib.ptr(rough), _lib.ptr(points), _lib.ptr(irr), _lib.ptr(cam),
-                                                  _lib.ptr(shift), _lib.ptr(Ls), _lib.ptr(d_rgb), P, S, float(clamp_eps), _lib.ptr(d_a), _lib.ptr(d_r),
-                                                  _lib.stream_ptr()))
+        if dw is not None:
+            _lib.check(_lib.lib().texir_spec_backward_ws(_lib.ptr(irr), _lib.ptr(Ls), _lib.ptr(dw), _lib.ptr(d_rgb), P, S, _lib.ptr(d_a), _lib.ptr(d_r), _lib.stream_ptr()))
+        else:
+            _lib.check(_lib.lib().texir_spec_backward(_lib.ptr(normal), _lib.ptr(rough), _lib.ptr(points), _lib.ptr(irr), _lib.ptr(cam),
+                                                      _lib.ptr(shift), _lib.ptr(Ls), _lib.ptr(d_rgb), P, S, float(clamp_eps), _lib.ptr(d_a), _lib.ptr(d_r),
+                                                      _lib.stream_ptr()))
     return d_a, d_r
 
 
@@ -192,16 +202,22 @@ class _SpecRender(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, scene, normal, albedo, rough, points, irr, cam, shift, S, clamp_eps=1e-14, lighting=None):
-        rgb, Ls = spec_forward_raw(scene, normal, albedo, rough, points, irr, cam, shift, S, clamp_eps, lighting)
-        ctx.save_for_backward(normal, rough, points, irr, cam, shift, Ls)
+        # roughness is being optimised: keep the weights' derivatives the forward computes anyway, and the backward needs no second pass over the sample chain
+        want_dw = bool(ctx.needs_input_grad[3]) and _TRAIN_FORM[0]
+        rgb, Ls, dw = spec_forward_raw(scene, normal, albedo, rough, points, irr, cam, shift, S, clamp_eps, lighting, want_dw)
+        ctx.save_for_backward(normal, rough, points, irr, cam, shift, Ls, dw)
         ctx.S, ctx.clamp_eps = S, float(clamp_eps)
         return rgb
 
     @staticmethod
     def backward(ctx, d_rgb):
-        normal, rough, points, irr, cam, shift, Ls = ctx.saved_tensors
-        d_a, d_r = spec_backward_raw(normal, rough, points, irr, cam, shift, Ls, d_rgb, ctx.S, ctx.clamp_eps, ctx.needs_input_grad[2], ctx.needs_input_grad[3])
+        normal, rough, points, irr, cam, shift, Ls, dw = ctx.saved_tensors
+        d_a, d_r = spec_backward_raw(normal, rough, points, irr, cam, shift, Ls, d_rgb, ctx.S, ctx.clamp_eps, ctx.needs_input_grad[2], ctx.needs_input_grad[3], dw)
         return None, None, d_a, d_r, None, None, None, None, None, None, None
+
+
+# A/B switch (TEXIR_SPEC_TRAIN_FORM=0: the backward recomputes the sample chain, texir_spec_backward -- the round-3 form)
+_TRAIN_FORM = [__import__("os").environ.get("TEXIR_SPEC_TRAIN_FORM", "1") != "0"]
 
 
 def spec_shift_arg(shift, P, dev):

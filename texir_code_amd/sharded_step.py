@@ -56,7 +56,8 @@ class ShardedMatStep:
               "rough": flat(r_full, 1)[p0:p1].reshape(-1).contiguous(), "points": flat(gb["_points"], 3)[p0:p1].contiguous(),
               "irr": flat(irr, 3)[p0:p1].contiguous(), "cam": st["cam"].to(torch.float32).reshape(3).contiguous(),
               "shift": spec_shift_arg(st["shift"][p0:p1], p1 - p0, st["gt"].device)}
-        rgb_slice, sl["Ls"] = spec_forward_raw(m.scene, sl["normal"], sl["albedo"], sl["rough"], sl["points"], sl["irr"], sl["cam"], sl["shift"], int(m.sample_l[1]))
+        rgb_slice, sl["Ls"], sl["dw"] = spec_forward_raw(m.scene, sl["normal"], sl["albedo"], sl["rough"], sl["points"], sl["irr"], sl["cam"], sl["shift"], int(m.sample_l[1]),
+                                                         want_dw=bool(m.materials_r.requires_grad))
         st["slice"] = sl
         st["send1"][: p1 - p0].copy_(rgb_slice)
 
@@ -80,7 +81,7 @@ class ShardedMatStep:
         # backward of the slice's specular term (stage 1 renders on the detached albedo: no albedo gradient)
         sl = st["slice"]
         d_a, d_r = spec_backward_raw(sl["normal"], sl["rough"], sl["points"], sl["irr"], sl["cam"], sl["shift"], sl["Ls"], got[0][p0:p1], int(m.sample_l[1]),
-                                     need_albedo=(stage == 2 and m.materials_a.requires_grad), need_rough=m.materials_r.requires_grad)
+                                     need_albedo=(stage == 2 and m.materials_a.requires_grad), need_rough=m.materials_r.requires_grad, dw=sl["dw"])
         s2 = st["send2"]
         s2.zero_()
         if d_a is not None:
