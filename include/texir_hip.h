@@ -272,7 +272,9 @@ TEXIR_API int texir_adam_step_tex(float* param, const float* grad /*nullable: le
  * and betas of up to 64 parameters live in device memory (`state` [n][4] doubles: step count, lr, beta1, beta2).  texir_adam_tick
  * advances the step count of the records selected by `mask` (bit i = record i) and writes hyper[i] = (lr / (1 - beta1^step),
  * sqrt(1 - beta2^step)) in double precision, the expressions of torch.optim.Adam's single-tensor path; the *_dev steps read their
- * record's pair instead of taking (lr, step).  A learning-rate scheduler writes state[i][1] between steps. */
+ * record's pair instead of taking (lr, step).  A learning-rate scheduler writes state[i][1] between steps.
+ * texir_adam_step_tex_dev: grad_level1 may be NULL when grad_level2 is given and no tap of the view's lists touches mip level 1 (its direct
+ * gradient is identically zero: the level-1 stack -- a quarter of the texture -- is then not read at all). */
 TEXIR_API int texir_adam_tick(double* state /*dev [n][4]*/, float* hyper /*dev [n][2]*/, int32_t n_records, uint64_t mask, void* stream);
 TEXIR_API int texir_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper /*dev [2]*/,
                        float beta1, float beta2, float eps, float clamp_lo, float clamp_hi, void* stream);

@@ -211,3 +211,38 @@ def test_load_state_dict_keeps_the_buffers_captured_graphs_point_to(golden):
     for got, ref in zip((m.materials_a, m.materials_r), want):
         assert torch.equal(got.detach(), ref)
     assert int(opt.state[m.materials_a]["step"]) == 4
+
+
+def test_level1_stack_is_not_read_when_no_tap_touches_level1(tx):
+    """round 4: a view whose taps start at mip level >= 2 leaves the parked level-1 gradient stack all zeros; FusedAdam then passes NULL for it
+    (the kernel's read of a quarter of the texture disappears) -- same bits as reading the zeros, and a view that DOES touch level 1 keeps the read"""
+    from oracle import ref_torch as RT
+    from texir_code_amd.optim import FusedAdam
+    from texir_code_amd.texture import texture
+    torch.manual_seed(8)
+    t0 = torch.rand(128, 128, 3)
+    for coarse in (True, False):
+        uv, da, w = _fetch_args(700, 5)
+        da = da.abs() * (40.0 if coarse else 1.0) + (0.08 if coarse else 0.0)         # footprints of >= 4 texels: levels >= 2 only
+        res = []
+        for skip in (True, False):
+            p = torch.nn.Parameter(t0.clone().cuda())
+            opt = FusedAdam([p], lr=3e-2, fuse_mip_fold=True)
+            cache = {}
+            for _ in range(3):
+                opt.zero_grad()
+                (texture(p, uv, da, "linear-mipmap-linear", 13, cache=cache) * w).sum().backward()
+                flagged = bool(getattr(p, "_texir_l1_zero", False))
+                if not skip:
+                    p._texir_l1_zero = False                                          # force the read of the (all-zero) stack
+                opt.step()
+            res.append((p.detach().clone(), flagged))
+        assert res[0][1] == coarse, (coarse, res[0][1])
+        assert torch.equal(res[0][0], res[1][0])
+        a = torch.nn.Parameter(t0.clone())
+        oa = torch.optim.Adam([a], lr=3e-2)
+        for _ in range(3):
+            oa.zero_grad()
+            (RT.texture(a, uv.cpu(), da.cpu(), "linear-mipmap-linear", 13) * w.cpu()).sum().backward()
+            oa.step()
+        assert rel_l2(res[0][0].cpu().numpy(), a.detach().numpy()) < 1e-5

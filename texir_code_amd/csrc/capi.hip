@@ -480,7 +480,7 @@ int texir_adam_step_tex_dev(float* param, const float* grad, const uint32_t* gra
                             float* exp_avg_sq, float* mip_level1, int32_t H, int32_t W, int32_t C, const float* hyper, float beta1, float beta2, float eps,
                             float clamp_lo, float clamp_hi, void* stream)
 {
-    if (!param || !grad_level1 || !exp_avg || !exp_avg_sq || !hyper) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex_dev: null argument");
+    if (!param || (!grad_level1 && !grad_level2) || !exp_avg || !exp_avg_sq || !hyper) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex_dev: null argument");
     if (H < 2 || W < 2 || (H & 1) || (W & 1) || C < 1 || C > 4) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex_dev: bad H/W/C");
     if (grad_level2 && ((H & 3) || (W & 3))) return fail(TEXIR_ERR_INVALID, "texir_adam_step_tex_dev: a level-2 gradient needs H and W divisible by 4");
     HIP_TRY(launch_adam_tex(param, grad, grad_mask, grad_level1, grad_level2, exp_avg, exp_avg_sq, mip_level1, H, W, C, 0.f, beta1, beta2, eps, 1, clamp_lo, clamp_hi, hyper,

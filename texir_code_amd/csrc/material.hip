@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256) void adam_tex_kernel(float* __restrict__ p, co
     const int bx = t / C, ch = t - bx * C;
     const int e0 = bx * 2 * C + ch;
     for (int by = blockIdx.y; by < Hh; by += gridDim.y) {
-        float g1c = g1[(size_t)by * Wh * C + t];
+        float g1c = g1 ? g1[(size_t)by * Wh * C + t] : 0.f;          // (g1 == nullptr: no tap of the view touches level 1, its direct gradient is identically zero)
         if (g2) g1c = __builtin_fmaf(0.25f, g2[((size_t)(by >> 1) * (Wh >> 1) + (bx >> 1)) * C + ch], g1c);      // the fold level 2 -> level 1, taken over as well
         float acc = 0.f;
 #pragma unroll
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256) void adam_tex_vec_kernel(float* __restrict__ p
     const int h_base = e_base / 2, n_half = n_here / 2;              // this block's segment of the half-resolution row
     for (int by = blockIdx.y; by < Hh; by += gridDim.y) {
         for (int k = threadIdx.x; k < n_half; k += 256) {
-            float x = g1[(size_t)by * Wh * C + h_base + k];
+            float x = g1 ? g1[(size_t)by * Wh * C + h_base + k] : 0.f;      // (g1 == nullptr: level-1 direct gradient identically zero -- not read)
             if (g2) {                                               // the fold level 2 -> level 1, taken over as well (same fma as mip_pyr_fold_kernel's)
                 const int txh = (h_base + k) / C, ch = (h_base + k) - txh * C;
                 x = __builtin_fmaf(0.25f, g2[((size_t)(by >> 1) * (Wh >> 1) + (txh >> 1)) * C + ch], x);

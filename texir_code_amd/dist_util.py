@@ -106,6 +106,7 @@ def reduce_texture_grads(params):
             if getattr(p, "_texir_grad_l1", None) is None:
                 p._texir_grad_l1 = zeros(0, e1)
             dist.all_reduce(p._texir_grad_l1)
+            p._texir_l1_zero = False            # (another rank's view may have written level 1: the summed stack must be read)
             if n2 > 0:                         # (the fold level 2 -> 1 is left to the optimiser step as well: both parts are linear in the ranks' sums)
                 dist.all_reduce(p._texir_grad_l2)
         if n0 > 0:

@@ -104,7 +104,8 @@ class GraphedMatStep:
         # during this capture (a level-0 gradient, when the view samples level 0) is remembered per graph and re-attached to the
         # parameters before every optimiser step.
         self.grads[(key, stage)] = [(p.grad, getattr(p, "_texir_grad_l1", None), getattr(p, "_texir_l0_touched", True),
-                                     getattr(p, "_texir_l0_mask", None), getattr(p, "_texir_l0_sparse", False), getattr(p, "_texir_grad_l2", None))
+                                     getattr(p, "_texir_l0_mask", None), getattr(p, "_texir_l0_sparse", False), getattr(p, "_texir_grad_l2", None),
+                                     getattr(p, "_texir_l1_zero", False))
                                     for p in self.params]
         self.graphs[(key, stage)] = g
         self.stepped[(key, stage)] = list(getattr(self, "_stepping", [])) if self.step_in_graph else None
@@ -176,10 +177,11 @@ class GraphedMatStep:
         if self.stepped[(key, stage)] is not None:
             self.opt.note_replayed_step(self.stepped[(key, stage)])      # the replay contained the optimiser step
             return self.losses[(key, stage)]
-        for p, (g, g1, l0, mask, sparse, g2) in zip(self.params, self.grads[(key, stage)]):
+        for p, (g, g1, l0, mask, sparse, g2, l1z) in zip(self.params, self.grads[(key, stage)]):
             p.grad = g
             p._texir_grad_l1 = g1
             p._texir_grad_l2 = g2
+            p._texir_l1_zero = l1z
             p._texir_l0_touched = l0
             p._texir_l0_mask = mask
             p._texir_l0_sparse = sparse

@@ -149,6 +149,7 @@ class FusedAdam(torch.optim.Optimizer):
                 p._texir_l0_touched = False
                 p._texir_l0_mask = None
                 p._texir_l0_sparse = False
+                p._texir_l1_zero = False
         super().zero_grad(set_to_none=set_to_none)
 
     def release(self):
@@ -246,7 +247,9 @@ class FusedAdam(torch.optim.Optimizer):
                 # level 1 of the next forward's mip stack is written on the way (texture._mips_for then builds levels 2.. only)
                 mips = getattr(p, "_texir_mips", None)
                 mip1 = mips[1] if (mips is not None and mips[1].numel() >= (H // 2) * (W // 2) * C and mips[1].device == p.device) else None
-                _lib.check(L.texir_adam_step_tex_dev(_lib.ptr(p), _lib.ptr(g), _lib.ptr(mask), _lib.ptr(g1), _lib.ptr(getattr(p, "_texir_grad_l2", None)),
+                g2 = getattr(p, "_texir_grad_l2", None)
+                g1_read = None if (g2 is not None and getattr(p, "_texir_l1_zero", False)) else g1      # (all zeros: not read, texture.py backward)
+                _lib.check(L.texir_adam_step_tex_dev(_lib.ptr(p), _lib.ptr(g), _lib.ptr(mask), _lib.ptr(g1_read), _lib.ptr(g2),
                                                      _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]), _lib.ptr(mip1), H, W, C, _lib.ptr(hyper),
                                                      float(b1), float(b2), float(group["eps"]), lo, hi, _lib.stream_ptr()))
                 # one-shot: the next mip build of this parameter may start from level 1 (texture._mips_for consumes the flag)

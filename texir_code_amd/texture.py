@@ -114,8 +114,12 @@ def _tap_lists(cache, H, W, C, levels, mode, uv, uv_da):
         w = (touched.view(-1, 32).to(torch.int64) << torch.arange(32, device=uv.device, dtype=torch.int64)).sum(1)
         l0_mask = (w & 0xFFFFFFFF).to(torch.int64)
         l0_mask = torch.where(l0_mask >= 2 ** 31, l0_mask - 2 ** 32, l0_mask).to(torch.int32).contiguous()
+    # does any tap of these lists write mip level 1 (keys [H*W, H*W + (H/2)(W/2)): level 1 leads the `rest` stack)?  When none does, the level-1 gradient
+    # consists of what the fold from level 2 brings and the fused optimiser need not read the level-1 stack at all
+    n0, n1 = H * W, (H // 2) * (W // 2)
+    has_l1 = bool(((seg_key >= n0) & (seg_key < n0 + n1)).any().item()) if levels > 1 else False
     hit = (seg_key.contiguous(), starts.contiguous(), counts.to(torch.int32).contiguous(), (order // 8).to(torch.int32).contiguous(),
-           wts[order].contiguous(), has_l0, l0_mask)
+           wts[order].contiguous(), has_l0, l0_mask, has_l1)
     cache[key] = hit
     nbytes = sum(t.numel() * t.element_size() for t in hit[:5]) + (0 if l0_mask is None else l0_mask.numel() * 4)
     _tap_bytes += nbytes
@@ -227,6 +231,9 @@ class _TexFetch(torch.autograd.Function):
             n1 = (H // 2) * (W // 2) * C
             owner._texir_grad_l1 = g_rest[:n1]
             owner._texir_grad_l2 = g_rest[n1:n1 + (H // 4) * (W // 4) * C] if defer_levels == 2 else None
+            # level 1 untouched by this view's taps and the fold 2 -> 1 left to the optimiser: the parked level-1 stack is all zeros (the arena fill) and
+            # FusedAdam.step passes NULL for it (the stack stays parked as the marker of a deferred gradient)
+            owner._texir_l1_zero = bool(defer_levels == 2 and ctx.taps is not None and not ctx.taps[7])
         if owner is not None:
             # does the level-0 gradient of this parameter hold anything at all after this backward pass?  A deferred fetch none of whose
             # pixels samples level 0 leaves d_tex all zero (the multi-GPU reduction can then skip it); any other fetch of the parameter
