@@ -79,3 +79,14 @@ def test_fused_adam_groups_are_fixed_at_construction():
     assert len(opt.param_groups) == 2 and opt.param_groups[1]["lr"] == 1e-2
     with pytest.raises(TexirError, match="fixed at construction"):
         opt.add_param_group({"params": [torch.nn.Parameter(torch.zeros(2))]})
+
+
+def test_cpu_baseline_reports_the_cpus_it_may_really_use():
+    """the baseline line states affinity, cgroup quota and the thread count derived from them (the round-3 line said "256 cores" on a
+    box whose cgroup allowed 16), and the parts-per-texel helper of the footprint figure follows the launcher's rule (kernels.hip irt_plan)"""
+    import bench
+    h = bench.host_cpus()
+    assert 1 <= h["usable"] <= h["affinity"] <= (h["os_cpu_count"] or h["affinity"])
+    if h["cgroup_cpus"] is not None:
+        assert h["usable"] <= int(h["cgroup_cpus"]) + 1
+    assert [bench.irt_plan_parts(n) for n in (2048, 1024, 256, 64, 16, 8, 100)] == [32, 32, 32, 8, 2, 1, 1]

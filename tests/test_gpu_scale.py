@@ -78,7 +78,7 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert fp["replicated_scene_bytes"] > 0 and fp["irt_scratch_bytes"] >= 0 and fp["texel_gbuffers_bytes"] > 0
     # the material leg of the N > 1 line: one view per rank per optimiser step, texture gradients summed over the ranks
     m = d["material_step"]
-    assert m["views_per_step"] == 2 and m["ms"] > 0 and m["ms_per_view"] == round(m["ms"] / 2, 3)
+    assert m["views_per_step"] == 2 and m["ms"] > 0 and abs(m["ms_per_view"] - m["ms"] / 2) < 2e-3
 
 
 def test_pixel_sharded_material_step_is_the_single_gpu_step_bit_for_bit(tmp_path):
