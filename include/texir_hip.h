@@ -282,6 +282,59 @@ TEXIR_API int texir_adam_step_tex_dev(float* param, const float* grad, const uin
                        float* exp_avg, float* exp_avg_sq, float* mip_level1, int32_t H, int32_t W, int32_t C, const float* hyper /*dev [2]*/,
                        float beta1, float beta2, float eps, float clamp_lo, float clamp_hi, void* stream);
 
+/* ---- batched forms of the texture-side launches of one material step (trainer/train_material.py:408-458: the reference fetches its albedo and roughness
+ * textures with separate dr.texture calls, models/mat_nvdiffrast.py:131-139, and steps them with one torch.optim.Adam) --------------------------------------
+ * A step over k material textures launches k x (mip build + tail, fetch, gather, fold, Adam); these entry points take up to TEXIR_MAX_BATCH jobs and issue ONE
+ * launch per kind (blocks are dealt to the jobs by block index; every job keeps its own sizes and channel count).  Each job's result is bit-identical to the
+ * corresponding single-texture entry point above.  Errors of these three functions are reported through texir_batch_last_error() (thread-local). */
+#define TEXIR_MAX_BATCH 4
+TEXIR_API const char* texir_batch_last_error(void);
+
+/* texir_mip_build (when build_from >= 0) followed by texir_tex_fetch_forward, for every job: one pyramid launch, one tail launch, one fetch launch */
+typedef struct texir_tex_fetch_job {
+    const float* tex;          /* dev [H,W,C] */
+    float* mips_rest;          /* dev: levels 1.. (texir_mip_elems floats); nullable when levels == 1 */
+    int32_t H, W, C, levels;
+    int32_t build_from;        /* -1: the stack is valid as it is; 0: build levels 1.. from tex; 1: level 1 is valid (texir_adam_step_tex wrote it), build levels 2.. */
+    int32_t filter_mode;       /* 0 bilinear | 1 trilinear */
+    const float* uv;           /* dev [P,2] */
+    const float* uv_da;        /* dev [P,4]; nullable for mode 0 */
+    int64_t P;
+    float* out;                /* dev [P,C] */
+} texir_tex_fetch_job;
+TEXIR_API int texir_tex_fetch_forward_batch(const texir_tex_fetch_job* jobs /*host*/, int32_t n_jobs, void* stream);
+
+/* texir_tex_gather_backward for every job: one gather launch, one fold launch.
+ * rest_mask (nullable; needs defer_last_fold = 2): one bit per texel of grad_rest (bit t & 31 of word t >> 5; t = the key of texir_tex_taps minus H*W), set for
+ * exactly the texels the job's tap lists name.  With it grad_rest need NOT be zero on entry and is never cleared: the folds read the levels above 2 through the
+ * mask (an unset texel counts as zero) and WRITE level 2; level 1 is left as the gather wrote it, valid where the mask says so --
+ * texir_adam_step_tex_dev_batch(level1_mask = the same mask) reads it accordingly.  The per-step fill of the gradient stacks (a third of the texture) and the
+ * optimiser's dense read of the level-1 stack (a quarter) disappear; same floats as with a zero-filled stack. */
+typedef struct texir_tex_gather_job {
+    float* d_tex;              /* dev [H,W,C]; nullable as in texir_tex_gather_backward */
+    float* grad_rest;          /* dev */
+    int32_t H, W, C, levels;
+    const int64_t* seg_key; const int32_t* seg_start; const int32_t* seg_count; int32_t n_seg;
+    const int32_t* pix; const float* weights;
+    const float* d_out;        /* dev [P,C] */
+    int32_t filter_mode, defer_last_fold;
+    const uint32_t* rest_mask; /* dev, nullable */
+} texir_tex_gather_job;
+TEXIR_API int texir_tex_gather_backward_batch(const texir_tex_gather_job* jobs /*host*/, int32_t n_jobs, void* stream);
+
+/* texir_adam_step_tex_dev for every job in one launch */
+typedef struct texir_adam_tex_job {
+    float* param; const float* grad; const uint32_t* grad_mask;
+    const float* grad_level1;
+    const uint32_t* level1_mask;   /* dev, nullable; only with grad_level2: grad_level1 is valid -- and read -- only where the bit of its texel is set (see above) */
+    const float* grad_level2;
+    float* exp_avg; float* exp_avg_sq; float* mip_level1;
+    int32_t H, W, C;
+    const float* hyper;            /* dev [2] (texir_adam_tick) */
+    float beta1, beta2, eps, clamp_lo, clamp_hi;
+} texir_adam_tex_job;
+TEXIR_API int texir_adam_step_tex_dev_batch(const texir_adam_tex_job* jobs /*host*/, int32_t n_jobs, void* stream);
+
 /* ---- host-side codec loops of the file formats around the path (both take HOST pointers) ----------------------------
  * PNG scanline un-filtering (filters 0-4, PNG spec 9.2) of zlib-inflated IDAT data: raw [H][stride+1] -> out [H][stride]; replaces the
  * decode half of cv2.imread("0.png", -1) (models/tracer_o3d_irt.py:91, datasets/dataset.py:489-492). */

@@ -70,6 +70,10 @@ def lib():
         sig["texir_adam_tick"] = [vp, vp, i32, C.c_uint64, vp]
         sig["texir_adam_step_dev"] = [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, vp]
         sig["texir_adam_step_tex_dev"] = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, f32, f32, f32, f32, f32, vp]
+        L.texir_batch_last_error.restype = C.c_char_p
+        sig["texir_tex_fetch_forward_batch"] = [vp, i32, vp]
+        sig["texir_tex_gather_backward_batch"] = [vp, i32, vp]
+        sig["texir_adam_step_tex_dev_batch"] = [vp, i32, vp]
         L.texir_reload_env.argtypes = []
         L.texir_reload_env.restype = i32
         L.texir_mip_levels.argtypes = [i32, i32, i32]
@@ -87,6 +91,47 @@ def lib():
             fn.restype = i32
         _LIB = L
     return _LIB
+
+
+class TexFetchJob(C.Structure):
+    """texir_tex_fetch_job (include/texir_hip.h)"""
+    _fields_ = [("tex", C.c_void_p), ("mips_rest", C.c_void_p), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("levels", C.c_int32),
+                ("build_from", C.c_int32), ("filter_mode", C.c_int32), ("uv", C.c_void_p), ("uv_da", C.c_void_p), ("P", C.c_int64), ("out", C.c_void_p)]
+
+
+class TexGatherJob(C.Structure):
+    """texir_tex_gather_job"""
+    _fields_ = [("d_tex", C.c_void_p), ("grad_rest", C.c_void_p), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("levels", C.c_int32),
+                ("seg_key", C.c_void_p), ("seg_start", C.c_void_p), ("seg_count", C.c_void_p), ("n_seg", C.c_int32), ("pix", C.c_void_p),
+                ("weights", C.c_void_p), ("d_out", C.c_void_p), ("filter_mode", C.c_int32), ("defer_last_fold", C.c_int32), ("rest_mask", C.c_void_p)]
+
+
+class AdamTexJob(C.Structure):
+    """texir_adam_tex_job"""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("grad_mask", C.c_void_p), ("grad_level1", C.c_void_p), ("level1_mask", C.c_void_p),
+                ("grad_level2", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("mip_level1", C.c_void_p),
+                ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("hyper", C.c_void_p),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("clamp_lo", C.c_float), ("clamp_hi", C.c_float)]
+
+
+MAX_BATCH = 4
+
+
+def addr(t):
+    """data pointer of a contiguous tensor as a plain int (ctypes Structure fields), or None"""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "tensor must be contiguous"
+    return t.data_ptr()
+
+
+def batch_call(name, jobs):
+    """one batched launch sequence (texir_*_batch) over a list of job structures"""
+    L = lib()
+    arr = (type(jobs[0]) * len(jobs))(*jobs)
+    rc = getattr(L, name)(arr, len(jobs), stream_ptr())
+    if rc != 0:
+        raise TexirError("libtexir_hip: %s (code %d)" % (L.texir_batch_last_error().decode(), rc))
 
 
 def reload_env():

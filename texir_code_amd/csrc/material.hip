@@ -11,8 +11,11 @@
 //   adam_kernel        torch.optim.Adam step fused with the trainer's post-step clamp (train_material.py:448-458).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
 #include <stdlib.h>
 
+#include "../../include/texir_hip.h"
 #include "device_common.h"
 #include "env.h"
 #include "kernels.h"
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256) void mip_down_kernel(const float* __restrict__
 }
 
 // all remaining (small) levels in one single-block launch: level l from level l-1, block barrier in between
-__global__ __launch_bounds__(1024) void mip_down_tail_kernel(float* __restrict__ rest, MipDesc d, int l_begin)
+__device__ __forceinline__ void mip_down_tail_body(float* __restrict__ rest, const MipDesc& d, int l_begin)
 {
     for (int l = l_begin; l < d.levels; l++) {
         const int Hd = d.H >> l, Wd = d.W >> l, C = d.C, Ws = Wd * 2;
@@ -210,6 +213,8 @@ __global__ __launch_bounds__(1024) void mip_down_tail_kernel(float* __restrict__
         __syncthreads();
     }
 }
+
+__global__ __launch_bounds__(1024) void mip_down_tail_kernel(float* __restrict__ rest, MipDesc d, int l_begin) { mip_down_tail_body(rest, d, l_begin); }
 
 // fold: grad[l-1][2y+a][2x+b] += 0.25 * grad[l][y][x].  One thread per FINE float (coalesced read-modify-write of the fine row),
 // rows from blockIdx.y, 32-bit index math with compile-time C.
@@ -244,12 +249,12 @@ __global__ __launch_bounds__(1024) void mip_fold_tail_kernel(float* __restrict__
 // descendants (levels s+1 .. s+5) through LDS; the levels above (at most 32^2 texels) are left to the single-block tail kernel.
 // Same arithmetic as one mip_down_kernel launch per level (0.25 * (((a + b) + c) + d)), so the stack is bit-identical.
 template <int C>
-__global__ __launch_bounds__(256) void mip_pyr_down_kernel(const float* __restrict__ src, float* __restrict__ rest, MipDesc d, int s, int n_out)
+__device__ __forceinline__ void mip_pyr_down_body(const float* __restrict__ src, float* __restrict__ rest, const MipDesc& d, int s, int n_out, int bid,
+                                                  float (*buf)[16 * 16 * C] /* LDS: 2 x 16*16*C floats */)
 {
-    __shared__ float buf[2][16 * 16 * C];
     const int Hs = d.H >> s, Ws = d.W >> s;
     const int tiles_x = (Ws + 31) / 32;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int ty = bid / tiles_x, tx = bid - ty * tiles_x;
     // level s+1: 16x16 outputs straight from global memory, one thread per output texel
     {
         const int oy = threadIdx.x >> 4, ox = threadIdx.x & 15;
@@ -281,18 +286,39 @@ __global__ __launch_bounds__(256) void mip_pyr_down_kernel(const float* __restri
     }
 }
 
+template <int C>
+__global__ __launch_bounds__(256) void mip_pyr_down_kernel(const float* __restrict__ src, float* __restrict__ rest, MipDesc d, int s, int n_out)
+{
+    __shared__ float buf[2][16 * 16 * C];
+    mip_pyr_down_body<C>(src, rest, d, s, n_out, blockIdx.x, buf);
+}
+
 // The folds of a whole gradient stack in one launch: level f (the finest one to fold INTO) += 0.25 * level f+1 += 0.25 * level f+2 ...
 // A block owns a 32x32 tile of level f.  It first walks its chain of ancestors down from the top level (one texel per level: the
 // same fused multiply-adds the level-by-level kernels perform on those texels), then folds its own sub-pyramid (levels f+5 .. f+1)
 // through LDS and finally read-modify-writes its tile of level f.  Only level f is written back: nothing reads the coarser
 // gradient levels afterwards.  Bit-identical to mip_fold_tail_kernel + one mip_fold_kernel launch per level.
+// `mask` (nullable): one bit per texel of the `rest` stack (bit t & 31 of word t >> 5, t = d.off[l] / C + y * W_l + x).  With a mask the stack is NEVER
+// cleared between steps: only the texels a view's tap lists wrote this step (their bit is set) hold values, every other texel counts as zero --
+// reads of levels f+1 .. top go through the mask, and level f itself is WRITTEN (own masked value + a quarter of the parent) instead of
+// read-modify-written.  Same floats as folding a zero-filled stack.
 template <int C>
-__global__ __launch_bounds__(256) void mip_pyr_fold_kernel(float* __restrict__ fine_base /* level f */, const float* __restrict__ rest, MipDesc d, int f)
+__device__ __forceinline__ float rest_read(const float* __restrict__ rest, const uint32_t* __restrict__ mask, int64_t off, int64_t texel, int c)
 {
-    __shared__ float buf[2][16 * 16 * C];
+    if (mask) {
+        const int64_t t = off / C + texel;
+        if (!((mask[t >> 5] >> (t & 31)) & 1u)) return 0.f;
+    }
+    return rest[off + texel * C + c];
+}
+
+template <int C>
+__device__ __forceinline__ void mip_pyr_fold_body(float* __restrict__ fine_base /* level f */, const float* __restrict__ rest, const MipDesc& d, int f,
+                                                  const uint32_t* __restrict__ mask, int bid, float (*buf)[16 * 16 * C])
+{
     const int Hf = d.H >> f, Wf = d.W >> f;
     const int tiles_x = (Wf + 31) / 32;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int ty = bid / tiles_x, tx = bid - ty * tiles_x;
     const int top = d.levels - 1;
     const int K = min(5, top - f);                              // levels f+1 .. f+K live inside the tile
     // ancestors: levels top .. f+K (one texel each for this tile), folded from the top down by the first C threads
@@ -306,7 +332,7 @@ __global__ __launch_bounds__(256) void mip_pyr_fold_kernel(float* __restrict__ f
             gl[j] = 0.f;
             if (l >= f + 5) {
                 const int sh = l - f - 5;                       // tile coordinate -> texel of level l (tile = 32 texels of level f = 1 texel of level f+5)
-                gl[j] = rest[d.off[l] + ((size_t)(ty >> sh) * (d.W >> l) + (tx >> sh)) * C + c];
+                gl[j] = rest_read<C>(rest, mask, d.off[l], (int64_t)(ty >> sh) * (d.W >> l) + (tx >> sh), c);
             }
         }
         float acc = gl[0];
@@ -322,7 +348,7 @@ __global__ __launch_bounds__(256) void mip_pyr_fold_kernel(float* __restrict__ f
         for (int i = threadIdx.x; i < n * n * C; i += 256) {
             const int c = i % C, t = i / C, ox = t % n, oy = t / n;
             const int Y = ty * n + oy, X = tx * n + ox;
-            buf[1][i] = (Y < Hl && X < Wl) ? rest[d.off[f + K] + ((size_t)Y * Wl + X) * C + c] : 0.f;
+            buf[1][i] = (Y < Hl && X < Wl) ? rest_read<C>(rest, mask, d.off[f + K], (int64_t)Y * Wl + X, c) : 0.f;
         }
         cur = 1;
     }
@@ -333,21 +359,34 @@ __global__ __launch_bounds__(256) void mip_pyr_fold_kernel(float* __restrict__ f
             const int c = i % C, t = i / C, ox = t % n, oy = t / n;
             const int Y = ty * n + oy, X = tx * n + ox;
             float v = 0.f;
-            if (Y < Hl && X < Wl) v = __builtin_fmaf(0.25f, buf[cur][((oy >> 1) * (n >> 1) + (ox >> 1)) * C + c], rest[d.off[f + k] + ((size_t)Y * Wl + X) * C + c]);
+            if (Y < Hl && X < Wl) v = __builtin_fmaf(0.25f, buf[cur][((oy >> 1) * (n >> 1) + (ox >> 1)) * C + c], rest_read<C>(rest, mask, d.off[f + k], (int64_t)Y * Wl + X, c));
             buf[cur ^ 1][i] = v;
         }
         cur ^= 1;
     }
     __syncthreads();
-    // level f: 32x32 texels, read-modify-write (when K == 0 there is nothing above f: the launcher does not call us)
+    // level f: 32x32 texels, read-modify-write -- or, under a mask, a plain write (when K == 0 there is nothing above f: the launcher does not call us)
+    const bool masked_f = mask != nullptr && f >= 1;                    // (level 0 is not part of the `rest` stack: never masked)
     for (int i = threadIdx.x; i < 32 * 32 * C; i += 256) {
         const int c = i % C, t = i / C, ox = t & 31, oy = t >> 5;
         const int Y = ty * 32 + oy, X = tx * 32 + ox;
         if (Y < Hf && X < Wf) {
             float* o = fine_base + ((size_t)Y * Wf + X) * C + c;
-            *o = __builtin_fmaf(0.25f, buf[cur][((oy >> 1) * 16 + (ox >> 1)) * C + c], *o);
+            float own;
+            if (masked_f) {
+                const int64_t tt = d.off[f] / C + (int64_t)Y * Wf + X;
+                own = ((mask[tt >> 5] >> (tt & 31)) & 1u) ? *o : 0.f;
+            } else own = *o;
+            *o = __builtin_fmaf(0.25f, buf[cur][((oy >> 1) * 16 + (ox >> 1)) * C + c], own);
         }
     }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void mip_pyr_fold_kernel(float* __restrict__ fine_base /* level f */, const float* __restrict__ rest, MipDesc d, int f)
+{
+    __shared__ float buf[2][16 * 16 * C];
+    mip_pyr_fold_body<C>(fine_base, rest, d, f, nullptr, blockIdx.x, buf);
 }
 
 __device__ __forceinline__ float mip_level_from_da(float4 da, int W, int H, int maxl)
@@ -380,11 +419,11 @@ __device__ __forceinline__ Tap bilinear_wrap(float u, float v, int W, int H)
 }
 
 template <bool BWD>
-__global__ __launch_bounds__(256) void tex_fetch_kernel(float* __restrict__ lvl0, float* __restrict__ rest, MipDesc d, const float* __restrict__ uv,
-                                                        const float* __restrict__ uvda, int trilinear, int64_t P, float* __restrict__ io)
+__device__ __forceinline__ void tex_fetch_body(float* __restrict__ lvl0, float* __restrict__ rest, const MipDesc& d, const float* __restrict__ uv,
+                                               const float* __restrict__ uvda, int trilinear, int64_t P, float* __restrict__ io, int bid, int nb)
 {
     const int C = d.C;
-    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
+    for (int64_t p = (int64_t)bid * 256 + threadIdx.x; p < P; p += (int64_t)nb * 256) {
         const float u = uv[2 * p], v = uv[2 * p + 1];
         int l0 = 0, l1 = 0; float f = 0.f;
         if (trilinear && d.levels > 1) {
@@ -413,6 +452,13 @@ __global__ __launch_bounds__(256) void tex_fetch_kernel(float* __restrict__ lvl0
         }
         if (!BWD) for (int ch = 0; ch < C; ch++) io[(int64_t)C * p + ch] = out[ch];
     }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void tex_fetch_kernel(float* __restrict__ lvl0, float* __restrict__ rest, MipDesc d, const float* __restrict__ uv,
+                                                        const float* __restrict__ uvda, int trilinear, int64_t P, float* __restrict__ io)
+{
+    tex_fetch_body<BWD>(lvl0, rest, d, uv, uvda, trilinear, P, io, blockIdx.x, gridDim.x);
 }
 
 static int grid1d(int64_t n, int bs) { int64_t nb = (n + bs - 1) / bs; return (int)(nb > 4096 ? 4096 : (nb < 1 ? 1 : nb)); }
@@ -475,11 +521,11 @@ __global__ __launch_bounds__(256) void tex_taps_kernel(MipDesc d, const float* _
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void tex_gather_kernel(float* __restrict__ lvl0, float* __restrict__ rest, int64_t n0, const long long* __restrict__ seg_key,
-                                                         const int* __restrict__ seg_start, const int* __restrict__ seg_count, int n_seg,
-                                                         const int* __restrict__ pix, const float* __restrict__ w, const float* __restrict__ d_out)
+__device__ __forceinline__ void tex_gather_body(float* __restrict__ lvl0, float* __restrict__ rest, int64_t n0, const long long* __restrict__ seg_key,
+                                                const int* __restrict__ seg_start, const int* __restrict__ seg_count, int n_seg,
+                                                const int* __restrict__ pix, const float* __restrict__ w, const float* __restrict__ d_out, int bid, int nb)
 {
-    for (int s = blockIdx.x * 256 + threadIdx.x; s < n_seg; s += gridDim.x * 256) {
+    for (int s = bid * 256 + threadIdx.x; s < n_seg; s += nb * 256) {
         const long long key = seg_key[s];
         if (key < n0 && !lvl0) continue;                     // (caller passed no level-0 buffer: it promised that no list samples level 0)
         const int b = seg_start[s], e = b + seg_count[s];
@@ -507,6 +553,14 @@ __global__ __launch_bounds__(256) void tex_gather_kernel(float* __restrict__ lvl
         float* o = key < n0 ? lvl0 + key * C : rest + (key - n0) * C;
         for (int c = 0; c < C; c++) o[c] = acc[c];
     }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void tex_gather_kernel(float* __restrict__ lvl0, float* __restrict__ rest, int64_t n0, const long long* __restrict__ seg_key,
+                                                         const int* __restrict__ seg_start, const int* __restrict__ seg_count, int n_seg,
+                                                         const int* __restrict__ pix, const float* __restrict__ w, const float* __restrict__ d_out)
+{
+    tex_gather_body<C>(lvl0, rest, n0, seg_key, seg_start, seg_count, n_seg, pix, w, d_out, blockIdx.x, gridDim.x);
 }
 
 template <int C>
@@ -665,7 +719,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 template <int C>
 __global__ __launch_bounds__(256) void adam_tex_kernel(float* __restrict__ p, const float* __restrict__ g, const uint32_t* __restrict__ l0_mask,
                                                        const float* __restrict__ g1, const float* __restrict__ g2, float* __restrict__ m, float* __restrict__ v, float* __restrict__ mip1,
-                                                       int H, int W, float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float lo, float hi, const float* __restrict__ hyp)
+                                                       int H, int W, float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float lo, float hi, const float* __restrict__ hyp,
+                                                       const uint32_t* __restrict__ g1_mask /* nullable: see adam_tex_vec_body */)
 {
     if (hyp) { step_size = hyp[0]; bc2_sqrt = hyp[1]; }
     // one thread per (2x2 block column, channel): t = bx * C + ch.  Its level-1 element and its g1 element sit at index t of the
@@ -677,7 +732,12 @@ __global__ __launch_bounds__(256) void adam_tex_kernel(float* __restrict__ p, co
     const int bx = t / C, ch = t - bx * C;
     const int e0 = bx * 2 * C + ch;
     for (int by = blockIdx.y; by < Hh; by += gridDim.y) {
-        float g1c = g1 ? g1[(size_t)by * Wh * C + t] : 0.f;          // (g1 == nullptr: no tap of the view touches level 1, its direct gradient is identically zero)
+        float g1c = 0.f;                                             // (g1 == nullptr: no tap of the view touches level 1, its direct gradient is identically zero)
+        if (g1) {
+            bool has = true;
+            if (g1_mask) { const size_t tt = (size_t)by * Wh + bx; has = (g1_mask[tt >> 5] >> (tt & 31)) & 1u; }
+            if (has) g1c = g1[(size_t)by * Wh * C + t];
+        }
         if (g2) g1c = __builtin_fmaf(0.25f, g2[((size_t)(by >> 1) * (Wh >> 1) + (bx >> 1)) * C + ch], g1c);      // the fold level 2 -> level 1, taken over as well
         float acc = 0.f;
 #pragma unroll
@@ -711,28 +771,34 @@ constexpr int adam_vec_epb(int C) { return C == 3 ? 960 : (1024 / (2 * C)) * (2 
 // that no 2x2 texel block straddles two blocks), every thread one float4 of each row; the level-1 gradient segment and the updated
 // texels go through LDS so that the level-1 texels come out in the mip build's own summation order ((p00 + p01) + p10) + p11.
 // Needs W*C % 4 == 0 (16-byte aligned rows); launch_adam_tex falls back to adam_tex_kernel otherwise.  Identical bits.
+//   * g1_mask (nullable, only together with g2): the level-1 stack is a never-cleared buffer; its texels carry this step's values only where the view's tap
+//     lists wrote them (bit by * W/2 + x of the mask -- level 1 leads the `rest` stack, so this is the stack's own mask), all others count as zero and
+//     are not read.
 template <int C>
-__global__ __launch_bounds__(256) void adam_tex_vec_kernel(float* __restrict__ p, const float* __restrict__ g, const uint32_t* __restrict__ l0_mask,
-                                                           const float* __restrict__ g1, const float* __restrict__ g2, float* __restrict__ m, float* __restrict__ v, float* __restrict__ mip1,
-                                                           int H, int W, float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float lo, float hi, const float* __restrict__ hyp)
+__device__ __forceinline__ void adam_tex_vec_body(float* __restrict__ p, const float* __restrict__ g, const uint32_t* __restrict__ l0_mask,
+                                                  const float* __restrict__ g1, const uint32_t* __restrict__ g1_mask, const float* __restrict__ g2,
+                                                  float* __restrict__ m, float* __restrict__ v, float* __restrict__ mip1,
+                                                  int H, int W, float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float lo, float hi,
+                                                  int bx, int by0, int gy, float* __restrict__ g1s /* LDS [EPB / 2] */, float (*ps)[adam_vec_epb(C)] /* LDS [2][EPB] */)
 {
-    if (hyp) { step_size = hyp[0]; bc2_sqrt = hyp[1]; }
     constexpr int EPB = adam_vec_epb(C);
-    __shared__ float g1s[EPB / 2];
-    __shared__ float ps[2][EPB];
     const int row_elems = W * C, Wh = W >> 1, Hh = H >> 1;
-    const int e_base = blockIdx.x * EPB;
+    const int e_base = bx * EPB;
     const int n_here = min(EPB, row_elems - e_base);                 // multiple of 2C and of 4
     const int j4 = threadIdx.x * 4;
     const bool act = j4 < n_here;
     const int h_base = e_base / 2, n_half = n_here / 2;              // this block's segment of the half-resolution row
-    for (int by = blockIdx.y; by < Hh; by += gridDim.y) {
+    for (int by = by0; by < Hh; by += gy) {
         for (int k = threadIdx.x; k < n_half; k += 256) {
-            float x = g1 ? g1[(size_t)by * Wh * C + h_base + k] : 0.f;      // (g1 == nullptr: level-1 direct gradient identically zero -- not read)
-            if (g2) {                                               // the fold level 2 -> level 1, taken over as well (same fma as mip_pyr_fold_kernel's)
-                const int txh = (h_base + k) / C, ch = (h_base + k) - txh * C;
-                x = __builtin_fmaf(0.25f, g2[((size_t)(by >> 1) * (Wh >> 1) + (txh >> 1)) * C + ch], x);
+            const int txh = (h_base + k) / C, ch = (h_base + k) - txh * C;
+            float x = 0.f;                                          // (g1 == nullptr: level-1 direct gradient identically zero -- not read)
+            if (g1) {
+                bool has = true;
+                if (g1_mask) { const size_t t = (size_t)by * Wh + txh; has = (g1_mask[t >> 5] >> (t & 31)) & 1u; }
+                if (has) x = g1[(size_t)by * Wh * C + h_base + k];
             }
+            if (g2)                                                 // the fold level 2 -> level 1, taken over as well (same fma as mip_pyr_fold_kernel's)
+                x = __builtin_fmaf(0.25f, g2[((size_t)(by >> 1) * (Wh >> 1) + (txh >> 1)) * C + ch], x);
             g1s[k] = x;
         }
         __syncthreads();
@@ -773,6 +839,18 @@ __global__ __launch_bounds__(256) void adam_tex_vec_kernel(float* __restrict__ p
     }
 }
 
+template <int C>
+__global__ __launch_bounds__(256) void adam_tex_vec_kernel(float* __restrict__ p, const float* __restrict__ g, const uint32_t* __restrict__ l0_mask,
+                                                           const float* __restrict__ g1, const float* __restrict__ g2, float* __restrict__ m, float* __restrict__ v, float* __restrict__ mip1,
+                                                           int H, int W, float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float lo, float hi, const float* __restrict__ hyp)
+{
+    if (hyp) { step_size = hyp[0]; bc2_sqrt = hyp[1]; }
+    constexpr int EPB = adam_vec_epb(C);
+    __shared__ float g1s[EPB / 2];
+    __shared__ float ps[2][EPB];
+    adam_tex_vec_body<C>(p, g, l0_mask, g1, nullptr, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, blockIdx.x, blockIdx.y, gridDim.y, g1s, ps);
+}
+
 hipError_t launch_adam_tex(float* p, const float* g, const uint32_t* l0_mask, const float* g1, const float* g2, float* m, float* v, float* mip1, int H, int W, int C,
                            float lr, float beta1, float beta2, float eps, int step, float lo, float hi, const float* hyp, hipStream_t st)
 {
@@ -794,10 +872,10 @@ hipError_t launch_adam_tex(float* p, const float* g, const uint32_t* l0_mask, co
         return hipGetLastError();
     }
     dim3 grid(((W >> 1) * C + 255) / 256, (H >> 1) > 4096 ? 4096 : (H >> 1));
-    if (C == 1) hipLaunchKernelGGL(adam_tex_kernel<1>, grid, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp);
-    else if (C == 2) hipLaunchKernelGGL(adam_tex_kernel<2>, grid, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp);
-    else if (C == 3) hipLaunchKernelGGL(adam_tex_kernel<3>, grid, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp);
-    else hipLaunchKernelGGL(adam_tex_kernel<4>, grid, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp);
+    if (C == 1) hipLaunchKernelGGL(adam_tex_kernel<1>, grid, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp, (const uint32_t*)nullptr);
+    else if (C == 2) hipLaunchKernelGGL(adam_tex_kernel<2>, grid, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp, (const uint32_t*)nullptr);
+    else if (C == 3) hipLaunchKernelGGL(adam_tex_kernel<3>, grid, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp, (const uint32_t*)nullptr);
+    else hipLaunchKernelGGL(adam_tex_kernel<4>, grid, dim3(256), 0, st, p, g, l0_mask, g1, g2, m, v, mip1, H, W, beta1, beta2, eps, step_size, bc2_sqrt, lo, hi, hyp, (const uint32_t*)nullptr);
     return hipGetLastError();
 }
 
@@ -838,4 +916,293 @@ hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Batched launches (include/texir_hip.h, "batched forms"): one launch per KIND of kernel for up to TEXIR_MAX_BATCH textures.  A step over the
+// albedo and the roughness texture is latency-bound in these kernels (5 ... 20 us each, the launch-to-launch floor is ~4.7 us): dealing the
+// blocks of ONE grid to the jobs removes a launch per kind and lets the short jobs hide in the long ones' tails.  The job bodies are the
+// single-texture kernels' own (…_body above), so every job's result keeps its bits.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kMaxBatch = TEXIR_MAX_BATCH;
+
+struct PyrDownJob { const float* src; float* rest; MipDesc d; int s, n_out, first; };
+struct PyrDownBatch { int n; PyrDownJob j[kMaxBatch]; };
+struct TailJob { float* rest; MipDesc d; int l_begin; };
+struct TailBatch { int n; TailJob j[kMaxBatch]; };
+struct FetchJob { float* lvl0; float* rest; MipDesc d; const float* uv; const float* uvda; int trilinear; int64_t P; float* out; int first, nb; };
+struct FetchBatch { int n; FetchJob j[kMaxBatch]; };
+struct GatherJob { float* lvl0; float* rest; int64_t n0; const long long* seg_key; const int* seg_start; const int* seg_count; int n_seg; const int* pix; const float* w;
+                   const float* d_out; int C, first, nb; };
+struct GatherBatch { int n; GatherJob j[kMaxBatch]; };
+struct FoldJob { float* fine; const float* rest; MipDesc d; int f; const uint32_t* mask; int first; };
+struct FoldBatch { int n; FoldJob j[kMaxBatch]; };
+struct AdamTexJob { float* p; const float* g; const uint32_t* l0_mask; const float* g1; const uint32_t* g1_mask; const float* g2; float* m; float* v; float* mip1;
+                    int H, W, C; float beta1, beta2, eps, lo, hi; const float* hyp; int first, gy; };
+struct AdamTexBatch { int n; AdamTexJob j[kMaxBatch]; };
+
+// job of a block: jobs own consecutive block ranges [first, next job's first)
+template <class B>
+__device__ __forceinline__ int job_of_block(const B& b, int bid)
+{
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxBatch; i++) if (i < b.n && bid >= b.j[i].first) k = i;
+    return k;
+}
+
+__global__ __launch_bounds__(256) void mip_pyr_down_batch_kernel(PyrDownBatch b)
+{
+    __shared__ float smem[2 * 16 * 16 * 4];
+    const PyrDownJob& J = b.j[job_of_block(b, blockIdx.x)];
+    const int bid = blockIdx.x - J.first;
+    switch (J.d.C) {
+        case 1: mip_pyr_down_body<1>(J.src, J.rest, J.d, J.s, J.n_out, bid, reinterpret_cast<float (*)[16 * 16 * 1]>(smem)); break;
+        case 2: mip_pyr_down_body<2>(J.src, J.rest, J.d, J.s, J.n_out, bid, reinterpret_cast<float (*)[16 * 16 * 2]>(smem)); break;
+        case 3: mip_pyr_down_body<3>(J.src, J.rest, J.d, J.s, J.n_out, bid, reinterpret_cast<float (*)[16 * 16 * 3]>(smem)); break;
+        default: mip_pyr_down_body<4>(J.src, J.rest, J.d, J.s, J.n_out, bid, reinterpret_cast<float (*)[16 * 16 * 4]>(smem)); break;
+    }
+}
+
+__global__ __launch_bounds__(1024) void mip_down_tail_batch_kernel(TailBatch b)
+{
+    const TailJob& J = b.j[blockIdx.x];
+    mip_down_tail_body(J.rest, J.d, J.l_begin);
+}
+
+__global__ __launch_bounds__(256) void tex_fetch_batch_kernel(FetchBatch b)
+{
+    const FetchJob& J = b.j[job_of_block(b, blockIdx.x)];
+    tex_fetch_body<false>(J.lvl0, J.rest, J.d, J.uv, J.uvda, J.trilinear, J.P, J.out, blockIdx.x - J.first, J.nb);
+}
+
+__global__ __launch_bounds__(256) void tex_gather_batch_kernel(GatherBatch b)
+{
+    const GatherJob& J = b.j[job_of_block(b, blockIdx.x)];
+    const int bid = blockIdx.x - J.first;
+    switch (J.C) {
+        case 1: tex_gather_body<1>(J.lvl0, J.rest, J.n0, J.seg_key, J.seg_start, J.seg_count, J.n_seg, J.pix, J.w, J.d_out, bid, J.nb); break;
+        case 2: tex_gather_body<2>(J.lvl0, J.rest, J.n0, J.seg_key, J.seg_start, J.seg_count, J.n_seg, J.pix, J.w, J.d_out, bid, J.nb); break;
+        case 3: tex_gather_body<3>(J.lvl0, J.rest, J.n0, J.seg_key, J.seg_start, J.seg_count, J.n_seg, J.pix, J.w, J.d_out, bid, J.nb); break;
+        default: tex_gather_body<4>(J.lvl0, J.rest, J.n0, J.seg_key, J.seg_start, J.seg_count, J.n_seg, J.pix, J.w, J.d_out, bid, J.nb); break;
+    }
+}
+
+__global__ __launch_bounds__(256) void mip_pyr_fold_batch_kernel(FoldBatch b)
+{
+    __shared__ float smem[2 * 16 * 16 * 4];
+    const FoldJob& J = b.j[job_of_block(b, blockIdx.x)];
+    const int bid = blockIdx.x - J.first;
+    switch (J.d.C) {
+        case 1: mip_pyr_fold_body<1>(J.fine, J.rest, J.d, J.f, J.mask, bid, reinterpret_cast<float (*)[16 * 16 * 1]>(smem)); break;
+        case 2: mip_pyr_fold_body<2>(J.fine, J.rest, J.d, J.f, J.mask, bid, reinterpret_cast<float (*)[16 * 16 * 2]>(smem)); break;
+        case 3: mip_pyr_fold_body<3>(J.fine, J.rest, J.d, J.f, J.mask, bid, reinterpret_cast<float (*)[16 * 16 * 3]>(smem)); break;
+        default: mip_pyr_fold_body<4>(J.fine, J.rest, J.d, J.f, J.mask, bid, reinterpret_cast<float (*)[16 * 16 * 4]>(smem)); break;
+    }
+}
+
+// grid.x = the jobs' row segments side by side, grid.y = the largest row-pair stride of the batch (a job with fewer rows leaves the surplus rows idle)
+__global__ __launch_bounds__(256) void adam_tex_vec_batch_kernel(AdamTexBatch b)
+{
+    __shared__ float g1s[512];
+    __shared__ float ps[2 * 1024];
+    const AdamTexJob& J = b.j[job_of_block(b, blockIdx.x)];
+    if ((int)blockIdx.y >= J.gy) return;
+    const float step_size = J.hyp[0], bc2_sqrt = J.hyp[1];
+    const int bx = blockIdx.x - J.first;
+    switch (J.C) {
+        case 1: adam_tex_vec_body<1>(J.p, J.g, J.l0_mask, J.g1, J.g1_mask, J.g2, J.m, J.v, J.mip1, J.H, J.W, J.beta1, J.beta2, J.eps, step_size, bc2_sqrt, J.lo, J.hi, bx, blockIdx.y, J.gy, g1s,
+                                     reinterpret_cast<float (*)[adam_vec_epb(1)]>(ps)); break;
+        case 2: adam_tex_vec_body<2>(J.p, J.g, J.l0_mask, J.g1, J.g1_mask, J.g2, J.m, J.v, J.mip1, J.H, J.W, J.beta1, J.beta2, J.eps, step_size, bc2_sqrt, J.lo, J.hi, bx, blockIdx.y, J.gy, g1s,
+                                     reinterpret_cast<float (*)[adam_vec_epb(2)]>(ps)); break;
+        case 3: adam_tex_vec_body<3>(J.p, J.g, J.l0_mask, J.g1, J.g1_mask, J.g2, J.m, J.v, J.mip1, J.H, J.W, J.beta1, J.beta2, J.eps, step_size, bc2_sqrt, J.lo, J.hi, bx, blockIdx.y, J.gy, g1s,
+                                     reinterpret_cast<float (*)[adam_vec_epb(3)]>(ps)); break;
+        default: adam_tex_vec_body<4>(J.p, J.g, J.l0_mask, J.g1, J.g1_mask, J.g2, J.m, J.v, J.mip1, J.H, J.W, J.beta1, J.beta2, J.eps, step_size, bc2_sqrt, J.lo, J.hi, bx, blockIdx.y, J.gy, g1s,
+                                      reinterpret_cast<float (*)[adam_vec_epb(4)]>(ps)); break;
+    }
+}
+
+static thread_local char g_batch_err[384];
+
+static int bfail(int code, const char* fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_batch_err, sizeof(g_batch_err), fmt, ap); va_end(ap);
+    return code;
+}
+
+static int bcheck_tex(const char* fn, int k, int H, int W, int C, int levels)
+{
+    if (H <= 0 || W <= 0 || C <= 0 || C > 4 || levels < 1 || levels > 16) return bfail(TEXIR_ERR_INVALID, "%s: job %d: bad texture H=%d W=%d C=%d levels=%d", fn, k, H, W, C, levels);
+    if (levels > mip_levels(H, W, 15)) return bfail(TEXIR_ERR_INVALID, "%s: job %d: %d mip levels not available for %dx%d", fn, k, levels, H, W);
+    return 0;
+}
+
+#define BATCH_HIP_TRY(fn, expr)                                                                              \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) return bfail(TEXIR_ERR_HIP, "%s: %s failed: %s", fn, #expr, hipGetErrorString(e_)); \
+    } while (0)
+
 }  // namespace texir
+
+using namespace texir;
+
+extern "C" {
+
+const char* texir_batch_last_error(void) { return g_batch_err; }
+
+int texir_tex_fetch_forward_batch(const texir_tex_fetch_job* jobs, int32_t n, void* stream)
+{
+    const char* fn = "texir_tex_fetch_forward_batch";
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 0 || n > kMaxBatch || (n > 0 && !jobs)) return bfail(TEXIR_ERR_INVALID, "%s: 0..%d jobs (got %d)", fn, kMaxBatch, n);
+    for (int k = 0; k < n; k++) {
+        const texir_tex_fetch_job& q = jobs[k];
+        if (!q.tex || (q.P > 0 && (!q.uv || !q.out || (q.filter_mode == 1 && !q.uv_da))) || (q.filter_mode == 1 && q.levels > 1 && !q.mips_rest))
+            return bfail(TEXIR_ERR_INVALID, "%s: job %d: null argument", fn, k);
+        if (q.filter_mode < 0 || q.filter_mode > 1 || q.P < 0 || q.build_from < -1 || q.build_from > 1) return bfail(TEXIR_ERR_INVALID, "%s: job %d: bad filter_mode/P/build_from", fn, k);
+        if (q.build_from >= 0 && q.levels > 1 && !q.mips_rest) return bfail(TEXIR_ERR_INVALID, "%s: job %d: a build needs mips_rest", fn, k);
+        if (int rc = bcheck_tex(fn, k, q.H, q.W, q.C, q.levels)) return rc;
+    }
+    if (n == 0) return TEXIR_OK;
+    // the reference form (one launch per level, TEXIR_MIP_PER_LEVEL=1) stays a sequence of single launches
+    if (env().mip_per_level || n == 1) {
+        for (int k = 0; k < n; k++) {
+            const texir_tex_fetch_job& q = jobs[k];
+            if (q.build_from >= 0) BATCH_HIP_TRY(fn, launch_mip_build(q.tex, q.mips_rest, q.H, q.W, q.C, q.levels, q.build_from, st));
+        }
+        for (int k = 0; k < n; k++) {
+            const texir_tex_fetch_job& q = jobs[k];
+            if (q.P > 0) BATCH_HIP_TRY(fn, launch_tex_fetch(q.tex, q.mips_rest, q.H, q.W, q.C, q.levels, q.uv, q.uv_da, q.filter_mode, q.P, q.out, st));
+        }
+        return TEXIR_OK;
+    }
+    PyrDownBatch pb; pb.n = 0;
+    TailBatch tb; tb.n = 0;
+    int blocks = 0;
+    for (int k = 0; k < n; k++) {
+        const texir_tex_fetch_job& q = jobs[k];
+        if (q.build_from < 0 || q.levels <= 1 + q.build_from) continue;
+        MipDesc d = make_desc(q.H, q.W, q.C, q.levels);
+        const int s_lvl = q.build_from;
+        const int n_out = (q.levels - 1 - s_lvl) < 5 ? (q.levels - 1 - s_lvl) : 5;
+        PyrDownJob& J = pb.j[pb.n++];
+        J.src = s_lvl == 0 ? q.tex : q.mips_rest + d.off[s_lvl]; J.rest = q.mips_rest; J.d = d; J.s = s_lvl; J.n_out = n_out; J.first = blocks;
+        blocks += (((q.H >> s_lvl) + 31) / 32) * (((q.W >> s_lvl) + 31) / 32);
+        const int lt = s_lvl + n_out + 1;
+        if (lt < q.levels) { TailJob& T = tb.j[tb.n++]; T.rest = q.mips_rest; T.d = d; T.l_begin = lt; }
+    }
+    if (pb.n > 0) hipLaunchKernelGGL(mip_pyr_down_batch_kernel, dim3(blocks), dim3(256), 0, st, pb);
+    if (tb.n > 0) hipLaunchKernelGGL(mip_down_tail_batch_kernel, dim3(tb.n), dim3(1024), 0, st, tb);
+    FetchBatch fb; fb.n = 0;
+    blocks = 0;
+    for (int k = 0; k < n; k++) {
+        const texir_tex_fetch_job& q = jobs[k];
+        if (q.P <= 0) continue;
+        FetchJob& J = fb.j[fb.n++];
+        J.lvl0 = const_cast<float*>(q.tex); J.rest = q.mips_rest; J.d = make_desc(q.H, q.W, q.C, q.levels); J.uv = q.uv; J.uvda = q.uv_da; J.trilinear = q.filter_mode; J.P = q.P; J.out = q.out;
+        J.first = blocks; J.nb = grid1d(q.P, 256);
+        blocks += J.nb;
+    }
+    if (fb.n > 0) hipLaunchKernelGGL(tex_fetch_batch_kernel, dim3(blocks), dim3(256), 0, st, fb);
+    BATCH_HIP_TRY(fn, hipGetLastError());
+    return TEXIR_OK;
+}
+
+int texir_tex_gather_backward_batch(const texir_tex_gather_job* jobs, int32_t n, void* stream)
+{
+    const char* fn = "texir_tex_gather_backward_batch";
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 0 || n > kMaxBatch || (n > 0 && !jobs)) return bfail(TEXIR_ERR_INVALID, "%s: 0..%d jobs (got %d)", fn, kMaxBatch, n);
+    for (int k = 0; k < n; k++) {
+        const texir_tex_gather_job& q = jobs[k];
+        if ((!q.d_tex && !q.defer_last_fold) || !q.d_out || (q.n_seg > 0 && (!q.seg_key || !q.seg_start || !q.seg_count || !q.pix || !q.weights)) || (q.filter_mode == 1 && q.levels > 1 && !q.grad_rest))
+            return bfail(TEXIR_ERR_INVALID, "%s: job %d: null argument", fn, k);
+        if (q.filter_mode < 0 || q.filter_mode > 1 || q.n_seg < 0 || q.defer_last_fold < 0 || q.defer_last_fold > 2 || (q.defer_last_fold && (q.filter_mode != 1 || q.levels < 2))
+            || (q.defer_last_fold == 2 && (q.levels < 4 || (q.H & 3) || (q.W & 3))))
+            return bfail(TEXIR_ERR_INVALID, "%s: job %d: bad filter_mode/n_seg/defer_last_fold", fn, k);
+        if (q.rest_mask && q.defer_last_fold != 2) return bfail(TEXIR_ERR_INVALID, "%s: job %d: rest_mask needs defer_last_fold = 2", fn, k);
+        if (q.rest_mask && env().mip_per_level) return bfail(TEXIR_ERR_INVALID, "%s: job %d: rest_mask is not available with TEXIR_MIP_PER_LEVEL=1 (the per-level folds read a cleared stack)", fn, k);
+        if (int rc = bcheck_tex(fn, k, q.H, q.W, q.C, q.levels)) return rc;
+    }
+    if (n == 0) return TEXIR_OK;
+    if (env().mip_per_level) {
+        for (int k = 0; k < n; k++) {
+            const texir_tex_gather_job& q = jobs[k];
+            BATCH_HIP_TRY(fn, launch_tex_gather_bwd(q.d_tex, q.grad_rest, q.H, q.W, q.C, q.levels, (const long long*)q.seg_key, q.seg_start, q.seg_count, q.n_seg, q.pix, q.weights, q.d_out,
+                                                    q.filter_mode, q.defer_last_fold, st));
+        }
+        return TEXIR_OK;
+    }
+    GatherBatch gb; gb.n = 0;
+    int blocks = 0;
+    for (int k = 0; k < n; k++) {
+        const texir_tex_gather_job& q = jobs[k];
+        if (q.n_seg <= 0) continue;
+        GatherJob& J = gb.j[gb.n++];
+        J.lvl0 = q.d_tex; J.rest = q.grad_rest; J.n0 = (int64_t)q.H * q.W; J.seg_key = (const long long*)q.seg_key; J.seg_start = q.seg_start; J.seg_count = q.seg_count; J.n_seg = q.n_seg;
+        J.pix = q.pix; J.w = q.weights; J.d_out = q.d_out; J.C = q.C; J.first = blocks; J.nb = grid1d(q.n_seg, 256);
+        blocks += J.nb;
+    }
+    if (gb.n > 0) hipLaunchKernelGGL(tex_gather_batch_kernel, dim3(blocks), dim3(256), 0, st, gb);
+    FoldBatch fb; fb.n = 0;
+    blocks = 0;
+    for (int k = 0; k < n; k++) {
+        const texir_tex_gather_job& q = jobs[k];
+        const int f = q.defer_last_fold;
+        if (!(q.filter_mode == 1 && q.levels > 1) || q.levels - 1 - f < 1) continue;
+        FoldJob& J = fb.j[fb.n++];
+        J.d = make_desc(q.H, q.W, q.C, q.levels);
+        J.fine = f == 0 ? q.d_tex : q.grad_rest + J.d.off[f]; J.rest = q.grad_rest; J.f = f; J.mask = q.rest_mask; J.first = blocks;
+        blocks += (((q.H >> f) + 31) / 32) * (((q.W >> f) + 31) / 32);
+    }
+    if (fb.n > 0) hipLaunchKernelGGL(mip_pyr_fold_batch_kernel, dim3(blocks), dim3(256), 0, st, fb);
+    BATCH_HIP_TRY(fn, hipGetLastError());
+    return TEXIR_OK;
+}
+
+int texir_adam_step_tex_dev_batch(const texir_adam_tex_job* jobs, int32_t n, void* stream)
+{
+    const char* fn = "texir_adam_step_tex_dev_batch";
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 0 || n > kMaxBatch || (n > 0 && !jobs)) return bfail(TEXIR_ERR_INVALID, "%s: 0..%d jobs (got %d)", fn, kMaxBatch, n);
+    bool vec = !env().adam_scalar;
+    for (int k = 0; k < n; k++) {
+        const texir_adam_tex_job& q = jobs[k];
+        if (!q.param || (!q.grad_level1 && !q.grad_level2) || !q.exp_avg || !q.exp_avg_sq || !q.hyper) return bfail(TEXIR_ERR_INVALID, "%s: job %d: null argument", fn, k);
+        if (q.H < 2 || q.W < 2 || (q.H & 1) || (q.W & 1) || q.C < 1 || q.C > 4) return bfail(TEXIR_ERR_INVALID, "%s: job %d: bad H/W/C", fn, k);
+        if (q.grad_level2 && ((q.H & 3) || (q.W & 3))) return bfail(TEXIR_ERR_INVALID, "%s: job %d: a level-2 gradient needs H and W divisible by 4", fn, k);
+        if (q.level1_mask && !q.grad_level2) return bfail(TEXIR_ERR_INVALID, "%s: job %d: level1_mask needs grad_level2", fn, k);
+        if ((q.W * q.C) % 4 != 0) vec = false;
+    }
+    if (n == 0) return TEXIR_OK;
+    if (!vec) {
+        // scalar form (reference kernel of the parity tests, or rows that are not 16-byte aligned): one launch per job
+        for (int k = 0; k < n; k++) {
+            const texir_adam_tex_job& q = jobs[k];
+            dim3 grid(((q.W >> 1) * q.C + 255) / 256, (q.H >> 1) > 4096 ? 4096 : (q.H >> 1));
+#define TEXIR_ADAM_SCALAR_LAUNCH(CC) hipLaunchKernelGGL(adam_tex_kernel<CC>, grid, dim3(256), 0, st, q.param, q.grad, q.grad_mask, q.grad_level1, q.grad_level2, q.exp_avg, q.exp_avg_sq, \
+                                                        q.mip_level1, q.H, q.W, q.beta1, q.beta2, q.eps, 0.f, 1.f, q.clamp_lo, q.clamp_hi, q.hyper, q.level1_mask)
+            if (q.C == 1) TEXIR_ADAM_SCALAR_LAUNCH(1); else if (q.C == 2) TEXIR_ADAM_SCALAR_LAUNCH(2); else if (q.C == 3) TEXIR_ADAM_SCALAR_LAUNCH(3); else TEXIR_ADAM_SCALAR_LAUNCH(4);
+#undef TEXIR_ADAM_SCALAR_LAUNCH
+        }
+        BATCH_HIP_TRY(fn, hipGetLastError());
+        return TEXIR_OK;
+    }
+    AdamTexBatch ab; ab.n = n;
+    int gx = 0, gy = 1;
+    for (int k = 0; k < n; k++) {
+        const texir_adam_tex_job& q = jobs[k];
+        AdamTexJob& J = ab.j[k];
+        J.p = q.param; J.g = q.grad; J.l0_mask = q.grad_mask; J.g1 = q.grad_level1; J.g1_mask = q.level1_mask; J.g2 = q.grad_level2; J.m = q.exp_avg; J.v = q.exp_avg_sq; J.mip1 = q.mip_level1;
+        J.H = q.H; J.W = q.W; J.C = q.C; J.beta1 = q.beta1; J.beta2 = q.beta2; J.eps = q.eps; J.lo = q.clamp_lo; J.hi = q.clamp_hi; J.hyp = q.hyper;
+        const int epb = adam_vec_epb(q.C);
+        J.first = gx; J.gy = (q.H >> 1) > 2048 ? 2048 : (q.H >> 1);
+        if (const int v = env().adam_grid_y; v >= 1 && v < J.gy) J.gy = v;
+        gx += (q.W * q.C + epb - 1) / epb;
+        if (J.gy > gy) gy = J.gy;
+    }
+    hipLaunchKernelGGL(adam_tex_vec_batch_kernel, dim3(gx, gy), dim3(256), 0, st, ab);
+    BATCH_HIP_TRY(fn, hipGetLastError());
+    return TEXIR_OK;
+}
+
+}  // extern "C"

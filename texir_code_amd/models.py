@@ -17,7 +17,7 @@ from torch import nn
 from . import dist_util, gbuffer as GB, io_formats as IO
 from .cube2pano import Cube2Pano
 from .scene import Scene, generate_dir, spec_render
-from .texture import texture as tex_fetch
+from .texture import texture as tex_fetch, texture_batch as tex_fetch_batch
 
 TINY_NUMBER = 1e-6
 
@@ -221,9 +221,11 @@ class MaterialModel(nn.Module):
         stage-1 loss reads it, train_material.py via loss.py:98-104)"""
         texc, texd = gb["uv"], gb["uv_da"]
         # (cache=gb: the view's fetch coordinates never change, so the backward is a gather over tap lists sorted once per view)
-        albedo = tex_fetch(self.materials_a, texc, texd, "linear-mipmap-linear", self.max_mip_level, cache=gb)
         roughness_womipmap = tex_fetch(self.materials_r, texc, texd, "linear", cache=gb) if womipmap else None
-        roughness = tex_fetch(self.materials_r, texc, texd, "linear-mipmap-linear", self.max_mip_level, cache=gb)
+        # the two trilinear fetches as ONE node: one launch per kind of kernel over both textures, forward and backward (texture.texture_batch).  Made after
+        # the un-mipmapped fetch, so that autograd runs its backward first: the trilinear fetch of the roughness texture decides between the sparse and the
+        # dense level-0 form by `grad is None` (texture._bwd_prepare), as it did when it was a node of its own.
+        albedo, roughness = tex_fetch_batch([self.materials_a, self.materials_r], texc, texd, "linear-mipmap-linear", self.max_mip_level, cache=gb)
         # the irradiance texture is frozen and the view's uvs are constant: fetch once per view
         irr = gb.get("_irr")
         if irr is None or gb.get("_irr_version") != self.irrt._version or self.irrt.requires_grad:

@@ -181,6 +181,12 @@ class FusedAdam(torch.optim.Optimizer):
             g[bits] += p._texir_g0[bits]
         up = lambda t: t.repeat_interleave(2, 0).repeat_interleave(2, 1)
         l1 = g1.view(H // 2, W // 2, C).clone()
+        m1 = getattr(g1, "_texir_mask", None)
+        if m1 is not None:
+            # a never-cleared stack: only the texels of the view's tap mask hold this step's values (level 1 leads the stack: bits [0, H/2 * W/2))
+            n1 = (H // 2) * (W // 2)
+            bits1 = ((m1.view(-1, 1).to(torch.int64) >> torch.arange(32, device=p.device)) & 1).bool().reshape(-1)[:n1].reshape(H // 2, W // 2, 1)
+            l1 = torch.where(bits1, l1, torch.zeros((), device=p.device))
         g2 = getattr(p, "_texir_grad_l2", None)
         if g2 is not None:
             l1 += 0.25 * up(g2.view(H // 4, W // 4, C))
@@ -217,6 +223,14 @@ class FusedAdam(torch.optim.Optimizer):
                 if p.device == device:
                     mask |= 1 << self._rec[id(p)]
             _lib.check(L.texir_adam_tick(_lib.ptr(d["state"]), _lib.ptr(d["hyper"]), d["state"].shape[0], mask, _lib.stream_ptr()))
+        from . import texture as _tx
+        pending, keep = [], []            # texture jobs waiting for their batched launch (texir_adam_step_tex_dev_batch); tensors they point to
+
+        def flush():
+            if pending:
+                _lib.batch_call("texir_adam_step_tex_dev_batch", pending)
+                del pending[:], keep[:]
+
         for group, p, g1 in todo:
             b1, b2 = group["betas"]
             st = self._ensure_state(p)
@@ -249,14 +263,30 @@ class FusedAdam(torch.optim.Optimizer):
                 mip1 = mips[1] if (mips is not None and mips[1].numel() >= (H // 2) * (W // 2) * C and mips[1].device == p.device) else None
                 g2 = getattr(p, "_texir_grad_l2", None)
                 g1_read = None if (g2 is not None and getattr(p, "_texir_l1_zero", False)) else g1      # (all zeros: not read, texture.py backward)
-                _lib.check(L.texir_adam_step_tex_dev(_lib.ptr(p), _lib.ptr(g), _lib.ptr(mask), _lib.ptr(g1_read), _lib.ptr(g2),
-                                                     _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]), _lib.ptr(mip1), H, W, C, _lib.ptr(hyper),
-                                                     float(b1), float(b2), float(group["eps"]), lo, hi, _lib.stream_ptr()))
+                # a stack that is never cleared: valid -- and read -- only where the view's tap mask says so (texture._bwd_finish parks the mask on the stack)
+                g1_mask = getattr(g1, "_texir_mask", None) if g2 is not None else None
+                if g1_mask is not None and g1_read is None:
+                    g1_mask = None
+                if _tx._BATCH:
+                    A = _lib.addr
+                    pending.append(_lib.AdamTexJob(A(p), A(g), A(mask), A(g1_read), A(g1_mask), A(g2), A(st["exp_avg"]), A(st["exp_avg_sq"]), A(mip1), H, W, C,
+                                                   A(hyper), float(b1), float(b2), float(group["eps"]), lo, hi))
+                    keep.extend([g, mask, g1_read, g1_mask, g2, hyper])
+                    if len(pending) == _lib.MAX_BATCH:
+                        flush()
+                else:
+                    if getattr(g1, "_texir_mask", None) is not None:
+                        raise _lib.TexirError("FusedAdam.step: a masked gradient stack needs the batched step (TEXIR_TEX_BATCH was switched off between backward and step)")
+                    _lib.check(L.texir_adam_step_tex_dev(_lib.ptr(p), _lib.ptr(g), _lib.ptr(mask), _lib.ptr(g1_read), _lib.ptr(g2),
+                                                         _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]), _lib.ptr(mip1), H, W, C, _lib.ptr(hyper),
+                                                         float(b1), float(b2), float(group["eps"]), lo, hi, _lib.stream_ptr()))
                 # one-shot: the next mip build of this parameter may start from level 1 (texture._mips_for consumes the flag)
                 p._texir_mip1_fresh = (p.data_ptr(), p._version) if mip1 is not None else None
                 p._texir_grad_l1 = p._texir_grad_l2 = None         # consumed (a hipGraph replay re-attaches its own, graph_step.step)
             else:
+                flush()                                            # (launch order = parameter order)
                 p._texir_mip1_fresh = None                         # the texture changes behind the mip stack's back
                 _lib.check(L.texir_adam_step_dev(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]), p.numel(), _lib.ptr(hyper),
                                                  float(b1), float(b2), float(group["eps"]), lo, hi, _lib.stream_ptr()))
+        flush()
         return loss

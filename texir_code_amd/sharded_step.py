@@ -120,14 +120,16 @@ class ShardedMatStep:
 
         add(f["albedo"], dl.get("albedo"), d_spec_a if stage == 2 else None)
         add(f["roughness"], dl.get("roughness"), d_spec_r if stage == 2 else None)
+        n_tri = len(outs)                        # the trilinear fetches: outputs of ONE node (texture.texture_batch) -- walked together
         add(f["roughness_womipmap"], dl.get("roughness_womipmap"), d_spec_r if stage == 1 else None)
         # the fetch backward of the full view: gathers over the view's tap lists, folds, parked stacks -- the gradient lands on the parameters exactly as in
-        # the single-process step.  One fetch at a time, the trilinear fetch of a texture before its un-mipmapped one (the order the single-process
+        # the single-process step.  The trilinear fetches of the textures first, then the un-mipmapped one (the order the single-process
         # backward runs them; texture.py asks `owner.grad is None` to decide between the sparse and the dense level-0 form)
         train = [p for p in self.params if p.requires_grad]
         total = {id(p): None for p in train}
-        for t, g in zip(outs, grads):
-            part = torch.autograd.grad([t], train, [g], allow_unused=True)
+        walks = ([(outs[:n_tri], grads[:n_tri])] if n_tri else []) + [([t], [g]) for t, g in zip(outs[n_tri:], grads[n_tri:])]
+        for ts, gs in walks:
+            part = torch.autograd.grad(ts, train, gs, allow_unused=True)
             for p, d in zip(train, part):
                 if d is not None:
                     total[id(p)] = d if total[id(p)] is None else total[id(p)] + d

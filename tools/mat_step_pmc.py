@@ -23,7 +23,8 @@ def steps_of(path, n_steps=20):
         disp.setdefault(int(r["Dispatch_Id"]), []).append(r)
     ids = sorted(disp)
     names = [disp[i][0]["Kernel_Name"] for i in ids]
-    ends = [k for k, nm in enumerate(names) if "adam_tex" in nm and "kernel<1>" in nm]
+    # (the step's last launch: the batched Adam over both textures, or -- TEXIR_TEX_BATCH=0 -- the one-channel texture's own)
+    ends = [k for k, nm in enumerate(names) if "adam_tex" in nm and ("kernel<1>" in nm or "batch_kernel" in nm)]
     assert len(ends) > n_steps + 1, "not enough replayed steps in %s" % path
     per_step = ends[-1] - ends[-2]
     assert all(ends[-k] - ends[-k - 1] == per_step for k in range(1, n_steps + 1)), "steps of different length"

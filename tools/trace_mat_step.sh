@@ -8,8 +8,8 @@ python - "$f" <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-# the roughness texture's Adam launch (one channel) ends a step: take the kernels between the last two of them
-idx=[i for i,r in enumerate(rows) if 'adam_tex' in r['Kernel_Name'] and 'kernel<1>' in r['Kernel_Name']]
+# the Adam launch (batched over both textures; or the one-channel texture's own) ends a step: take the kernels between the last two of them
+idx=[i for i,r in enumerate(rows) if 'adam_tex' in r['Kernel_Name'] and ('kernel<1>' in r['Kernel_Name'] or 'batch_kernel' in r['Kernel_Name'])]
 end=idx[-1]; start=idx[-2]+1
 seg=rows[start:end+1]
 t0=int(seg[0]['Start_Timestamp']); tot=0
