@@ -309,6 +309,19 @@ def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5, cube=12
         if it >= warmup:
             times.append((time.perf_counter() - t0) * 1e3)
     med = float(np.median(times))
+    # The same steps queued back to back, as the trainer's loop issues them (no host synchronisation per step: the next step's shifts are drawn and
+    # staged while the current one runs): total time / steps.  `ms` above is the LATENCY of one step (launch + run + the host noticing the end), the
+    # figure of the earlier rounds; this is the step PERIOD of a running optimisation.
+    b2b = host_ms = None
+    if gs is not None and world == 1:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for it in range(warmup + steps, warmup + 2 * steps):
+            gs.step(view_of(it), 2, staged=True)
+            gs.stage_shift(view_of(it + 1), gs.draw_shift())
+        host_ms = (time.perf_counter() - t0) * 1e3 / steps           # what the host needs per step (it must stay below the period)
+        torch.cuda.synchronize()
+        b2b = (time.perf_counter() - t0) * 1e3 / steps
     model._static_shift = None
     if world > 1:
         tt = torch.tensor([med], device=dev, dtype=torch.float64)
@@ -333,7 +346,8 @@ def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5, cube=12
             tnote = "measured: %.2f GB read + %.2f GB written per step over the fabric (profiles/pmc_mat_step.json)" % (tj["read_bytes_per_step"] / 1e9, tj["write_bytes_per_step"] / 1e9)
         else:
             tnote = "profiles/pmc_mat_step.json was taken with other sources"
-    return {"ms": round(med, 3), "views_per_step": world, "ms_per_view": round(med / world, 3),
+    return {"ms": round(med, 3), "ms_back_to_back": None if b2b is None else round(b2b, 3), "host_ms_per_step": None if host_ms is None else round(host_ms, 3),
+            "views_per_step": world, "ms_per_view": round(med / world, 3),
             "stage": 2, "steps": steps, "warmup": warmup, "hipgraph": bool(graphs),
             "roofline": {"bound": "hbm", "achieved": round(step_bytes / (med * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(step_bytes / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_step": int(step_bytes),

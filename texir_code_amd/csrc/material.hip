@@ -305,11 +305,113 @@ __global__ __launch_bounds__(256) void mip_pyr_down_kernel(const float* __restri
 template <int C>
 __device__ __forceinline__ float rest_read(const float* __restrict__ rest, const uint32_t* __restrict__ mask, int64_t off, int64_t texel, int c)
 {
+    // (the value is loaded whether its bit is set or not and SELECTED afterwards: a branch on the mask word would put every value load behind its own
+    // mask load -- a block of the fold issues ~20 of these per thread, and as dependent round trips they were the whole launch, 23 us.  What an unset
+    // texel holds is never used in arithmetic.)
+    const float val = rest[off + texel * C + c];
     if (mask) {
         const int64_t t = off / C + texel;
-        if (!((mask[t >> 5] >> (t & 31)) & 1u)) return 0.f;
+        return ((mask[t >> 5] >> (t & 31)) & 1u) ? val : 0.f;
     }
-    return rest[off + texel * C + c];
+    return val;
+}
+
+// The tile of a stack with at least five levels above f whose level f is made of whole 32 x 32 tiles with 16-byte aligned rows (every texture that matters): the
+// same fused multiply-adds as the general body below, but
+//   * EVERY global load of the tile -- the ancestors' texels, the tile's own texels of levels f+4 .. f+1 and of level f, through the mask where there is one --
+//     is issued before the first barrier (the general form walks the levels with a load + barrier each);
+//   * level f, where the bytes are, moves as float4: C loads and C stores per thread instead of 4C.  On gfx9 a store holds its address / data registers until it
+//     completes, and the compiler reuses them for the next one: the twelve scalar stores of the 3-channel tile ran as twelve dependent round trips (an
+//     `s_waitcnt vmcnt(0)` in front of each, see the ISA) -- 17 us for 12 MB against 8 us for the 1-channel texture's 4 MB.
+template <int C>
+__device__ __forceinline__ void mip_pyr_fold_tile5(float* __restrict__ fine_base, const float* __restrict__ rest, const MipDesc& d, int f,
+                                                   const uint32_t* __restrict__ mask, int ty, int tx, float (*buf)[16 * 16 * C])
+{
+    const int tid = threadIdx.x, top = d.levels - 1;
+    const int Wf = d.W >> f;
+    const bool masked_f = mask != nullptr && f >= 1;
+    // element i of the tile's n x n x C block of level f+k (n = 32 >> k, k = 1 .. 4): channel, texel inside the level, in bounds?
+    auto locate = [&](int k, int i, int& c, int& ox, int& oy, int64_t& texel) -> bool {
+        const int n = 32 >> k, Hl = d.H >> (f + k), Wl = d.W >> (f + k);
+        c = i % C; const int t = i / C; ox = t % n; oy = t / n;
+        const int Y = ty * n + oy, X = tx * n + ox;
+        texel = (int64_t)Y * Wl + X;
+        return i < n * n * C && Y < Hl && X < Wl;
+    };
+    auto load = [&](int k, int i) -> float {
+        int c, ox, oy; int64_t texel;
+        return locate(k, i, c, ox, oy, texel) ? rest_read<C>(rest, mask, d.off[f + k], texel, c) : 0.f;
+    };
+    // ---- all loads ----
+    // (ancestors: thread j * C + c holds the tile's texel of level top - j, channel c; they meet in LDS below)
+    float anc = 0.f;
+    if (tid < 16 * C) {
+        const int j = tid / C, l = top - j;
+        if (l >= f + 5) {
+            const int sh = l - f - 5;                           // tile coordinate -> texel of level l (tile = 32 texels of level f = 1 texel of level f+5)
+            anc = rest_read<C>(rest, mask, d.off[l], (int64_t)(ty >> sh) * (d.W >> l) + (tx >> sh), tid - j * C);
+        }
+    }
+    const float l4 = load(4, tid), l3 = load(3, tid), l2 = load(2, tid);
+    float l1[C];
+#pragma unroll
+    for (int j = 0; j < C; j++) l1[j] = load(1, tid + 256 * j);
+    // level f: the tile is 32 rows of 32 * C floats = 8 * C float4; thread tid owns float4 number tid + 256 * j (j < C) of the tile
+    float4 own[C];
+    uint32_t ownbits = 0xffffu;                                  // bit 4 * j + m: element m of float4 j holds a value of this step (mask)
+    const int64_t f_off = d.off[f] / C;
+#pragma unroll
+    for (int j = 0; j < C; j++) {
+        const int q = tid + 256 * j, row = q / (8 * C), e0 = (q - row * (8 * C)) * 4;
+        const int64_t texel0 = (int64_t)(ty * 32 + row) * Wf + tx * 32;
+        own[j] = *reinterpret_cast<const float4*>(fine_base + texel0 * C + e0);
+        if (masked_f) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int64_t tt = f_off + texel0 + (e0 + m) / C;
+                if (!((mask[tt >> 5] >> (tt & 31)) & 1u)) ownbits &= ~(1u << (4 * j + m));
+            }
+        }
+    }
+    // ---- the chain, top down ----
+    if (tid < 16 * C) buf[1][tid] = anc;
+    __syncthreads();
+    if (tid < C) {
+        float acc = buf[1][tid];
+        for (int j = 1; j < 16; j++) if (top - j >= f + 5) acc = __builtin_fmaf(0.25f, acc, buf[1][j * C + tid]);
+        buf[0][tid] = acc;                                       // folded level f+5: the tile's one texel there
+    }
+    int cur = 0;
+    auto fold_level = [&](int k, int i, float val) {
+        int c, ox, oy; int64_t texel;
+        const int n = 32 >> k;
+        if (i < n * n * C) {
+            const bool in = locate(k, i, c, ox, oy, texel);
+            buf[cur ^ 1][i] = in ? __builtin_fmaf(0.25f, buf[cur][((oy >> 1) * (n >> 1) + (ox >> 1)) * C + c], val) : 0.f;
+        }
+    };
+    __syncthreads(); fold_level(4, tid, l4); cur ^= 1;
+    __syncthreads(); fold_level(3, tid, l3); cur ^= 1;
+    __syncthreads(); fold_level(2, tid, l2); cur ^= 1;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < C; j++) fold_level(1, tid + 256 * j, l1[j]);
+    cur ^= 1;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < C; j++) {
+        const int q = tid + 256 * j, row = q / (8 * C), e0 = (q - row * (8 * C)) * 4;
+        const int64_t texel0 = (int64_t)(ty * 32 + row) * Wf + tx * 32;
+        const float o4[4] = {own[j].x, own[j].y, own[j].z, own[j].w};
+        float r4[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int ox = (e0 + m) / C, c = (e0 + m) - ox * C;
+            const float mine = ((ownbits >> (4 * j + m)) & 1u) ? o4[m] : 0.f;
+            r4[m] = __builtin_fmaf(0.25f, buf[cur][((row >> 1) * 16 + (ox >> 1)) * C + c], mine);
+        }
+        *reinterpret_cast<float4*>(fine_base + texel0 * C + e0) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+    }
 }
 
 template <int C>
@@ -321,6 +423,8 @@ __device__ __forceinline__ void mip_pyr_fold_body(float* __restrict__ fine_base 
     const int ty = bid / tiles_x, tx = bid - ty * tiles_x;
     const int top = d.levels - 1;
     const int K = min(5, top - f);                              // levels f+1 .. f+K live inside the tile
+    // (whole tiles, 16-byte aligned rows and level base: the float4 form)
+    if (K == 5 && (Hf & 31) == 0 && (Wf & 31) == 0 && ((uintptr_t)fine_base & 15) == 0) { mip_pyr_fold_tile5<C>(fine_base, rest, d, f, mask, ty, tx, buf); return; }
     // ancestors: levels top .. f+K (one texel each for this tile), folded from the top down by the first C threads
     if (K == 5 && (int)threadIdx.x < C) {
         const int c = threadIdx.x;
@@ -372,11 +476,11 @@ __device__ __forceinline__ void mip_pyr_fold_body(float* __restrict__ fine_base 
         const int Y = ty * 32 + oy, X = tx * 32 + ox;
         if (Y < Hf && X < Wf) {
             float* o = fine_base + ((size_t)Y * Wf + X) * C + c;
-            float own;
+            float own = *o;
             if (masked_f) {
                 const int64_t tt = d.off[f] / C + (int64_t)Y * Wf + X;
-                own = ((mask[tt >> 5] >> (tt & 31)) & 1u) ? *o : 0.f;
-            } else own = *o;
+                own = ((mask[tt >> 5] >> (tt & 31)) & 1u) ? own : 0.f;
+            }
             *o = __builtin_fmaf(0.25f, buf[cur][((oy >> 1) * 16 + (ox >> 1)) * C + c], own);
         }
     }
@@ -525,28 +629,39 @@ __device__ __forceinline__ void tex_gather_body(float* __restrict__ lvl0, float*
                                                 const int* __restrict__ seg_start, const int* __restrict__ seg_count, int n_seg,
                                                 const int* __restrict__ pix, const float* __restrict__ w, const float* __restrict__ d_out, int bid, int nb)
 {
+    constexpr int R = 8;                                         // taps per round
     for (int s = bid * 256 + threadIdx.x; s < n_seg; s += nb * 256) {
         const long long key = seg_key[s];
         if (key < n0 && !lvl0) continue;                     // (caller passed no level-0 buffer: it promised that no list samples level 0)
         const int b = seg_start[s], e = b + seg_count[s];
         float acc[C];
         for (int c = 0; c < C; c++) acc[c] = 0.f;
-        // (four taps' loads in flight at a time -- index, weight, then the gathered gradient; a short tail re-reads the last tap -- and the fused
-        // multiply-adds in list order, one per real tap: the chain of dependent loads per tap is what this kernel waits for, and the sum keeps its bits)
-        for (int i = b; i < e; i += 4) {
-            const int n = e - i;                                   // taps of this round: 4, or 1..3 in the last one
-            const int i1 = n > 1 ? i + 1 : i, i2 = n > 2 ? i + 2 : i, i3 = n > 3 ? i + 3 : i;
-            const int p0 = pix[i], p1 = pix[i1], p2 = pix[i2], p3 = pix[i3];
-            const float w0 = w[i], w1 = w[i1], w2 = w[i2], w3 = w[i3];
-            float v0[C], v1[C], v2[C], v3[C];
+        // The launch lasts as long as its LONGEST list (one thread per touched texel; median 2 taps, 99.9 % below 40, a few coarse-level texels near 100 --
+        // profiles/r04/tap_level_probe.txt), and a tap is two dependent loads (index + weight, then the gathered gradient).  Eight taps' loads are in flight per
+        // round (a short tail re-reads the last tap), and the next round's indices and weights are requested BEFORE this round's gradient values are consumed:
+        // one round trip per eight taps instead of two per four.  The fused multiply-adds stay in list order, one per real tap: the sum keeps its bits.
+        int pp[R]; float ww[R];
 #pragma unroll
-            for (int c = 0; c < C; c++) { v0[c] = d_out[(int64_t)p0 * C + c]; v1[c] = d_out[(int64_t)p1 * C + c]; v2[c] = d_out[(int64_t)p2 * C + c]; v3[c] = d_out[(int64_t)p3 * C + c]; }
+        for (int k = 0; k < R; k++) { const int ik = min(b + k, e - 1); pp[k] = pix[ik]; ww[k] = w[ik]; }
+        for (int i = b; i < e; i += R) {
+            const int n = e - i;                                   // taps of this round: R, or fewer in the last one
+            float v[R][C];
+#pragma unroll
+            for (int k = 0; k < R; k++)
+#pragma unroll
+                for (int c = 0; c < C; c++) v[k][c] = d_out[(int64_t)pp[k] * C + c];
+            float wc[R];
+#pragma unroll
+            for (int k = 0; k < R; k++) wc[k] = ww[k];
+            if (i + R < e) {
+#pragma unroll
+                for (int k = 0; k < R; k++) { const int ik = min(i + R + k, e - 1); pp[k] = pix[ik]; ww[k] = w[ik]; }
+            }
 #pragma unroll
             for (int c = 0; c < C; c++) {
-                float a = __builtin_fmaf(v0[c], w0, acc[c]);
-                if (n > 1) a = __builtin_fmaf(v1[c], w1, a);
-                if (n > 2) a = __builtin_fmaf(v2[c], w2, a);
-                if (n > 3) a = __builtin_fmaf(v3[c], w3, a);
+                float a = acc[c];
+#pragma unroll
+                for (int k = 0; k < R; k++) if (k < n) a = __builtin_fmaf(v[k][c], wc[k], a);
                 acc[c] = a;
             }
         }
@@ -771,6 +886,38 @@ constexpr int adam_vec_epb(int C) { return C == 3 ? 960 : (1024 / (2 * C)) * (2 
 // that no 2x2 texel block straddles two blocks), every thread one float4 of each row; the level-1 gradient segment and the updated
 // texels go through LDS so that the level-1 texels come out in the mip build's own summation order ((p00 + p01) + p10) + p11.
 // Needs W*C % 4 == 0 (16-byte aligned rows); launch_adam_tex falls back to adam_tex_kernel otherwise.  Identical bits.
+// A/B switch of the build (make EXTRA=-DTEXIR_ADAM_NT=n): non-temporal hint on the step's loads (1), stores (2) or both (3) of texels and moments
+#ifndef TEXIR_ADAM_NT
+#define TEXIR_ADAM_NT 3          // measured (profiles/r04/adam_batch_probe_s15.txt): 310 -> 283 us per launch over both 4k textures, 5.5 -> 6.0 TB/s; loads or stores alone: a third of it each
+#endif
+#ifndef TEXIR_ADAM_WAVES
+#define TEXIR_ADAM_WAVES 5       // 94 VGPRs, no scratch (unbounded: 116 = 4 waves; 6: 24 bytes of scratch).  Alone the launch takes the same time at 4 / 5 / 6; inside the step 5 was 10 us ahead of 4
+#endif
+#if TEXIR_ADAM_WAVES
+#define TEXIR_ADAM_BOUNDS __launch_bounds__(256, TEXIR_ADAM_WAVES)
+#else
+#define TEXIR_ADAM_BOUNDS __launch_bounds__(256)
+#endif
+typedef float texir_vf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 adam_ld4(const float* __restrict__ q)
+{
+#if TEXIR_ADAM_NT & 1
+    const texir_vf4 t = __builtin_nontemporal_load(reinterpret_cast<const texir_vf4*>(q));
+    return make_float4(t.x, t.y, t.z, t.w);
+#else
+    return *reinterpret_cast<const float4*>(q);
+#endif
+}
+__device__ __forceinline__ void adam_st4(float* __restrict__ q, float a, float b, float c, float d)
+{
+#if TEXIR_ADAM_NT & 2
+    texir_vf4 t; t.x = a; t.y = b; t.z = c; t.w = d;
+    __builtin_nontemporal_store(t, reinterpret_cast<texir_vf4*>(q));
+#else
+    *reinterpret_cast<float4*>(q) = make_float4(a, b, c, d);
+#endif
+}
+
 //   * g1_mask (nullable, only together with g2): the level-1 stack is a never-cleared buffer; its texels carry this step's values only where the view's tap
 //     lists wrote them (bit by * W/2 + x of the mask -- level 1 leads the `rest` stack, so this is the stack's own mask), all others count as zero and
 //     are not read.
@@ -789,16 +936,37 @@ __device__ __forceinline__ void adam_tex_vec_body(float* __restrict__ p, const f
     const bool act = j4 < n_here;
     const int h_base = e_base / 2, n_half = n_here / 2;              // this block's segment of the half-resolution row
     for (int by = by0; by < Hh; by += gy) {
+        // The thread's own texels, moments and level-0 gradient (or the mask bits that say where it is valid) FIRST: these loads depend on nothing, and
+        // issued here they are in flight while the level-1 segment is staged (mask word -> value -> level-2 value: up to three dependent round trips
+        // that the barrier below would otherwise put in front of them).
+        float4 pv[2], mv[2], vv[2], gv[2];
+        uint32_t l0bits = 0;                                        // bit r * 4 + q: element q of row r has a level-0 gradient to read
+        if (act) {
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const size_t i = (size_t)(2 * by + r) * row_elems + e_base + j4;
+                pv[r] = adam_ld4(p + i); mv[r] = adam_ld4(m + i); vv[r] = adam_ld4(v + i);
+                if (g && !l0_mask) gv[r] = *reinterpret_cast<const float4*>(g + i);
+                if (g && l0_mask) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const size_t texel = (size_t)(2 * by + r) * W + (e_base / C) + (j4 + q) / C;
+                        l0bits |= ((l0_mask[texel >> 5] >> (texel & 31)) & 1u) << (r * 4 + q);
+                    }
+                }
+            }
+        }
         for (int k = threadIdx.x; k < n_half; k += 256) {
             const int txh = (h_base + k) / C, ch = (h_base + k) - txh * C;
+            // (the level-2 value is loaded before the mask word is tested: it does not depend on it)
+            const float x2 = g2 ? g2[((size_t)(by >> 1) * (Wh >> 1) + (txh >> 1)) * C + ch] : 0.f;
             float x = 0.f;                                          // (g1 == nullptr: level-1 direct gradient identically zero -- not read)
             if (g1) {
                 bool has = true;
                 if (g1_mask) { const size_t t = (size_t)by * Wh + txh; has = (g1_mask[t >> 5] >> (t & 31)) & 1u; }
                 if (has) x = g1[(size_t)by * Wh * C + h_base + k];
             }
-            if (g2)                                                 // the fold level 2 -> level 1, taken over as well (same fma as mip_pyr_fold_kernel's)
-                x = __builtin_fmaf(0.25f, g2[((size_t)(by >> 1) * (Wh >> 1) + (txh >> 1)) * C + ch], x);
+            if (g2) x = __builtin_fmaf(0.25f, x2, x);               // the fold level 2 -> level 1, taken over as well (same fma as mip_pyr_fold_kernel's)
             g1s[k] = x;
         }
         __syncthreads();
@@ -806,24 +974,25 @@ __device__ __forceinline__ void adam_tex_vec_body(float* __restrict__ p, const f
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 const size_t i = (size_t)(2 * by + r) * row_elems + e_base + j4;
-                float4 pv = *reinterpret_cast<const float4*>(p + i), mv = *reinterpret_cast<const float4*>(m + i), vv = *reinterpret_cast<const float4*>(v + i);
-                float pe[4] = {pv.x, pv.y, pv.z, pv.w}, me[4] = {mv.x, mv.y, mv.z, mv.w}, ve[4] = {vv.x, vv.y, vv.z, vv.w};
+                float pe[4] = {pv[r].x, pv[r].y, pv[r].z, pv[r].w}, me[4] = {mv[r].x, mv[r].y, mv[r].z, mv[r].w}, ve[4] = {vv[r].x, vv[r].y, vv[r].z, vv[r].w};
+                const float ge[4] = {gv[r].x, gv[r].y, gv[r].z, gv[r].w};
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int el = j4 + q;                           // element inside the block's segment
                     const int tx = el / C, ch = el - tx * C;
                     float g0 = 0.f;
                     if (g) {
-                        const size_t texel = (size_t)(2 * by + r) * W + (e_base / C) + tx;
-                        if (!l0_mask || ((l0_mask[texel >> 5] >> (texel & 31)) & 1u)) g0 = g[i + q];
+                        // dense level-0 gradient (read above), or only where this view's tap lists wrote one (bit of the texel set: rare)
+                        if (!l0_mask) g0 = ge[q];
+                        else if ((l0bits >> (r * 4 + q)) & 1u) g0 = g[i + q];
                     }
                     const float gi = __builtin_fmaf(0.25f, g1s[(tx >> 1) * C + ch], g0);
                     adam_update(pe[q], gi, me[q], ve[q], beta1, beta2, eps, step_size, bc2_sqrt, lo, hi);
                     ps[r][el] = pe[q];
                 }
-                *reinterpret_cast<float4*>(p + i) = make_float4(pe[0], pe[1], pe[2], pe[3]);
-                *reinterpret_cast<float4*>(m + i) = make_float4(me[0], me[1], me[2], me[3]);
-                *reinterpret_cast<float4*>(v + i) = make_float4(ve[0], ve[1], ve[2], ve[3]);
+                adam_st4(p + i, pe[0], pe[1], pe[2], pe[3]);
+                adam_st4(m + i, me[0], me[1], me[2], me[3]);
+                adam_st4(v + i, ve[0], ve[1], ve[2], ve[3]);
             }
         }
         __syncthreads();
@@ -840,7 +1009,7 @@ __device__ __forceinline__ void adam_tex_vec_body(float* __restrict__ p, const f
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void adam_tex_vec_kernel(float* __restrict__ p, const float* __restrict__ g, const uint32_t* __restrict__ l0_mask,
+__global__ TEXIR_ADAM_BOUNDS void adam_tex_vec_kernel(float* __restrict__ p, const float* __restrict__ g, const uint32_t* __restrict__ l0_mask,
                                                            const float* __restrict__ g1, const float* __restrict__ g2, float* __restrict__ m, float* __restrict__ v, float* __restrict__ mip1,
                                                            int H, int W, float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float lo, float hi, const float* __restrict__ hyp)
 {
@@ -1000,7 +1169,10 @@ __global__ __launch_bounds__(256) void mip_pyr_fold_batch_kernel(FoldBatch b)
 }
 
 // grid.x = the jobs' row segments side by side, grid.y = the largest row-pair stride of the batch (a job with fewer rows leaves the surplus rows idle)
-__global__ __launch_bounds__(256) void adam_tex_vec_batch_kernel(AdamTexBatch b)
+// CSET: bit C-1 set for every channel count that occurs in the batch -- the other bodies are not compiled in (the kernel's register count is the largest of
+// its bodies': 92 VGPRs with all four, 64 with the albedo + roughness pair)
+template <int CSET>
+__global__ TEXIR_ADAM_BOUNDS void adam_tex_vec_batch_kernel(AdamTexBatch b)
 {
     __shared__ float g1s[512];
     __shared__ float ps[2 * 1024];
@@ -1008,16 +1180,15 @@ __global__ __launch_bounds__(256) void adam_tex_vec_batch_kernel(AdamTexBatch b)
     if ((int)blockIdx.y >= J.gy) return;
     const float step_size = J.hyp[0], bc2_sqrt = J.hyp[1];
     const int bx = blockIdx.x - J.first;
-    switch (J.C) {
-        case 1: adam_tex_vec_body<1>(J.p, J.g, J.l0_mask, J.g1, J.g1_mask, J.g2, J.m, J.v, J.mip1, J.H, J.W, J.beta1, J.beta2, J.eps, step_size, bc2_sqrt, J.lo, J.hi, bx, blockIdx.y, J.gy, g1s,
-                                     reinterpret_cast<float (*)[adam_vec_epb(1)]>(ps)); break;
-        case 2: adam_tex_vec_body<2>(J.p, J.g, J.l0_mask, J.g1, J.g1_mask, J.g2, J.m, J.v, J.mip1, J.H, J.W, J.beta1, J.beta2, J.eps, step_size, bc2_sqrt, J.lo, J.hi, bx, blockIdx.y, J.gy, g1s,
-                                     reinterpret_cast<float (*)[adam_vec_epb(2)]>(ps)); break;
-        case 3: adam_tex_vec_body<3>(J.p, J.g, J.l0_mask, J.g1, J.g1_mask, J.g2, J.m, J.v, J.mip1, J.H, J.W, J.beta1, J.beta2, J.eps, step_size, bc2_sqrt, J.lo, J.hi, bx, blockIdx.y, J.gy, g1s,
-                                     reinterpret_cast<float (*)[adam_vec_epb(3)]>(ps)); break;
-        default: adam_tex_vec_body<4>(J.p, J.g, J.l0_mask, J.g1, J.g1_mask, J.g2, J.m, J.v, J.mip1, J.H, J.W, J.beta1, J.beta2, J.eps, step_size, bc2_sqrt, J.lo, J.hi, bx, blockIdx.y, J.gy, g1s,
-                                      reinterpret_cast<float (*)[adam_vec_epb(4)]>(ps)); break;
-    }
+#define TEXIR_ADAM_BODY(CC)                                                                                                                                   \
+    if constexpr ((CSET >> (CC - 1)) & 1)                                                                                                                     \
+        if (J.C == CC) {                                                                                                                                      \
+            adam_tex_vec_body<CC>(J.p, J.g, J.l0_mask, J.g1, J.g1_mask, J.g2, J.m, J.v, J.mip1, J.H, J.W, J.beta1, J.beta2, J.eps, step_size, bc2_sqrt, J.lo, \
+                                  J.hi, bx, blockIdx.y, J.gy, g1s, reinterpret_cast<float (*)[adam_vec_epb(CC)]>(ps));                                        \
+            return;                                                                                                                                           \
+        }
+    TEXIR_ADAM_BODY(1) TEXIR_ADAM_BODY(2) TEXIR_ADAM_BODY(3) TEXIR_ADAM_BODY(4)
+#undef TEXIR_ADAM_BODY
 }
 
 static thread_local char g_batch_err[384];
@@ -1200,7 +1371,12 @@ int texir_adam_step_tex_dev_batch(const texir_adam_tex_job* jobs, int32_t n, voi
         gx += (q.W * q.C + epb - 1) / epb;
         if (J.gy > gy) gy = J.gy;
     }
-    hipLaunchKernelGGL(adam_tex_vec_batch_kernel, dim3(gx, gy), dim3(256), 0, st, ab);
+    int cset = 0;
+    for (int k = 0; k < n; k++) cset |= 1 << (jobs[k].C - 1);
+    if (cset == 0b0001) hipLaunchKernelGGL(adam_tex_vec_batch_kernel<0b0001>, dim3(gx, gy), dim3(256), 0, st, ab);
+    else if (cset == 0b0100) hipLaunchKernelGGL(adam_tex_vec_batch_kernel<0b0100>, dim3(gx, gy), dim3(256), 0, st, ab);
+    else if (cset == 0b0101) hipLaunchKernelGGL(adam_tex_vec_batch_kernel<0b0101>, dim3(gx, gy), dim3(256), 0, st, ab);
+    else hipLaunchKernelGGL(adam_tex_vec_batch_kernel<0b1111>, dim3(gx, gy), dim3(256), 0, st, ab);
     BATCH_HIP_TRY(fn, hipGetLastError());
     return TEXIR_OK;
 }

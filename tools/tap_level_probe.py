@@ -22,4 +22,13 @@ for v in range(len(views)):
             key = t[0]; n0 = k[1] * k[2]; n1 = n0 // 4
             out.append((k[1], k[4], bool(t[5]), bool(t[7]), int(((key >= n0) & (key < n0 + n1)).sum()), int(key.numel())))
     print(v, out, [bool(getattr(p, "_texir_l1_zero", False)) for p in (model.materials_a, model.materials_r)], flush=True)
+    # lengths of the per-texel tap lists the gather walks (one thread per list, taps summed in list order): segments, taps, mean / 99 % / 99.9 % / longest list
+    for k, t in gb.items():
+        if isinstance(k, tuple) and k[0] == "_taps" and t is not None and k[4] == 1:
+            c = t[2].to(torch.float32)
+            q = torch.quantile(c, torch.tensor([0.5, 0.99, 0.999], device=c.device))
+            big = t[2] > 64
+            print("   lists %d taps %d  median %.0f  99%% %.0f  99.9%% %.0f  longest %d   lists > 64 taps: %d holding %.1f %% of the taps" % (
+                c.numel(), int(c.sum()), q[0], q[1], q[2], int(c.max()), int(big.sum()), 100.0 * float(t[2][big].sum()) / float(c.sum())), flush=True)
+            break
     opt.step()

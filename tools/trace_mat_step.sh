@@ -18,4 +18,9 @@ for r in seg:
     tot+=d
     print('%8.1f us @%8.1f  %s'%(d,(int(r['Start_Timestamp'])-t0)/1e3,r['Kernel_Name'][:100]))
 print('kernels',len(seg),'busy %.1f us'%tot,'span %.1f us'%((int(seg[-1]['End_Timestamp'])-t0)/1e3))
+# period of the replayed steps (end of one step's last kernel to the end of the next one's) and the idle time between two replays
+ends=[int(rows[i]['End_Timestamp']) for i in idx]
+per=[(b-a)/1e3 for a,b in zip(ends[-21:-1],ends[-20:])]
+gaps=[(int(rows[i+1]['Start_Timestamp'])-int(rows[i]['End_Timestamp']))/1e3 for i in idx[-21:-1]]
+if per: print('step period over the last %d replays: mean %.1f us, min %.1f; idle between replays: mean %.1f us, min %.1f'%(len(per),sum(per)/len(per),min(per),sum(gaps)/len(gaps),min(gaps)))
 PY
