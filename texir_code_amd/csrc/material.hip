@@ -632,8 +632,8 @@ __device__ __forceinline__ void tex_gather_body(float* __restrict__ lvl0, float*
     constexpr int R = 8;                                         // taps per round
     for (int s = bid * 256 + threadIdx.x; s < n_seg; s += nb * 256) {
         const long long key = seg_key[s];
+        const int b = seg_start[s], e = b + seg_count[s];    // (all three loads before the first branch: one round trip, not three)
         if (key < n0 && !lvl0) continue;                     // (caller passed no level-0 buffer: it promised that no list samples level 0)
-        const int b = seg_start[s], e = b + seg_count[s];
         float acc[C];
         for (int c = 0; c < C; c++) acc[c] = 0.f;
         // The launch lasts as long as its LONGEST list (one thread per touched texel; median 2 taps, 99.9 % below 40, a few coarse-level texels near 100 --
