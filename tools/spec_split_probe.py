@@ -40,3 +40,50 @@ t_trace = timed(lambda: sc.trace_shade(org, l))
 l2 = l.reshape(P, Sn, 3).transpose(0, 1).reshape(P * Sn, 3).contiguous(); org2 = org.reshape(P, Sn, 3).transpose(0, 1).reshape(P * Sn, 3).contiguous()
 t_trace2 = timed(lambda: sc.trace_shade(org2, l2))
 print("fused spec_kernel %.1f us; trace_shade on the same %d rays: pixel-major %.1f us, sample-major %.1f us" % (t_fused, P * Sn, t_trace, t_trace2))
+
+# ---- would binning pay?  The same rays in other orders (round 4): 8x8-pixel tiles, and inside a tile sorted by direction cell (8x8 octahedral grid, Morton order);
+# per roughness (the GGX lobe of r = 0.1 is a needle -- the 16 rays of a pixel are nearly one direction -- and widens with r) ----
+def morton(a, b):
+    k = torch.zeros_like(a)
+    for bit in range(3):
+        k |= ((a >> bit) & 1) << (2 * bit) | ((b >> bit) & 1) << (2 * bit + 1)
+    return k
+
+
+def orders(rough):
+    r = torch.full((P,), rough, device="cuda")
+    h = S.generate_dir(n, Sn, sh, "importance", r)
+    vdh = (v[:, None] * h).sum(-1, keepdim=True).clamp(0, 1)
+    l = (2 * vdh * h - v[:, None]).reshape(P * Sn, 3).contiguous()
+    org = pts[:, None].expand(P, Sn, 3).reshape(P * Sn, 3).contiguous()
+    p = torch.arange(P, device="cuda")
+    c = 128
+    face, rem = p // (c * c), p % (c * c)
+    i, j = rem // c, rem % c
+    tile = face * 256 + (i // 8) * 16 + (j // 8)
+    tile_r = tile[:, None].expand(P, Sn).reshape(-1)
+    pix_in_tile = ((i % 8) * 8 + (j % 8))[:, None].expand(P, Sn).reshape(-1)
+    smp = torch.arange(Sn, device="cuda")[None].expand(P, Sn).reshape(-1)
+    # octahedral cell of the direction
+    d = l / l.abs().sum(-1, keepdim=True)
+    ox = torch.where(d[:, 2] >= 0, d[:, 0], (1 - d[:, 1].abs()) * torch.sign(d[:, 0]))
+    oy = torch.where(d[:, 2] >= 0, d[:, 1], (1 - d[:, 0].abs()) * torch.sign(d[:, 1]))
+    cx = ((ox * 0.5 + 0.5) * 8).clamp(0, 7).long()
+    cy = ((oy * 0.5 + 0.5) * 8).clamp(0, 7).long()
+    cell = morton(cx, cy)
+    out = {}
+    out["pixel-major (as shipped)"] = torch.arange(P * Sn, device="cuda")
+    out["8x8 tiles, pixel-major inside"] = torch.argsort(tile_r * 1024 + pix_in_tile * 16 + smp)
+    out["8x8 tiles, direction cell inside"] = torch.argsort((tile_r * 64 + cell) * 1024 + pix_in_tile * 16 + smp)
+    out["direction cell, then tile (global)"] = torch.argsort((cell * 4096 * 6 + tile_r) * 1024 + pix_in_tile * 16 + smp)
+    res = []
+    for name, perm in out.items():
+        o2, l2 = org[perm].contiguous(), l[perm].contiguous()
+        res.append((name, timed(lambda: sc.trace_shade(o2, l2))))
+    cells_per_tile = torch.unique(tile_r * 64 + cell).numel() / torch.unique(tile_r).numel()
+    return res, cells_per_tile
+
+
+for rough in (0.1, 0.3, 0.6):
+    res, cpt = orders(rough)
+    print("roughness %.1f: %.1f occupied direction cells per 8x8 tile (of 64);  trace_shade of the %d rays: " % (rough, cpt, P * Sn) + ";  ".join("%s %.1f us" % kv for kv in res), flush=True)
