@@ -2,6 +2,7 @@
 # kernel sequence of ONE replayed material step (name, duration), from a rocprofv3 kernel trace of bench.py's material leg
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/ktm
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ktm -- python $R/bench.py --no-cpu --steps 1 --warmup 0 > /tmp/ktm.log 2>&1
 f=$(find /tmp/ktm -name '*kernel_trace.csv' | head -1)
 python - "$f" <<'PY'
