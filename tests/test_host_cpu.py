@@ -1,7 +1,11 @@
 """CPU tests of host-side logic: conf parser, Cube2Pano restatement (golden), cameras."""
+import os
+
 import numpy as np
 import pytest
 import torch
+
+from conftest import ROOT
 
 # a conf shaped like the reference's configs/syn.conf (re-typed, not copied)
 CONF = """
@@ -363,3 +367,18 @@ def test_rle_hdr_decoder_on_a_hand_assembled_byte_string(tmp_path):
     B = np.array([16, 16, 16, 16, 255, 255, 255, 255], np.float32)
     scale = np.array([2.0 ** -8] * 6 + [2.0 ** -6, 0.0], np.float32)            # e = 128 -> 2^-8; 130 -> 2^-6; e = 0 -> the pixel is black
     assert np.array_equal(img[1], np.stack([R, G, B], -1) * scale[:, None])
+
+
+def test_bvh_builder_keeps_every_triangle_point_reachable(tmp_path):
+    """tests/native/bvh_cover.cpp: the product's host BVH builder compiled with the host compiler; point queries at corners, edge points and interior
+    points of every triangle (small ones, long thin rotated slats, large flat ones) must reach a leaf that holds the triangle, in the binary and in the
+    4-wide float-box tree.  (Written for the reference pre-splitting experiment, tools/experiments/bvh_presplit.patch -- whose split pieces it also
+    covered, TEXIR_PRESPLIT = 30 / 150 -- and kept as the builder's own coverage check.)"""
+    import subprocess
+    csrc = os.path.join(ROOT, "texir_code_amd", "csrc")
+    exe = str(tmp_path / "bvh_cover")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + csrc, os.path.join(ROOT, "tests", "native", "bvh_cover.cpp"), os.path.join(csrc, "bvh_build.cpp"),
+                           os.path.join(csrc, "env.cpp"), "-lpthread", "-o", exe])
+    for n, seed in ((6000, 3), (20000, 7)):
+        out = subprocess.check_output([exe, str(n), str(seed)]).decode().split()
+        assert out[-2:] == ["0", "0"] and int(out[1]) == n, out
