@@ -47,6 +47,28 @@ static bool find4(const BvhHost& h, int32_t node, const float* p, uint32_t prim)
     return false;
 }
 
+#ifdef TEXIR_COVER_BVH8          // (with tools/experiments/bvh8_wide.patch applied: -DTEXIR_COVER_BVH8)
+static bool find8(const BvhHost& h, int32_t node, const float* p, uint32_t prim)
+{
+    const GpuNode8& n = h.nodes8[(size_t)node];
+    const float cell[3] = {n.cell_x, n.cell_y, n.cell_z};
+    const uint32_t* lo[3] = {n.lox, n.loy, n.loz};
+    const uint32_t* hi[3] = {n.hix, n.hiy, n.hiz};
+    for (int k = 0; k < 8; k++) {
+        bool in = true;
+        for (int a = 0; a < 3; a++) {
+            const float l = n.origin[a] + (float)((lo[a][k >> 2] >> (8 * (k & 3))) & 255u) * cell[a], u = n.origin[a] + (float)((hi[a][k >> 2] >> (8 * (k & 3))) & 255u) * cell[a];
+            in = in && p[a] >= l && p[a] <= u;
+        }
+        if (!in) continue;
+        const int32_t c = n.c[k];
+        if (c >= 0) { if (find8(h, c, p, prim)) return true; }
+        else { const uint32_t code = (uint32_t)~c; const uint32_t first = code >> 3, cnt = (code & 7u) + 1; for (uint32_t i = 0; i < cnt; i++) if (h.tris[first + i].prim == prim) return true; }
+    }
+    return false;
+}
+#endif
+
 int main(int argc, char** argv)
 {
     const int T = argc > 1 ? atoi(argv[1]) : 2000;
@@ -70,7 +92,7 @@ int main(int argc, char** argv)
     }
     BvhHost h;
     build_bvh(verts.data(), 3 * T, tris.data(), T, uvs.data(), h);
-    long checked = 0, miss2 = 0, miss4 = 0;
+    long checked = 0, miss2 = 0, miss4 = 0, miss8 = 0;
     for (int t = 0; t < T; t++) {
         const float* A = &verts[9 * (size_t)t], *B = A + 3, *C = A + 6;
         for (int s = 0; s < 24; s++) {
@@ -83,8 +105,14 @@ int main(int argc, char** argv)
             checked++;
             if (!find2(h, 0, p, (uint32_t)t)) miss2++;
             if (!h.nodes4f.empty() && !find4(h, 0, p, (uint32_t)t)) miss4++;
+#ifdef TEXIR_COVER_BVH8
+            if (!h.nodes8.empty() && !find8(h, 0, p, (uint32_t)t)) miss8++;
+#endif
         }
     }
+#ifdef TEXIR_COVER_BVH8
+    if (!h.nodes8.empty()) printf("8-wide: %zu nodes (4-wide: %zu), depth %d (4-wide: %d), misses %ld\n", h.nodes8.size(), h.nodes4.size(), h.max_depth8, h.max_depth4, miss8);
+#endif
     printf("references %zu  checked %ld  misses %ld %ld\n", h.tris.size() - 1, checked, miss2, miss4);
-    return (miss2 || miss4) ? 1 : 0;
+    return (miss2 || miss4 || miss8) ? 1 : 0;
 }
