@@ -114,3 +114,31 @@ def test_batch_entry_points_validate_their_jobs(tx):
     g = _lib.TexGatherJob(A(t), A(t), 64, 64, 3, 5, None, None, None, 0, None, None, A(out), 1, 1, A(t))
     with pytest.raises(_lib.TexirError, match="rest_mask needs defer_last_fold = 2"):
         _lib.batch_call("texir_tex_gather_backward_batch", [g])
+
+
+@pytest.mark.parametrize("stage", [0, 1, 2])
+def test_recorded_step_keeps_its_trajectory_under_every_switch(golden, stage):
+    """the whole material step as a hipGraph (graph_step.GraphedMatStep on the 20 k room, different texture sizes for albedo and roughness): five replays with
+    one launch per texture and cleared stacks, with batched launches, and with batched launches + mask-read stacks leave the same textures, bit for bit --
+    in stage 1 the roughness texture also takes a dense gradient from its un-mipmapped fetch, in stages 0 / 1 one member of the batch is frozen"""
+    from test_gpu_optim_regressions import _small_graphed_world
+    from texir_code_amd import texture as T
+    was = (T._BATCH, T._GRAD_MASK)
+    got = []
+    try:
+        for batch, mask in ((False, False), (True, False), (True, True)):
+            T._BATCH, T._GRAD_MASK = batch, mask
+            m, opt, gs, c = _small_graphed_world(golden, stage)
+            gen = torch.Generator().manual_seed(1)
+            losses = []
+            for _ in range(5):
+                # (the clone is a launch of its own between two replays -- and a small allocation: it once landed on the freed camera vector a recorded
+                # kernel was still reading by address; GraphedMatStep keeps its captured inputs alive since)
+                losses.append(gs.step("v", stage, shift=torch.rand(6 * c * c, 2, generator=gen)).clone())
+            torch.cuda.synchronize()
+            got.append((m.materials_a.detach().clone(), m.materials_r.detach().clone(), torch.stack(losses)))
+    finally:
+        T._BATCH, T._GRAD_MASK = was
+    for k in (1, 2):
+        for i, name in enumerate(("albedo", "roughness", "losses")):
+            assert torch.equal(got[0][i], got[k][i]), (stage, k, name, float((got[0][i] - got[k][i]).abs().max()))

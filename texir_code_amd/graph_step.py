@@ -27,6 +27,7 @@ class GraphedMatStep:
         self.zero_copy = os.environ.get("TEXIR_SHIFT_ZEROCOPY", "1") != "0"
         self.shift_bufs = {}
         self.graphs, self.losses, self.outs, self.pool = {}, {}, {}, None
+        self.inputs = {}                   # (key, stage) -> the captured step's input tensors: the recorded kernels hold their ADDRESSES, so they must outlive the graph
         self.side = torch.cuda.Stream()
         self.grads_to_none = os.environ.get("TEXIR_GRAPH_GRADS_TO_NONE", "1") == "1"
         if not self.grads_to_none:
@@ -62,7 +63,8 @@ class GraphedMatStep:
         return loss
 
     def capture(self, key, mvp, cam, gt, gmask, seg, fm, room, stage):
-        """inputs must be device tensors that stay alive; one graph per (view key, stage)"""
+        """inputs must be device tensors (they are kept alive with the graph, self.inputs: the recorded kernels read them by address); one graph per
+        (view key, stage)"""
         P = gt.shape[0] * gt.shape[1] * gt.shape[2]
         if self.static_shift is None:
             self.static_shift = torch.zeros((P, 2), device=gt.device)
@@ -109,6 +111,9 @@ class GraphedMatStep:
                                      getattr(p, "_texir_l1_zero", False))
                                     for p in self.params]
         self.graphs[(key, stage)] = g
+        # the graph reads its inputs (camera position, ground truth, masks) by address on every replay: a caller that passed a temporary -- `cam.cuda()` --
+        # would otherwise leave the recorded kernels reading whatever the allocator puts there next
+        self.inputs[(key, stage)] = inp
         self.stepped[(key, stage)] = list(getattr(self, "_stepping", [])) if self.step_in_graph else None
         self.losses[(key, stage)] = loss.detach()      # keep no autograd graph of the captured region alive
         self.outs[(key, stage)] = self._last_out
