@@ -320,14 +320,15 @@ def test_runner_with_hipgraph_matches_eager_runner(tmp_path, monkeypatch):
     D.write_conf(conf_mat, root, cube_res=16, spp=(64, 16), albedo_res=64, rough_res=64, epochs=1, model="mat")
     D.render_gt_views(root, C.parse_file(conf_mat), sc, 64, 64)
     logs, finals = [], []
-    for graph, cap in ((False, None), (True, None), (True, "2")):
+    for graph, cap, lag in ((False, None, 0), (True, None, 0), (True, "2", 0), (True, None, 2), (False, None, 3)):
+        # (fourth / fifth run: train.log_lag -- the loss values are logged two / three steps late, from pinned copies, without a host synchronisation per step)
         # (third run: only two graphs may be captured per stage, the other views take the eager step in between)
         if cap is None:
             monkeypatch.delenv("TEXIR_MAX_GRAPHS", raising=False)
         else:
             monkeypatch.setenv("TEXIR_MAX_GRAPHS", cap)
-        txt = open(conf_mat).read().replace("batch_size = 1", "batch_size = 1\n    hipgraph = %s" % ("true" if graph else "false"))
-        p = str(tmp_path / ("mat_%d_%s.conf" % (graph, cap)))
+        txt = open(conf_mat).read().replace("batch_size = 1", "batch_size = 1\n    hipgraph = %s\n    log_lag = %d" % ("true" if graph else "false", lag))
+        p = str(tmp_path / ("mat_%d_%s_%d.conf" % (graph, cap, lag)))
         open(p, "w").write(txt)
         r = MatTrainRunner(conf=p, exps_folder_name=str(tmp_path / "exps"), expname="g", frame_skip=1, max_niters=10, is_continue=False,
                            timestamp="latest", checkpoint="latest", gpu_index=0, dry_dirs=True)
@@ -335,10 +336,13 @@ def test_runner_with_hipgraph_matches_eager_runner(tmp_path, monkeypatch):
         r.run()
         logs.append(np.array(r.log))
         finals.append((r.model.materials_a.detach().cpu().numpy(), r.model.materials_r.detach().cpu().numpy()))
-    for k in (1, 2):
+    for k in (1, 2, 3, 4):
         assert logs[0].shape == logs[k].shape == (24, 5)
         assert np.allclose(logs[0][:, 3], logs[k][:, 3], rtol=1e-4, atol=1e-6)
         assert rel_l2(finals[k][0], finals[0][0]) < 1e-4 and rel_l2(finals[k][1], finals[0][1]) < 1e-4
+    # lagged logging changes WHEN a value reaches the host, nothing else: same log, same textures as the run it lags behind
+    for a, b in ((3, 1), (4, 0)):
+        assert np.array_equal(logs[a], logs[b]) and np.array_equal(finals[a][0], finals[b][0]) and np.array_equal(finals[a][1], finals[b][1])
 
 
 def _sharded_worker(rank, world, port, conf_path, out_path):
