@@ -319,6 +319,8 @@ typedef struct texir_tex_gather_job {
     const float* d_out;        /* dev [P,C] */
     int32_t filter_mode, defer_last_fold;
     const uint32_t* rest_mask; /* dev, nullable */
+    const float* d_out2;       /* dev [P,C], nullable: a second gradient of the same fetch output (two consumers of one dr.texture result, models/mat_nvdiffrast.py:134 ->
+                                  :179 render and models/loss.py:108): the gather adds the two on the fly -- the sum autograd's add launch would have written */
 } texir_tex_gather_job;
 TEXIR_API int texir_tex_gather_backward_batch(const texir_tex_gather_job* jobs /*host*/, int32_t n_jobs, void* stream);
 

@@ -103,7 +103,7 @@ class TexGatherJob(C.Structure):
     """texir_tex_gather_job"""
     _fields_ = [("d_tex", C.c_void_p), ("grad_rest", C.c_void_p), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("levels", C.c_int32),
                 ("seg_key", C.c_void_p), ("seg_start", C.c_void_p), ("seg_count", C.c_void_p), ("n_seg", C.c_int32), ("pix", C.c_void_p),
-                ("weights", C.c_void_p), ("d_out", C.c_void_p), ("filter_mode", C.c_int32), ("defer_last_fold", C.c_int32), ("rest_mask", C.c_void_p)]
+                ("weights", C.c_void_p), ("d_out", C.c_void_p), ("filter_mode", C.c_int32), ("defer_last_fold", C.c_int32), ("rest_mask", C.c_void_p), ("d_out2", C.c_void_p)]
 
 
 class AdamTexJob(C.Structure):

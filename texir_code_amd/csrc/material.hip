@@ -627,7 +627,8 @@ __global__ __launch_bounds__(256) void tex_taps_kernel(MipDesc d, const float* _
 template <int C>
 __device__ __forceinline__ void tex_gather_body(float* __restrict__ lvl0, float* __restrict__ rest, int64_t n0, const long long* __restrict__ seg_key,
                                                 const int* __restrict__ seg_start, const int* __restrict__ seg_count, int n_seg,
-                                                const int* __restrict__ pix, const float* __restrict__ w, const float* __restrict__ d_out, int bid, int nb)
+                                                const int* __restrict__ pix, const float* __restrict__ w, const float* __restrict__ d_out, int bid, int nb,
+                                                const float* __restrict__ d_out2 = nullptr /* a second gradient of the same fetch output, added on the fly */)
 {
     constexpr int R = 8;                                         // taps per round
     for (int s = bid * 256 + threadIdx.x; s < n_seg; s += nb * 256) {
@@ -650,6 +651,14 @@ __device__ __forceinline__ void tex_gather_body(float* __restrict__ lvl0, float*
             for (int k = 0; k < R; k++)
 #pragma unroll
                 for (int c = 0; c < C; c++) v[k][c] = d_out[(int64_t)pp[k] * C + c];
+            // (two consumers of one fetch output -- the specular term and the loss both read the roughness -- send two gradients: their sum, the float
+            // autograd's add kernel would have written, is formed here instead)
+            if (d_out2) {
+#pragma unroll
+                for (int k = 0; k < R; k++)
+#pragma unroll
+                    for (int c = 0; c < C; c++) v[k][c] += d_out2[(int64_t)pp[k] * C + c];
+            }
             float wc[R];
 #pragma unroll
             for (int k = 0; k < R; k++) wc[k] = ww[k];
@@ -1100,7 +1109,7 @@ struct TailBatch { int n; TailJob j[kMaxBatch]; };
 struct FetchJob { float* lvl0; float* rest; MipDesc d; const float* uv; const float* uvda; int trilinear; int64_t P; float* out; int first, nb; };
 struct FetchBatch { int n; FetchJob j[kMaxBatch]; };
 struct GatherJob { float* lvl0; float* rest; int64_t n0; const long long* seg_key; const int* seg_start; const int* seg_count; int n_seg; const int* pix; const float* w;
-                   const float* d_out; int C, first, nb; };
+                   const float* d_out; const float* d_out2; int C, first, nb; };
 struct GatherBatch { int n; GatherJob j[kMaxBatch]; };
 struct FoldJob { float* fine; const float* rest; MipDesc d; int f; const uint32_t* mask; int first; };
 struct FoldBatch { int n; FoldJob j[kMaxBatch]; };
@@ -1148,10 +1157,10 @@ __global__ __launch_bounds__(256) void tex_gather_batch_kernel(GatherBatch b)
     const GatherJob& J = b.j[job_of_block(b, blockIdx.x)];
     const int bid = blockIdx.x - J.first;
     switch (J.C) {
-        case 1: tex_gather_body<1>(J.lvl0, J.rest, J.n0, J.seg_key, J.seg_start, J.seg_count, J.n_seg, J.pix, J.w, J.d_out, bid, J.nb); break;
-        case 2: tex_gather_body<2>(J.lvl0, J.rest, J.n0, J.seg_key, J.seg_start, J.seg_count, J.n_seg, J.pix, J.w, J.d_out, bid, J.nb); break;
-        case 3: tex_gather_body<3>(J.lvl0, J.rest, J.n0, J.seg_key, J.seg_start, J.seg_count, J.n_seg, J.pix, J.w, J.d_out, bid, J.nb); break;
-        default: tex_gather_body<4>(J.lvl0, J.rest, J.n0, J.seg_key, J.seg_start, J.seg_count, J.n_seg, J.pix, J.w, J.d_out, bid, J.nb); break;
+        case 1: tex_gather_body<1>(J.lvl0, J.rest, J.n0, J.seg_key, J.seg_start, J.seg_count, J.n_seg, J.pix, J.w, J.d_out, bid, J.nb, J.d_out2); break;
+        case 2: tex_gather_body<2>(J.lvl0, J.rest, J.n0, J.seg_key, J.seg_start, J.seg_count, J.n_seg, J.pix, J.w, J.d_out, bid, J.nb, J.d_out2); break;
+        case 3: tex_gather_body<3>(J.lvl0, J.rest, J.n0, J.seg_key, J.seg_start, J.seg_count, J.n_seg, J.pix, J.w, J.d_out, bid, J.nb, J.d_out2); break;
+        default: tex_gather_body<4>(J.lvl0, J.rest, J.n0, J.seg_key, J.seg_start, J.seg_count, J.n_seg, J.pix, J.w, J.d_out, bid, J.nb, J.d_out2); break;
     }
 }
 
@@ -1290,6 +1299,7 @@ int texir_tex_gather_backward_batch(const texir_tex_gather_job* jobs, int32_t n,
         if (q.filter_mode < 0 || q.filter_mode > 1 || q.n_seg < 0 || q.defer_last_fold < 0 || q.defer_last_fold > 2 || (q.defer_last_fold && (q.filter_mode != 1 || q.levels < 2))
             || (q.defer_last_fold == 2 && (q.levels < 4 || (q.H & 3) || (q.W & 3))))
             return bfail(TEXIR_ERR_INVALID, "%s: job %d: bad filter_mode/n_seg/defer_last_fold", fn, k);
+        if (q.d_out2 && env().mip_per_level) return bfail(TEXIR_ERR_INVALID, "%s: job %d: d_out2 is not available with TEXIR_MIP_PER_LEVEL=1", fn, k);
         if (q.rest_mask && q.defer_last_fold != 2) return bfail(TEXIR_ERR_INVALID, "%s: job %d: rest_mask needs defer_last_fold = 2", fn, k);
         if (q.rest_mask && env().mip_per_level) return bfail(TEXIR_ERR_INVALID, "%s: job %d: rest_mask is not available with TEXIR_MIP_PER_LEVEL=1 (the per-level folds read a cleared stack)", fn, k);
         if (int rc = bcheck_tex(fn, k, q.H, q.W, q.C, q.levels)) return rc;
@@ -1310,7 +1320,7 @@ int texir_tex_gather_backward_batch(const texir_tex_gather_job* jobs, int32_t n,
         if (q.n_seg <= 0) continue;
         GatherJob& J = gb.j[gb.n++];
         J.lvl0 = q.d_tex; J.rest = q.grad_rest; J.n0 = (int64_t)q.H * q.W; J.seg_key = (const long long*)q.seg_key; J.seg_start = q.seg_start; J.seg_count = q.seg_count; J.n_seg = q.n_seg;
-        J.pix = q.pix; J.w = q.weights; J.d_out = q.d_out; J.C = q.C; J.first = blocks; J.nb = grid1d(q.n_seg, 256);
+        J.pix = q.pix; J.w = q.weights; J.d_out = q.d_out; J.d_out2 = q.d_out2; J.C = q.C; J.first = blocks; J.nb = grid1d(q.n_seg, 256);
         blocks += J.nb;
     }
     if (gb.n > 0) hipLaunchKernelGGL(tex_gather_batch_kernel, dim3(blocks), dim3(256), 0, st, gb);

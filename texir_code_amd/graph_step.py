@@ -1,7 +1,8 @@
 """hipGraph capture of a whole material-estimation step (trainer/train_material.py:408-458): forward + loss + backward AND the optimiser
-step -- 14 launches in stage 2: mip pyramids + their tails + the fetches of both textures (one batched launch each, texture.texture_batch),
-specular trace, four loss passes, specular backward, one autograd add, gather + folds of both textures (batched; the gradient stacks are read
-through the view's tap mask and never cleared), one tick of the device-resident step counts and ONE fused Adam launch over both textures
+step -- 13 launches in stage 2: mip pyramids + their tails + the fetches of both textures (one batched launch each, texture.texture_batch),
+specular trace, four loss passes, specular backward, gather + folds of both textures (batched; the gradient stacks are read through the view's
+tap mask and never cleared; the roughness fetch's two gradients -- specular term and loss -- are added inside the gather), one tick of the
+device-resident step counts and ONE fused Adam launch over both textures
 (optim.FusedAdam keeps step count and learning rate in device memory, so no kernel argument changes from replay to replay).  The per-step GGX shifts still come from the CPU generator exactly as the reference draws them
 (utils/sample_util.py:102) -- they are copied into a static device buffer the captured kernels read.
 Multi-GPU runs (a gradient all-reduce between backward and step) keep the optimiser step outside the graph (step_in_graph=False)."""

@@ -225,7 +225,11 @@ class MaterialModel(nn.Module):
         # the two trilinear fetches as ONE node: one launch per kind of kernel over both textures, forward and backward (texture.texture_batch).  Made after
         # the un-mipmapped fetch, so that autograd runs its backward first: the trilinear fetch of the roughness texture decides between the sparse and the
         # dense level-0 form by `grad is None` (texture._bwd_prepare), as it did when it was a node of its own.
-        albedo, roughness = tex_fetch_batch([self.materials_a, self.materials_r], texc, texd, "linear-mipmap-linear", self.max_mip_level, cache=gb)
+        # _fan_roughness (set by forward() for stage 2; an attribute, not an argument: subclasses override this method with its reference-shaped signature):
+        # the mip-mapped roughness goes to the specular term AND to the loss; handed out as two tensors, its two gradients meet inside the gather instead of
+        # in an autograd add launch.  `roughness` is then the pair (for render, for the loss).
+        albedo, roughness = tex_fetch_batch([self.materials_a, self.materials_r], texc, texd, "linear-mipmap-linear", self.max_mip_level, cache=gb,
+                                            fanout=[1, 2] if getattr(self, "_fan_roughness", False) else None)
         # the irradiance texture is frozen and the view's uvs are constant: fetch once per view
         irr = gb.get("_irr")
         if irr is None or gb.get("_irr_version") != self.irrt._version or self.irrt.requires_grad:
@@ -247,7 +251,14 @@ class MaterialModel(nn.Module):
         pos, nrm, mask = gb["position"], gb["normal"], gb["mask"]
         self._view_consts(gb)
         # `lean_outputs` (set by the trainers' optimisation step): res["roughness_womipmap"] is None in the stages whose loss does not read it
-        albedo, roughness_womipmap, roughness, irr = self._fetch_materials(gb, womipmap=(stage == 1 or not getattr(self, "lean_outputs", False)))
+        self._fan_roughness = bool(stage == 2 and torch.is_grad_enabled())
+        try:
+            albedo, roughness_womipmap, roughness, irr = self._fetch_materials(gb, womipmap=(stage == 1 or not getattr(self, "lean_outputs", False)))
+        finally:
+            self._fan_roughness = False
+        roughness_loss = roughness
+        if isinstance(roughness, tuple):
+            roughness, roughness_loss = roughness
         cam_position = cam_position.to(self.device)
         if stage == -1:
             # light-source-only radiance texture (mat_nvdiffrast.py:141-150)
@@ -266,7 +277,7 @@ class MaterialModel(nn.Module):
             res = self.render(nrm, albedo, roughness, gb["_points"], cam_position, irr, gb["_position_out"])
         else:
             raise ValueError("MaterialModel.forward: unknown stage %r" % (stage,))
-        res.update({"empty_mask": mask, "roughness_womipmap": roughness_womipmap, "roughness": roughness})
+        res.update({"empty_mask": mask, "roughness_womipmap": roughness_womipmap, "roughness": roughness_loss})
         return res
 
     def render(self, normal, albedo, roughness, points, cam_position, irr, position_out=None):

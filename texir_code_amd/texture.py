@@ -244,7 +244,7 @@ def _gather_job(meta, taps, st):
     seg_key, starts, counts, pix, wts = taps[:5]
     A = _lib.addr
     return _lib.TexGatherJob(A(st["d_tex"]), A(st["g_rest"]), H, W, C, levels, A(seg_key), A(starts), A(counts), seg_key.numel(), A(pix), A(wts), A(st["d_out"]), mode,
-                             st["defer_levels"], A(taps[8]) if st["use_mask"] else None)
+                             st["defer_levels"], A(taps[8]) if st["use_mask"] else None, A(st.get("d_out2")))
 
 
 def _bwd_launch(meta, taps, uv, uv_da, st):
@@ -328,20 +328,24 @@ class _TexFetch(torch.autograd.Function):
 class _TexFetchBatch(torch.autograd.Function):
     """the fetches of several textures at the same coordinates (the albedo and the roughness texture of a view, models/mat_nvdiffrast.py:131-139) as ONE
     autograd node: one launch per kind of kernel over all of them, forward (mip pyramids, their tails, fetch) and backward (gather, folds).  Every
-    texture's values and gradients are those of its own _TexFetch, bit for bit."""
+    texture's values and gradients are those of its own _TexFetch, bit for bit.
+    A texture may hand its fetched values out TWICE (fan = 2: two tensors over one buffer, for two consumers -- the roughness goes to the specular term
+    and to the loss): the two gradients then arrive separately and the gather adds them while it reads them (texir_tex_gather_job.d_out2), instead of
+    autograd adding them in a launch of its own; the sum is the same float."""
 
     @staticmethod
     def forward(ctx, uv, uv_da, info, *texs):
-        # info: per texture (rest, build_from, mode, levels, owner, taps)
+        # info: per texture (rest, build_from, mode, levels, owner, taps, fan)
         P = uv.shape[0]
         outs, jobs, metas = [], [], []
         A = _lib.addr
-        for tex, (rest, build_from, mode, levels, owner, taps) in zip(texs, info):
+        for k, (tex, (rest, build_from, mode, levels, owner, taps, fan)) in enumerate(zip(texs, info)):
             H, W, C = tex.shape
             out = torch.empty((P, C), device=tex.device, dtype=torch.float32)
-            outs.append(out)
-            if not ctx.needs_input_grad[3 + len(metas)]:
-                ctx.mark_non_differentiable(out)         # (a frozen texture of the batch: its output is a constant, as its own node's would be)
+            mine = [out] + [out.detach() for _ in range(fan - 1)]          # (the further hand-outs alias the first one's memory)
+            outs += mine
+            if not ctx.needs_input_grad[3 + k]:
+                ctx.mark_non_differentiable(*mine)       # (a frozen texture of the batch: its output is a constant, as its own node's would be)
             metas.append((H, W, C, levels, mode))
             if P > 0 or build_from >= 0:
                 jobs.append(_lib.TexFetchJob(A(tex.detach()), A(rest), H, W, C, levels, build_from, mode, A(uv), A(uv_da), P, A(out)))
@@ -355,16 +359,23 @@ class _TexFetchBatch(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *d_outs):
         uv, uv_da = ctx.saved_tensors
-        grads = [None] * len(d_outs)
+        grads = [None] * len(ctx.info)
         todo = []
-        for i, d_out in enumerate(d_outs):
-            if d_out is None or not ctx.needs_input_grad[3 + i]:
+        pos = 0
+        for i, inf in enumerate(ctx.info):
+            fan = inf[6]
+            ds = [d.contiguous() for d in d_outs[pos:pos + fan] if d is not None]
+            pos += fan
+            if not ds or not ctx.needs_input_grad[3 + i]:
                 continue
-            _, _, _, _, owner, taps = ctx.info[i]
-            st = _bwd_prepare(ctx.metas[i], owner, taps, d_out.contiguous(), uv.shape[0] == 0)
+            owner, taps = inf[4], inf[5]
+            if len(ds) == 2 and (taps is None or not _BATCH):
+                ds = [ds[0] + ds[1]]                                        # (no gather to add them in: the float-atomic scatter takes one gradient)
+            st = _bwd_prepare(ctx.metas[i], owner, taps, ds[0], uv.shape[0] == 0)
             if "early" in st:
                 grads[i] = st["early"]
             else:
+                st["d_out2"] = ds[1] if len(ds) == 2 else None
                 todo.append((i, st))
         batched = [(i, st) for i, st in todo if ctx.info[i][5] is not None]
         if batched:
@@ -425,16 +436,26 @@ def texture(tex, uv, uv_da=None, filter_mode="linear", max_mip_level=13, cache=N
     return out.reshape(*lead, tex.shape[2])
 
 
-def texture_batch(texs, uv, uv_da=None, filter_mode="linear", max_mip_level=13, cache=None):
+def texture_batch(texs, uv, uv_da=None, filter_mode="linear", max_mip_level=13, cache=None, fanout=None):
     """[texture(t, uv, uv_da, ...) for t in texs] with one launch per kind of kernel over all textures (at most _lib.MAX_BATCH), forward and backward.
-    TEXIR_TEX_BATCH=0 (or a single texture) runs the plain per-texture fetches."""
+    TEXIR_TEX_BATCH=0 (or a single texture) runs the plain per-texture fetches.
+    fanout (optional, one entry per texture: 1 or 2): a texture with 2 is returned as a PAIR of tensors holding the same values, one per consumer; their
+    gradients are added inside the gather instead of by autograd (see _TexFetchBatch).  Without batching the pair is the same tensor twice."""
     texs = list(texs)
+    fan = [1] * len(texs) if fanout is None else [int(f) for f in fanout]
+    if any(f not in (1, 2) for f in fan) or len(fan) != len(texs):
+        raise ValueError("texture_batch: fanout takes one entry (1 or 2) per texture")
     if not _BATCH or len(texs) < 2 or len(texs) > _lib.MAX_BATCH:
-        return [texture(t, uv, uv_da, filter_mode, max_mip_level, cache) for t in texs]
+        single = [texture(t, uv, uv_da, filter_mode, max_mip_level, cache) for t in texs]
+        return [o if f == 1 else (o, o) for o, f in zip(single, fan)]
     lead = uv.shape[:-1]
     uvf = uv.reshape(-1, 2).to(torch.float32).contiguous()
     daf = None if uv_da is None else uv_da.reshape(-1, 4).to(torch.float32).contiguous()
     prepped = [_prep_fetch(t, uvf, daf, filter_mode, max_mip_level, cache, False) for t in texs]
-    info = tuple((rest, build_from, mode, levels, owner, taps) for _, owner, rest, build_from, mode, levels, taps in prepped)
-    outs = _TexFetchBatch.apply(uvf, daf, info, *[q[0] for q in prepped])
-    return [o.reshape(*lead, q[0].shape[2]) for o, q in zip(outs, prepped)]
+    info = tuple((rest, build_from, mode, levels, owner, taps, f) for (_, owner, rest, build_from, mode, levels, taps), f in zip(prepped, fan))
+    outs = list(_TexFetchBatch.apply(uvf, daf, info, *[q[0] for q in prepped]))
+    res = []
+    for q, f in zip(prepped, fan):
+        mine = [outs.pop(0).reshape(*lead, q[0].shape[2]) for _ in range(f)]
+        res.append(mine[0] if f == 1 else tuple(mine))
+    return res

@@ -264,7 +264,7 @@ class MatTrainRunner(RunnerBase):
 
         def after_step(epoch, data_index, out):
             loss, seg_item = out
-            if self.log_lag > 0 and torch.is_tensor(loss) and loss.is_cuda:
+            if getattr(self, "log_lag", 0) > 0 and torch.is_tensor(loss) and loss.is_cuda:
                 # (a recorded step's loss lives in a static tensor the next replay overwrites: copy it out on the stream, right behind the step)
                 host = torch.empty(2, dtype=torch.float32).pin_memory()
                 host[0:1].copy_(loss.detach().reshape(1), non_blocking=True)
@@ -275,7 +275,7 @@ class MatTrainRunner(RunnerBase):
                 ev = torch.cuda.Event()
                 ev.record()
                 pending.append((epoch, data_index, host, ev, time.time() - t0[0]))
-                drain(self.log_lag)
+                drain(getattr(self, "log_lag", 0))
             else:
                 report(epoch, data_index, loss.item(), seg_item, time.time() - t0[0])
             return max_steps is not None and self.cur_iter >= max_steps

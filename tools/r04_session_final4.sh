@@ -1,0 +1,18 @@
+#!/bin/bash
+# fourth final session of round 4 (the roughness fetch hands its values out twice and its two gradients meet in the gather: 13 launches) (material-side sources changed after tools/r04_session_final.sh; the IrT kernel sources and their PMC profiles did not): GPU suite, step trace + PMC, bench lines
+R=${GRAFT_REPO_ROOT:-/root/repo}
+out=$R/gpurun_out/r04_final4
+mkdir -p $out
+cd $R
+export TEXIR_SYNTH_CACHE=/tmp/texir_synth
+timeout 3000 python -m pytest tests -m gpu -q --durations=6 > $out/pytest_gpu.txt 2>&1
+tail -n 12 $out/pytest_gpu.txt | cut -c1-200
+bash tools/trace_mat_step.sh > $out/mat_step_trace.txt 2>&1
+tail -n 3 $out/mat_step_trace.txt | cut -c1-200
+bash tools/mat_step_pmc.sh r04_final4/matpmc > $out/mat_pmc.log 2>&1
+cp $R/profiles/pmc_mat_step.json $out/ 2>/dev/null
+head -n 1 $out/mat_pmc.log | cut -c1-300
+timeout 900 python bench.py > $out/bench_default.json 2> $out/bench_default.err
+tail -n 1 $out/bench_default.json | cut -c1-300
+TEXIR_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29561 bench.py --gpus 2 --workload c2 --steps 2 --warmup 1 --no-cpu --mat --mat-steps 10 > $out/bench_2rank_gloo_one_gpu.json 2>> $out/bench_default.err
+tail -n 1 $out/bench_2rank_gloo_one_gpu.json | cut -c1-300
