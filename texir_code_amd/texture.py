@@ -369,8 +369,8 @@ class _TexFetchBatch(torch.autograd.Function):
             if not ds or not ctx.needs_input_grad[3 + i]:
                 continue
             owner, taps = inf[4], inf[5]
-            if len(ds) == 2 and (taps is None or not _BATCH):
-                ds = [ds[0] + ds[1]]                                        # (no gather to add them in: the float-atomic scatter takes one gradient)
+            if len(ds) == 2 and (taps is None or not _BATCH or __import__("os").environ.get("TEXIR_MIP_PER_LEVEL") == "1"):
+                ds = [ds[0] + ds[1]]                # (no gather to add them in: the float-atomic scatter and the per-level reference folds take one gradient)
             st = _bwd_prepare(ctx.metas[i], owner, taps, ds[0], uv.shape[0] == 0)
             if "early" in st:
                 grads[i] = st["early"]
