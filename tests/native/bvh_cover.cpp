@@ -4,6 +4,7 @@
 // usage: bvh_cover <n_tris> <seed>      (prints "references R  checked N  misses M")
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <vector>
 
@@ -42,7 +43,21 @@ static bool find4(const BvhHost& h, int32_t node, const float* p, uint32_t prim)
         if (!in) continue;
         const int32_t c = n.c[k];
         if (c >= 0) { if (find4(h, c, p, prim)) return true; }
-        else { const uint32_t code = (uint32_t)~c; const uint32_t first = code >> 3, cnt = (code & 7u) + 1; for (uint32_t i = 0; i < cnt; i++) if (h.tris[first + i].prim == prim) return true; }
+        else {
+            const uint32_t code = (uint32_t)~c; const uint32_t first = code >> 3, cnt = (code & 7u) + 1;
+#if TEXIR_QUAD
+            // the 4-wide tree names quad records: record r owns slots 2 r, 2 r + 1, and its four vertices are those of its two stored triangles
+            for (uint32_t r = first; r < first + cnt; r++) {
+                const GpuQuad& q = h.quads[r]; const GpuTri& a = h.tris[2 * r]; const GpuTri& b = h.tris[2 * r + 1];
+                const bool geo = !std::memcmp(q.q, a.v0, 12) && !std::memcmp(q.q + 3, a.e1, 12) && !std::memcmp(q.q + 6, a.e2, 12) &&
+                                 (b.prim == 0xFFFFFFFFu ? !std::memcmp(q.q + 9, q.q + 6, 12)
+                                                        : (!std::memcmp(q.q + 9, b.v0, 12) && !std::memcmp(q.q + 6, b.e1, 12) && !std::memcmp(q.q + 3, b.e2, 12)));
+                if (geo && (a.prim == prim || b.prim == prim)) return true;
+            }
+#else
+            for (uint32_t i = 0; i < cnt; i++) if (h.tris[first + i].prim == prim) return true;
+#endif
+        }
     }
     return false;
 }
@@ -71,7 +86,7 @@ static bool find8(const BvhHost& h, int32_t node, const float* p, uint32_t prim)
 
 int main(int argc, char** argv)
 {
-    const int T = argc > 1 ? atoi(argv[1]) : 2000;
+    int T = argc > 1 ? atoi(argv[1]) : 2000;
     std::mt19937 rng(argc > 2 ? atoi(argv[2]) : 1);
     std::uniform_real_distribution<float> U(0.f, 1.f);
     std::vector<float> verts; std::vector<int32_t> tris; std::vector<float> uvs((size_t)T * 6, 0.f);
@@ -90,9 +105,42 @@ int main(int argc, char** argv)
             tris.push_back(3 * t + k);
         }
     }
+    if (argc > 3 && !strcmp(argv[3], "grid")) {
+        // a tessellated, consistently wound height field instead of the soup: T = 2 g^2 triangles over shared vertices -- the meshes whose leaves pair up into quads
+        int g = 1; while (2 * (g + 1) * (g + 1) <= T) g++;
+        verts.clear(); tris.clear();
+        for (int y = 0; y <= g; y++) for (int x = 0; x <= g; x++) { verts.push_back(x * 0.1f + 0.02f * U(rng)); verts.push_back(y * 0.1f + 0.02f * U(rng)); verts.push_back(0.3f * U(rng)); }
+        auto id = [&](int x, int y) { return y * (g + 1) + x; };
+        for (int y = 0; y < g; y++) for (int x = 0; x < g; x++) {
+            const int a = id(x, y), b = id(x + 1, y), c = id(x + 1, y + 1), d = id(x, y + 1);
+            const int rot = (x + 2 * y) % 3;                                      // (every rotation of the index triples occurs)
+            const int t0[3] = {a, b, c}, t1[3] = {a, c, d};
+            for (int k = 0; k < 3; k++) tris.push_back(t0[(k + rot) % 3]);
+            for (int k = 0; k < 3; k++) tris.push_back(t1[(k + 2 * rot) % 3]);
+        }
+        T = (int)tris.size() / 3;
+        uvs.assign((size_t)T * 6, 0.f);
+        // (the query loop below reads corner k of triangle t at verts[9 t + 3 k]: give it that view)
+        std::vector<float> flat; for (int t = 0; t < T; t++) for (int k = 0; k < 3; k++) for (int a = 0; a < 3; a++) flat.push_back(verts[3 * (size_t)tris[3 * t + k] + a]);
+        std::vector<int32_t> ft; for (int i = 0; i < 3 * T; i++) ft.push_back(i);
+        verts.swap(flat); tris.swap(ft);
+    }
     BvhHost h;
-    build_bvh(verts.data(), 3 * T, tris.data(), T, uvs.data(), h);
+    build_bvh(verts.data(), (int)verts.size() / 3, tris.data(), T, uvs.data(), h);
     long checked = 0, miss2 = 0, miss4 = 0, miss8 = 0;
+    {   // every triangle sits in exactly one slot, stored as the rotation its pad1 names
+        std::vector<int> seen((size_t)T, 0);
+        for (int64_t i = 0; i < h.n_slots; i++) {
+            const GpuTri& g = h.tris[(size_t)i];
+            if (g.prim == 0xFFFFFFFFu) continue;
+            uint32_t rot; std::memcpy(&rot, &g.pad1, 4);
+            const float* st[3] = {g.v0, g.e1, g.e2};
+            bool ok = g.prim < (uint32_t)T && rot < 3u && !seen[g.prim]++;
+            for (int k = 0; ok && k < 3; k++) ok = !std::memcmp(st[k], &verts[9 * (size_t)g.prim + 3 * ((rot + k) % 3)], 12);
+            if (!ok) miss2++;
+        }
+        for (int v : seen) if (v != 1) miss2++;
+    }
     for (int t = 0; t < T; t++) {
         const float* A = &verts[9 * (size_t)t], *B = A + 3, *C = A + 6;
         for (int s = 0; s < 24; s++) {
@@ -113,6 +161,8 @@ int main(int argc, char** argv)
 #ifdef TEXIR_COVER_BVH8
     if (!h.nodes8.empty()) printf("8-wide: %zu nodes (4-wide: %zu), depth %d (4-wide: %d), misses %ld\n", h.nodes8.size(), h.nodes4.size(), h.max_depth8, h.max_depth4, miss8);
 #endif
-    printf("references %zu  checked %ld  misses %ld %ld\n", h.tris.size() - 1, checked, miss2, miss4);
+    long paired = 0;
+    for (size_t i = 1; i < (size_t)h.n_slots; i += 2) if (!h.quads.empty() && h.tris[i].prim != 0xFFFFFFFFu) paired++;
+    printf("triangles %d  slots %ld  paired records %ld  checked %ld  misses %ld %ld\n", T, (long)h.n_slots, paired, checked, miss2, miss4);
     return (miss2 || miss4 || miss8) ? 1 : 0;
 }

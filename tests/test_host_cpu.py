@@ -372,7 +372,7 @@ def test_rle_hdr_decoder_on_a_hand_assembled_byte_string(tmp_path):
 def test_bvh_builder_keeps_every_triangle_point_reachable(tmp_path):
     """tests/native/bvh_cover.cpp: the product's host BVH builder compiled with the host compiler; point queries at corners, edge points and interior
     points of every triangle (small ones, long thin rotated slats, large flat ones) must reach a leaf that holds the triangle, in the binary and in the
-    4-wide float-box tree.  (Written for the reference pre-splitting experiment, tools/experiments/bvh_presplit.patch -- whose split pieces it also
+    4-wide float-box tree (whose leaves name quad records).  (Written for the reference pre-splitting experiment, tools/experiments/bvh_presplit.patch -- whose split pieces it also
     covered, TEXIR_PRESPLIT = 30 / 150 -- and kept as the builder's own coverage check.)"""
     import subprocess
     csrc = os.path.join(ROOT, "texir_code_amd", "csrc")
@@ -382,3 +382,7 @@ def test_bvh_builder_keeps_every_triangle_point_reachable(tmp_path):
     for n, seed in ((6000, 3), (20000, 7)):
         out = subprocess.check_output([exe, str(n), str(seed)]).decode().split()
         assert out[-2:] == ["0", "0"] and int(out[1]) == n, out
+    # a tessellated mesh with shared vertices: its 2-triangle leaves pair up into quad records (bvh_build.h) -- every triangle in exactly one slot, stored
+    # as the rotation its record needs, the records' four vertices those of their two triangles
+    out = subprocess.check_output([exe, "20000", "5", "grid"]).decode().split()
+    assert out[-2:] == ["0", "0"] and int(out[5]) > 0.8 * int(out[1]) / 2, out

@@ -28,7 +28,9 @@ struct Box {
 
 struct Tmp {
     Box box;
-    int first = 0, count = 0;           // leaf payload
+    int first = 0, count = 0;           // leaf payload: a run of `order`
+    int slot_first = 0, slot_count = 0; // ... as leaf-order slots (assign_slots)
+    int rec_first = 0, rec_count = 0;   // ... as quad records (TEXIR_QUAD)
     std::unique_ptr<Tmp> l, r;
     int depth_below = 0;
 };
@@ -114,7 +116,16 @@ std::unique_ptr<Tmp> build(const Ctx& c, int first, int count, int depth, int pa
     return n;
 }
 
-inline int32_t leaf_code(const Tmp* t) { return ~(int32_t)(((uint32_t)t->first << 3) | (uint32_t)(t->count - 1)); }
+// leaf codes (bvh_build.h): the binary tree names leaf-order slots, the 4-wide tree names quad records when the library has them
+inline int32_t leaf_code(const Tmp* t) { return ~(int32_t)(((uint32_t)t->slot_first << 3) | (uint32_t)(t->slot_count - 1)); }
+inline int32_t leaf_code4(const Tmp* t)
+{
+#if TEXIR_QUAD
+    return ~(int32_t)(((uint32_t)t->rec_first << 3) | (uint32_t)(t->rec_count - 1));
+#else
+    return leaf_code(t);
+#endif
+}
 
 void put_box(GpuNode& g, int slot, const Box& b)
 {
@@ -216,7 +227,7 @@ int32_t emit4(const Tmp* t, Emit4Ctx& cx, int depth)
         kids[best] = o->l.get(); kids[nk++] = o->r.get();
     }
     int32_t codes[4];
-    for (int k = 0; k < nk; k++) codes[k] = kids[k]->count ? leaf_code(kids[k]) : emit4(kids[k], cx, depth + 1);
+    for (int k = 0; k < nk; k++) codes[k] = kids[k]->count ? leaf_code4(kids[k]) : emit4(kids[k], cx, depth + 1);
     emit4_fill((*cx.out)[idx], t->box, kids, nk, codes, cx.dummy_leaf, cx.slack);
     emit4f_fill((*cx.out4f)[idx], kids, nk, codes, cx.dummy_leaf, cx.slack);
     return idx;
@@ -298,6 +309,52 @@ void build_bvh(const float* verts, int V, const int32_t* tris, int T, const floa
     while ((1u << par_levels) < hw && par_levels < 5) par_levels++;
     std::unique_ptr<Tmp> root = build(c, 0, T, 0, par_levels);
 
+    // ---- leaf-order slots and quad records (bvh_build.h) ----
+    struct Rec { int p0, r0, p1, r1; };                    // triangle, rotation; p1 < 0: no partner
+    std::vector<Rec> recs;
+    recs.reserve((size_t)T);
+    {
+        // two triangles pair up when they share an edge that they walk in OPPOSITE directions (a consistently wound mesh): both can then be stored as
+        // rotations of themselves, triangle 0 = (q0, q1, q2), triangle 1 = (q3, q2, q1)
+        auto vtx = [&](int p, int k) { return verts + 3 * (size_t)tris[3 * (size_t)p + k]; };
+        auto same = [&](const float* a, const float* b) { return std::memcmp(a, b, 3 * sizeof(float)) == 0; };
+        auto pair_up = [&](int p, int q, int& r0, int& r1) {
+#if TEXIR_QUAD
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+                if (same(vtx(p, i), vtx(q, (j + 1) % 3)) && same(vtx(p, (i + 1) % 3), vtx(q, j))) {
+                    // degenerate partners (a repeated vertex) stay single: their "shared edge" is not one
+                    if (same(vtx(p, i), vtx(p, (i + 1) % 3)) || same(vtx(p, (i + 2) % 3), vtx(q, (j + 2) % 3))) return false;
+                    r0 = (i + 2) % 3; r1 = (j + 2) % 3; return true;
+                }
+#endif
+            (void)p; (void)q; (void)r0; (void)r1;
+            return false;
+        };
+        std::vector<Tmp*> stack{root.get()};
+        while (!stack.empty()) {                            // leaves in emission order (left to right = increasing `first`)
+            Tmp* t = stack.back(); stack.pop_back();
+            if (!t->count) { stack.push_back(t->r.get()); stack.push_back(t->l.get()); continue; }
+            t->rec_first = (int)recs.size();
+            bool last_single = false;
+            for (int i = t->first; i < t->first + t->count;) {
+                int r0 = 0, r1 = 0;
+                if (TEXIR_QUAD && i + 1 < t->first + t->count && pair_up(order[i], order[i + 1], r0, r1)) { recs.push_back(Rec{order[i], r0, order[i + 1], r1}); i += 2; last_single = false; }
+                else if (TEXIR_QUAD) { recs.push_back(Rec{order[i], 0, -1, 0}); i += 1; last_single = true; }
+                else { recs.push_back(Rec{order[i], 0, -1, 0}); i += 1; }
+            }
+            t->rec_count = (int)recs.size() - t->rec_first;
+#if TEXIR_QUAD
+            t->slot_first = 2 * t->rec_first; t->slot_count = 2 * t->rec_count - (last_single ? 1 : 0);
+#else
+            (void)last_single;
+            t->slot_first = t->rec_first; t->slot_count = t->rec_count;
+#endif
+        }
+    }
+    const size_t n_rec = recs.size();
+    const size_t n_slots = TEXIR_QUAD ? 2 * n_rec : n_rec;
+    out.n_slots = (int64_t)n_slots;
+
     out.nodes.clear();
     out.nodes.reserve((size_t)T);
     if (root->count) {
@@ -318,34 +375,46 @@ void build_bvh(const float* verts, int V, const int32_t* tris, int T, const floa
     out.nodes4.reserve((size_t)T / 2 + 16);
     out.nodes4f.clear();
     out.nodes4f.reserve((size_t)T / 2 + 16);
-    // slot T holds a degenerate (all-zero) triangle: the target of unused child slots
-    Emit4Ctx cx{slack, &out.nodes4, &out.nodes4f, ~(int32_t)(((uint32_t)T << 3) | 0u), 0};
+    // the slot (quad libraries: the record) after the last one holds a degenerate all-zero triangle (record): the target of unused child slots
+    Emit4Ctx cx{slack, &out.nodes4, &out.nodes4f, ~(int32_t)(((uint32_t)(TEXIR_QUAD ? n_rec : n_slots) << 3) | 0u), 0};
     emit4(root.get(), cx, 1);
     out.max_depth4 = cx.max_depth;
     relayout4(out.nodes4, out.nodes4f, env().bvh_layout);
-    out.tris.resize((size_t)T + 1);
-    std::memset(&out.tris[T], 0, sizeof(GpuTri));
-    out.tris[T].prim = 0xFFFFFFFFu;
-    out.uvs.resize((size_t)T + 1);
-    std::memset(&out.uvs[T], 0, sizeof(GpuTriUV));
-    for (int i = 0; i < T; i++) {
-        int p = order[i];
-        const float* a = verts + 3 * (size_t)tris[3 * (size_t)p];
-        const float* b = verts + 3 * (size_t)tris[3 * (size_t)p + 1];
-        const float* cc = verts + 3 * (size_t)tris[3 * (size_t)p + 2];
-        GpuTri& g = out.tris[i];
+    // slot data in STORED corner order: stored corner k = the caller's corner (rot + k) % 3
+    out.tris.assign(n_slots + 1, GpuTri{});
+    out.uvs.assign(n_slots + 1, GpuTriUV{});
+    for (auto& g : out.tris) g.prim = 0xFFFFFFFFu;          // holes (the odd slot of a single) and the dummy: degenerate, never hit
+    auto put_slot = [&](size_t slot, int p, int rot) {
+        GpuTri& g = out.tris[slot];
+        const float* v[3];
+        for (int k = 0; k < 3; k++) v[k] = verts + 3 * (size_t)tris[3 * (size_t)p + (rot + k) % 3];
 #if TEXIR_TRI_WATERTIGHT
-        for (int k = 0; k < 3; k++) { g.v0[k] = a[k]; g.e1[k] = b[k]; g.e2[k] = cc[k]; }         // the vertices themselves, bit for bit
+        for (int k = 0; k < 3; k++) { g.v0[k] = v[0][k]; g.e1[k] = v[1][k]; g.e2[k] = v[2][k]; }         // the vertices themselves, bit for bit
 #else
-        for (int k = 0; k < 3; k++) { g.v0[k] = a[k]; g.e1[k] = b[k] - a[k]; g.e2[k] = cc[k] - a[k]; }
+        for (int k = 0; k < 3; k++) { g.v0[k] = v[0][k]; g.e1[k] = v[1][k] - v[0][k]; g.e2[k] = v[2][k] - v[0][k]; }
 #endif
         g.prim = (uint32_t)p;
-        const float* uv = tri_uvs + 6 * (size_t)p;
-        g.pad1 = g.pad2 = 0.f;
-        GpuTriUV& u = out.uvs[i];
-        std::memcpy(u.uv, uv, sizeof(float) * 6);
+        const uint32_t r = (uint32_t)rot;
+        std::memcpy(&g.pad1, &r, 4); g.pad2 = 0.f;
+        GpuTriUV& u = out.uvs[slot];
+        for (int k = 0; k < 3; k++) { const float* uv = tri_uvs + 6 * (size_t)p + 2 * (size_t)((rot + k) % 3); u.uv[2 * k] = uv[0]; u.uv[2 * k + 1] = uv[1]; }
         u.uv[6] = u.uv[7] = 0.f;
+    };
+#if TEXIR_QUAD
+    out.quads.assign(n_rec + 1, GpuQuad{});
+    for (size_t r = 0; r < n_rec; r++) {
+        const Rec& rc = recs[r];
+        put_slot(2 * r, rc.p0, rc.r0);
+        if (rc.p1 >= 0) put_slot(2 * r + 1, rc.p1, rc.r1);
+        GpuQuad& q = out.quads[r];
+        const GpuTri& a = out.tris[2 * r];
+        for (int k = 0; k < 3; k++) { q.q[k] = a.v0[k]; q.q[3 + k] = a.e1[k]; q.q[6 + k] = a.e2[k]; }
+        // (q3: the partner's first stored corner -- its other two are q2, q1 by construction; a single repeats q2: a triangle without area)
+        for (int k = 0; k < 3; k++) q.q[9 + k] = rc.p1 >= 0 ? out.tris[2 * r + 1].v0[k] : a.e2[k];
     }
+#else
+    for (size_t r = 0; r < n_rec; r++) put_slot(r, recs[r].p0, 0);
+#endif
 }
 
 }  // namespace texir

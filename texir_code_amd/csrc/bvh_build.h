@@ -35,6 +35,23 @@ struct alignas(16) GpuTri {
 static_assert(sizeof(GpuTri) == 48, "triangle must be 48 bytes");
 constexpr int kTriQuads = 3;          // float4s per triangle record
 
+// Quad leaves (TEXIR_QUAD = 1, default; watertight intersector only): the two triangles of a leaf that share an edge -- in a tessellated mesh nearly every
+// 2-triangle leaf -- are stored as ONE 48-byte record of their four vertices (q0, q1, q2, q3): triangle 0 = (q0, q1, q2), triangle 1 = (q3, q2, q1), the
+// shared edge being (q1, q2).  The 4-wide traversal fetches three 16-byte words per leaf record instead of six 12-byte vertices per pair, shears four
+// vertices instead of six and evaluates five edge functions instead of six (the shared edge's value is the neighbour's negated, exactly).
+//   Slots.  A record owns the two leaf-order slots 2 r and 2 r + 1 (sc.tris, sc.uvs, corner normals; a hit carries its slot): a triangle without a
+//   partner (or whose partner would have to be mirrored) is a record whose q3 repeats q2 -- its second triangle has no area and accepts no ray -- and
+//   whose odd slot holds the degenerate dummy triangle.  Each triangle is stored ROTATED so that the shared edge comes to lie where the record wants it:
+//   slot data (vertices, corner uvs, corner normals) are all in the stored order, GpuTri::pad1 holds the rotation (stored corner k = the caller's
+//   corner (rot + k) % 3), and only a barycentric that leaves the library (texir_trace_shade's primitive uvs) is turned back.
+//   Leaf codes: the binary tree's name slots (first slot << 3 | slots - 1: a dummy slot in the range is tested and never hit), the 4-wide tree's name
+//   records (first record << 3 | records - 1).
+#ifndef TEXIR_QUAD
+#define TEXIR_QUAD TEXIR_TRI_WATERTIGHT
+#endif
+struct alignas(16) GpuQuad { float q[12]; };          // q0.xyz q1.xyz q2.xyz q3.xyz
+static_assert(sizeof(GpuQuad) == 48, "quad record must be 48 bytes");
+
 // 32-byte leaf-ordered corner uvs: (uv0, uv1), (uv2, 0, 0)
 struct alignas(16) GpuTriUV {
     float uv[8];
@@ -74,8 +91,10 @@ struct BvhHost {
     std::vector<GpuNode> nodes;
     std::vector<GpuNode4> nodes4;
     std::vector<GpuNode4F> nodes4f;     // index-for-index with nodes4
-    std::vector<GpuTri> tris;
+    std::vector<GpuTri> tris;           // by leaf-order slot (+ one degenerate dummy at the end)
     std::vector<GpuTriUV> uvs;
+    std::vector<GpuQuad> quads;         // TEXIR_QUAD: by record (+ one all-zero dummy at the end); record r owns slots 2 r, 2 r + 1
+    int64_t n_slots = 0;                // leaf-order slots (= triangles without TEXIR_QUAD)
     int max_depth = 0, max_depth4 = 0;
 };
 

@@ -21,13 +21,14 @@ struct texir_scene {
     int device = 0;
     SceneDev dev{};
     void* d_nodes4 = nullptr; void* d_nodes4f = nullptr;
-    void* d_nodes = nullptr; void* d_tris = nullptr; void* d_uvs = nullptr; float* d_tex = nullptr;
+    void* d_nodes = nullptr; void* d_tris = nullptr; void* d_quads = nullptr; void* d_uvs = nullptr; float* d_tex = nullptr;
     float* d_tex_tiled = nullptr;        // retiled copy read by the hit shader (texture layouts 1, 2); d_tex stays the row-major master
     size_t tiled_bytes = 0;
-    int64_t n_nodes = 0, n_nodes4 = 0, n_tris = 0, max_depth = 0;
+    int64_t n_nodes = 0, n_nodes4 = 0, n_tris = 0, n_slots = 0 /* leaf-order slots behind d_tris / d_uvs / d_cnrm: = n_tris, or 2 per quad record (bvh_build.h) */, n_quads = 0, max_depth = 0;
     int width = 2;
     size_t tex_bytes = 0;
-    std::vector<uint32_t> slot_prim;     // leaf slot -> primitive id (host copy, for per-corner attribute uploads)
+    std::vector<uint32_t> slot_prim;     // leaf slot -> primitive id (host copy, for per-corner attribute uploads; 0xFFFFFFFF: an empty slot)
+    std::vector<uint8_t> slot_rot;       // leaf slot -> rotation of the stored corners (stored corner k = the caller's corner (rot + k) % 3)
     void* d_cnrm = nullptr;              // leaf-ordered corner normals, 3 x float4 per triangle
     float* d_scratch = nullptr;          // texir_scene_reserve_scratch: the IrT partial-sum scratch of RECORDED launches (eager launches allocate stream-ordered)
     size_t scratch_bytes = 0;
@@ -78,7 +79,7 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
     if (!verts || !tris || !tri_uvs || !hdr_tex || !out) return fail(TEXIR_ERR_INVALID, "texir_scene_create: null argument");
     if (V <= 0 || T <= 0 || Ht <= 0 || Wt <= 0) return fail(TEXIR_ERR_INVALID, "texir_scene_create: empty mesh or texture");
     // the traversal addresses nodes and triangles with 32-bit byte offsets (64-byte nodes, 48-byte triangle records)
-    if ((uint64_t)(T + 1) * sizeof(GpuTri) >= (1ull << 32)) return fail(TEXIR_ERR_INVALID, "texir_scene_create: too many triangles (%d; limit 89 M)", (int)T);
+    if ((uint64_t)(2 * (uint64_t)T + 1) * sizeof(GpuTri) >= (1ull << 32)) return fail(TEXIR_ERR_INVALID, "texir_scene_create: too many triangles (%d; limit 44 M)", (int)T);
     for (int64_t i = 0; i < 3 * (int64_t)T; i++)
         if (tris[i] < 0 || tris[i] >= V) return fail(TEXIR_ERR_INVALID, "texir_scene_create: triangle index %d out of range", (int)tris[i]);
     HIP_TRY(hipSetDevice(device));
@@ -86,8 +87,9 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
     try { build_bvh(verts, V, tris, T, tri_uvs, h); } catch (const std::bad_alloc&) { return fail(TEXIR_ERR_NOMEM, "BVH build: out of host memory"); }
     texir_scene* s = new (std::nothrow) texir_scene;
     if (!s) return fail(TEXIR_ERR_NOMEM, "out of host memory");
-    s->slot_prim.resize((size_t)T);
-    for (int i = 0; i < T; i++) s->slot_prim[i] = h.tris[i].prim;
+    s->n_slots = h.n_slots; s->n_quads = (int64_t)h.quads.size();
+    s->slot_prim.resize((size_t)h.n_slots); s->slot_rot.resize((size_t)h.n_slots);
+    for (int64_t i = 0; i < h.n_slots; i++) { s->slot_prim[i] = h.tris[i].prim; uint32_t r; std::memcpy(&r, &h.tris[i].pad1, 4); s->slot_rot[i] = (uint8_t)(r % 3u); }
     s->device = device; s->n_nodes = (int64_t)h.nodes.size(); s->n_tris = T; s->max_depth = h.max_depth;
     s->tex_bytes = sizeof(float) * 3 * (size_t)Ht * Wt;
     auto bail = [&](hipError_t e, const char* what) { texir_scene_destroy(s); return fail(TEXIR_ERR_HIP, "%s: %s", what, hipGetErrorString(e)); };
@@ -108,6 +110,10 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
     }
     if ((e = hipMalloc(&s->d_nodes, h.nodes.size() * sizeof(GpuNode))) != hipSuccess) return bail(e, "hipMalloc nodes");
     if ((e = hipMalloc(&s->d_tris, h.tris.size() * sizeof(GpuTri))) != hipSuccess) return bail(e, "hipMalloc tris");
+    if (!h.quads.empty()) {
+        if ((e = hipMalloc(&s->d_quads, h.quads.size() * sizeof(GpuQuad))) != hipSuccess) return bail(e, "hipMalloc quads");
+        if ((e = hipMemcpy(s->d_quads, h.quads.data(), h.quads.size() * sizeof(GpuQuad), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload quads");
+    }
     if (!h.uvs.empty() && (e = hipMalloc(&s->d_uvs, h.uvs.size() * sizeof(GpuTriUV))) != hipSuccess) return bail(e, "hipMalloc uvs");
     if ((e = hipMalloc((void**)&s->d_tex, s->tex_bytes)) != hipSuccess) return bail(e, "hipMalloc texture");
     if ((e = hipMalloc((void**)&s->d_work, texir_scene::kWorkSlots * 8 * kWorkStride * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc work counters");
@@ -116,7 +122,7 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
     if (!h.uvs.empty() && (e = hipMemcpy(s->d_uvs, h.uvs.data(), h.uvs.size() * sizeof(GpuTriUV), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload uvs");
     if ((e = hipMemcpy(s->d_tex, hdr_tex, s->tex_bytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "upload texture");
     s->dev.nodes4 = (const float4*)s->d_nodes4; s->dev.nodes4f = (const float4*)s->d_nodes4f;
-    s->dev.nodes = (const float4*)s->d_nodes; s->dev.tris = (const float4*)s->d_tris; s->dev.uvs = (const float4*)s->d_uvs;
+    s->dev.nodes = (const float4*)s->d_nodes; s->dev.tris = (const float4*)s->d_tris; s->dev.quads = (const float4*)s->d_quads; s->dev.uvs = (const float4*)s->d_uvs;
     s->dev.tex = s->d_tex; s->dev.Ht = Ht; s->dev.Wt = Wt; s->dev.tex_layout = 0; s->dev.tiles_x = 0; s->dev.sched_weight = 0;
     // hit-shader texture layout: 2 (one 128-byte line per bilinear footprint) by default, TEXIR_TEX_LAYOUT=0|1|2 for A/B runs
     const int layout = env().tex_layout;
@@ -140,6 +146,7 @@ int texir_scene_destroy(texir_scene* s)
     if (s->d_nodes4f) (void)hipFree(s->d_nodes4f);
     if (s->d_nodes) (void)hipFree(s->d_nodes);
     if (s->d_tris) (void)hipFree(s->d_tris);
+    if (s->d_quads) (void)hipFree(s->d_quads);
     if (s->d_uvs) (void)hipFree(s->d_uvs);
     if (s->d_tex) (void)hipFree(s->d_tex);
     if (s->d_tex_tiled) (void)hipFree(s->d_tex_tiled);
@@ -164,7 +171,7 @@ int texir_scene_info(const texir_scene* s, int64_t out[8])
     if (!s || !out) return fail(TEXIR_ERR_INVALID, "texir_scene_info: null argument");
     out[0] = s->width == 4 ? s->n_nodes4 : s->n_nodes; out[1] = s->n_tris; out[2] = s->max_depth;
     out[3] = s->width == 4 ? s->n_nodes4 * (int64_t)(sizeof(GpuNode4) + (s->d_nodes4f ? sizeof(GpuNode4F) : 0)) : s->n_nodes * (int64_t)sizeof(GpuNode);
-    out[4] = s->n_tris * (int64_t)sizeof(GpuTri); out[5] = s->d_uvs ? s->n_tris * (int64_t)sizeof(GpuTriUV) : 0; out[6] = (int64_t)(s->d_tex_tiled ? s->tiled_bytes : s->tex_bytes); out[7] = s->device;
+    out[4] = s->n_slots * (int64_t)sizeof(GpuTri) + s->n_quads * (int64_t)sizeof(GpuQuad); out[5] = s->d_uvs ? s->n_slots * (int64_t)sizeof(GpuTriUV) : 0; out[6] = (int64_t)(s->d_tex_tiled ? s->tiled_bytes : s->tex_bytes); out[7] = s->device;
     return TEXIR_OK;
 }
 
@@ -175,8 +182,10 @@ int texir_scene_prefetch(const texir_scene* s, int32_t what, int32_t blocks, voi
     uint32_t* sink = reinterpret_cast<uint32_t*>(s->d_work);         // (never written in practice; any device word will do)
     if ((what & 1) && s->d_nodes4) HIP_TRY(launch_prefetch(s->d_nodes4, (size_t)s->n_nodes4 * sizeof(GpuNode4), blocks, sink, (hipStream_t)stream));
     if ((what & 2) && s->d_nodes4f) HIP_TRY(launch_prefetch(s->d_nodes4f, (size_t)s->n_nodes4 * sizeof(GpuNode4F), blocks, sink, (hipStream_t)stream));
-    if ((what & 4) && s->d_tris) HIP_TRY(launch_prefetch(s->d_tris, (size_t)s->n_tris * sizeof(GpuTri), blocks, sink, (hipStream_t)stream));
-    if ((what & 8) && s->d_uvs) HIP_TRY(launch_prefetch(s->d_uvs, (size_t)s->n_tris * sizeof(GpuTriUV), blocks, sink, (hipStream_t)stream));
+    // (what the traversal reads of the triangles: the quad records where the library has them, else the leaf-ordered triangles)
+    if ((what & 4) && s->d_quads && s->width == 4) HIP_TRY(launch_prefetch(s->d_quads, (size_t)s->n_quads * sizeof(GpuQuad), blocks, sink, (hipStream_t)stream));
+    else if ((what & 4) && s->d_tris) HIP_TRY(launch_prefetch(s->d_tris, (size_t)s->n_slots * sizeof(GpuTri), blocks, sink, (hipStream_t)stream));
+    if ((what & 8) && s->d_uvs) HIP_TRY(launch_prefetch(s->d_uvs, (size_t)s->n_slots * sizeof(GpuTriUV), blocks, sink, (hipStream_t)stream));
     return TEXIR_OK;
 }
 
@@ -344,10 +353,14 @@ int texir_scene_set_corner_normals(texir_scene* s, const float* cn)
 {
     if (!s || !cn) return fail(TEXIR_ERR_INVALID, "texir_scene_set_corner_normals: null argument");
     HIP_TRY(hipSetDevice(s->device));
-    std::vector<float> buf((size_t)s->n_tris * 12);
-    for (int64_t i = 0; i < s->n_tris; i++) {
+    std::vector<float> buf((size_t)s->n_slots * 12, 0.f);
+    for (int64_t i = 0; i < s->n_slots; i++) {
+        if (s->slot_prim[i] == 0xFFFFFFFFu) continue;                            // an empty slot (bvh_build.h): never hit
         const float* src = cn + 9 * (size_t)s->slot_prim[i];
-        for (int k = 0; k < 3; k++) { buf[12 * i + 4 * k] = src[3 * k]; buf[12 * i + 4 * k + 1] = src[3 * k + 1]; buf[12 * i + 4 * k + 2] = src[3 * k + 2]; buf[12 * i + 4 * k + 3] = 0.f; }
+        for (int k = 0; k < 3; k++) {                                            // stored corner k = the caller's corner (rot + k) % 3
+            const float* c = src + 3 * ((s->slot_rot[i] + k) % 3);
+            buf[12 * i + 4 * k] = c[0]; buf[12 * i + 4 * k + 1] = c[1]; buf[12 * i + 4 * k + 2] = c[2]; buf[12 * i + 4 * k + 3] = 0.f;
+        }
     }
     if (!s->d_cnrm) HIP_TRY(hipMalloc(&s->d_cnrm, buf.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(s->d_cnrm, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice));

@@ -16,7 +16,8 @@ struct SceneDev {
     const float4* nodes4f; // GpuNode4F (float child planes of the same tree, index for index) -- read through the scalar cache by wave-uniform
                            // node steps; null = every node step per lane (TEXIR_UNIFORM_FLOAT=0)
     const float4* nodes;   // GpuNode as 4 x float4
-    const float4* tris;    // GpuTri as kTriQuads x float4
+    const float4* tris;    // GpuTri as kTriQuads x float4, by leaf-order slot
+    const float4* quads;   // GpuQuad as 3 x float4, by record (TEXIR_QUAD: what the 4-wide tree's leaves name; record r owns slots 2 r, 2 r + 1)
     const float4* uvs;     // GpuTriUV as 2 x float4
     const float* tex;      // [Ht,Wt,3] row-major (layout 0), or the retiled copy the hit shader reads (layouts 1, 2: see shade_hit)
     int Ht, Wt;
@@ -434,6 +435,47 @@ __device__ __forceinline__ Hit trace_core(const SceneDev& sc, float ox, float oy
     auto leaf_body = [&](auto KZ) __attribute__((always_inline)) {
         constexpr int kzc = decltype(KZ)::value;
         const uint32_t code = ~(uint32_t)node;
+#if TEXIR_QUAD
+        if constexpr (WIDTH == 4) {
+            // Quad records (bvh_build.h): three 16-byte words hold the four vertices of two triangles that share the edge (q1, q2): triangle 0 = (q0, q1, q2),
+            // triangle 1 = (q3, q2, q1).  Four vertices are sheared instead of six, five edge functions evaluated instead of six -- the shared edge's value
+            // for triangle 1 is triangle 0's negated (edge2_exact is antisymmetric bit for bit) -- and each triangle then goes through exactly the
+            // arithmetic of the single-triangle test below, in its stored corner order.
+            const int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
+            for (int r = first; r < first + cnt; r++) {
+                const float4* qp = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.quads) + (uint32_t)r * 48u);
+                const float4 w0 = qp[0], w1 = qp[1], w2 = qp[2];
+                if (STATS) { n_tris += 2; if (wave_iters && first_active()) wave_iters[1]++; }
+                auto shear = [&](float p0, float p1, float p2, float& X, float& Y, float& Z) __attribute__((always_inline)) {
+                    const float q0 = p0 - ox, q1 = p1 - oy, q2 = p2 - oz;
+                    float qz, qx, qy;
+                    if constexpr (kzc == 0) { qz = q0; qx = q1; qy = q2; }
+                    else if constexpr (kzc == 1) { qz = q1; qx = q2; qy = q0; }
+                    else if constexpr (kzc == 2) { qz = q2; qx = q0; qy = q1; }
+                    else { qz = kz == 0 ? q0 : (kz == 1 ? q1 : q2); qx = kz == 0 ? q1 : (kz == 1 ? q2 : q0); qy = kz == 0 ? q2 : (kz == 1 ? q0 : q1); }
+                    X = __builtin_fmaf(-Sx, qz, qx); Y = __builtin_fmaf(-Sy, qz, qy); Z = Sz * qz;
+                };
+                float X0, Y0, Z0, X1, Y1, Z1, X2, Y2, Z2, X3, Y3, Z3;
+                shear(w0.x, w0.y, w0.z, X0, Y0, Z0); shear(w0.w, w1.x, w1.y, X1, Y1, Z1); shear(w1.z, w1.w, w2.x, X2, Y2, Z2); shear(w2.y, w2.z, w2.w, X3, Y3, Z3);
+                const float E12 = edge2_exact(X1, Y1, X2, Y2);
+                auto accept = [&](float U, float V, float W, float Az, float Bz, float Cz, int slot) __attribute__((always_inline)) {
+                    const float mn = fminf(fminf(U, V), W), mxw = fmaxf(fmaxf(U, V), W);
+                    const float det = U + V + W;
+                    const float inv = __builtin_amdgcn_rcpf(det);
+                    const float t = (U * Az + V * Bz + W * Cz) * inv;
+                    const float u = V * inv, v = W * inv;
+                    const bool ok = !((mn < 0.f) & (mxw > 0.f)) & (det != 0.f) & (t > 0.f) & (t < h.t);
+                    if (ok) { h.t = t; h.u = u; h.v = v; h.slot = slot; }
+                };
+                // triangle 0 = (A, B, C) = (q0, q1, q2): U = e(B, C), V = e(C, A), W = e(A, B)
+                accept(E12, edge2_exact(X2, Y2, X0, Y0), edge2_exact(X0, Y0, X1, Y1), Z0, Z1, Z2, 2 * r);
+                // triangle 1 = (A, B, C) = (q3, q2, q1): U = e(q2, q1) = -e(q1, q2), V = e(q1, q3), W = e(q3, q2)
+                accept(-E12, edge2_exact(X1, Y1, X3, Y3), edge2_exact(X3, Y3, X2, Y2), Z3, Z2, Z1, 2 * r + 1);
+            }
+            node = pop();
+            return;
+        }
+#endif
         const int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
         for (int i = first; i < first + cnt; i++) {
             const float4* tp = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.tris) + (uint32_t)i * (uint32_t)(16 * kTriQuads));

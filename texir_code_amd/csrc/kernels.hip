@@ -432,7 +432,17 @@ __global__ __launch_bounds__(kBlock) void trace_shade_kernel(SceneDev sc, const 
         rad[3 * r] = L[0]; rad[3 * r + 1] = L[1]; rad[3 * r + 2] = L[2];
         if (t_hit) t_hit[r] = h.t;
         if (prim) prim[r] = h.slot >= 0 ? tri_prim(sc, h.slot) : 0xFFFFFFFFu;
-        if (puv) { puv[2 * r] = h.u; puv[2 * r + 1] = h.v; }
+        if (puv) {
+            // the caller's barycentrics (weights of ITS corners 1 and 2): the slot stores its corners rotated (bvh_build.h), stored corner k = corner (rot + k) % 3
+            float u = h.u, v = h.v;
+            if (h.slot >= 0) {
+                const uint32_t rot = __float_as_uint(sc.tris[3 * (size_t)h.slot + 1].w);
+                const float w = 1.f - u - v;
+                if (rot == 1u) { const float u1 = w, v1 = u; u = u1; v = v1; }           // stored (c1, c2, c0): weights (w, u, v) of (c1, c2, c0)
+                else if (rot == 2u) { const float u1 = v, v1 = w; u = u1; v = v1; }      // stored (c2, c0, c1)
+            }
+            puv[2 * r] = u; puv[2 * r + 1] = v;
+        }
     }
 }
 
