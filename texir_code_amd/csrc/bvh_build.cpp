@@ -336,6 +336,13 @@ void build_bvh(const float* verts, int V, const int32_t* tris, int T, const floa
             if (!t->count) { stack.push_back(t->r.get()); stack.push_back(t->l.get()); continue; }
             t->rec_first = (int)recs.size();
             bool last_single = false;
+            // (leaves of more than two triangles, TEXIR_MAX_LEAF: bring partners next to each other first -- the order inside a leaf is free)
+            if (TEXIR_QUAD && t->count > 2)
+                for (int i = t->first; i + 1 < t->first + t->count; i++) {
+                    int r0, r1, j = i + 1;
+                    while (j < t->first + t->count && !pair_up(order[i], order[j], r0, r1)) j++;
+                    if (j < t->first + t->count) { std::swap(order[i + 1], order[j]); i++; }
+                }
             for (int i = t->first; i < t->first + t->count;) {
                 int r0 = 0, r1 = 0;
                 if (TEXIR_QUAD && i + 1 < t->first + t->count && pair_up(order[i], order[i + 1], r0, r1)) { recs.push_back(Rec{order[i], r0, order[i + 1], r1}); i += 2; last_single = false; }

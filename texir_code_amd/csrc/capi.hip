@@ -44,11 +44,15 @@ struct texir_scene {
 };
 
 // the kernel-argument view of a scene for one launch: the immutable part + the scheduler weight in force now
-static SceneDev dev_of(const texir_scene* s)
+// (`coherent`: the launch traces direction cells -- texir_irt_generate, where quad leaves made weight 3 the better one for scenes whose node steps run full,
+// tools/r04_session33.sh; the other kernels' rays share no direction and keep what they were measured with: at most 2)
+static SceneDev dev_of(const texir_scene* s, bool coherent = false)
 {
     SceneDev d = s->dev;
     const int forced = env().sched_weight;
-    d.sched_weight = forced ? forced : s->sched_weight.load(std::memory_order_relaxed);
+    int w = forced ? forced : s->sched_weight.load(std::memory_order_relaxed);
+    if (!forced && !coherent && w > 2) w = 2;
+    d.sched_weight = w;
     return d;
 }
 
@@ -216,7 +220,7 @@ int texir_scene_tune(const texir_scene* s, const float* pos, const float* nrm, c
         const int64_t count = 16384, first = ((n_ids / 3) / 64) * 64;
         const hipError_t e = irt_probe_node_utilisation(s->dev, pos, nrm, shift, texel_ids, first, count, N, mode, work, (hipStream_t)stream, &util);
         if (e != hipSuccess) { s->sched_state.store(0); return fail(TEXIR_ERR_HIP, "texir_scene_tune: %s", hipGetErrorString(e)); }
-        w = (util >= 0.0 && util < 0.60) ? 1 : 2;
+        w = (util >= 0.0 && util < 0.60) ? 1 : 3;          // (3 since the quad leaves: a leaf visit is one record step, the node lanes are worth waiting for a little longer)
     }
     if (w == 0) { s->sched_state.store(0); return TEXIR_OK; }       // a short list decides nothing: a later, longer call may
     s->sched_weight.store(w);
@@ -272,7 +276,7 @@ int texir_irt_generate(const texir_scene* s, const float* pos, const float* nrm,
                                            "texir_scene_reserve_scratch(scene, n_ids, N) before recording", need, s->scratch_bytes);
         scratch = need ? s->d_scratch : nullptr;
     }
-    HIP_TRY(launch_irt(dev_of(s), pos, nrm, shift, texel_ids, n, N, mode, irr, (unsigned long long*)stats, work, (hipStream_t)stream, scratch));
+    HIP_TRY(launch_irt(dev_of(s, true), pos, nrm, shift, texel_ids, n, N, mode, irr, (unsigned long long*)stats, work, (hipStream_t)stream, scratch));
     return TEXIR_OK;
 }
 

@@ -20,7 +20,7 @@ static Env parse()
     v.uniform_float = geti("TEXIR_UNIFORM_FLOAT", 1) != 0;
     v.tex_layout = geti("TEXIR_TEX_LAYOUT", 2);
     const int w = geti("TEXIR_SCHED_WEIGHT", 0);
-    v.sched_weight = (w == 1 || w == 2) ? w : 0;
+    v.sched_weight = (w >= 1 && w <= 4) ? w : 0;
     v.mip_per_level = geti("TEXIR_MIP_PER_LEVEL", 0) != 0;
     v.adam_scalar = getenv("TEXIR_ADAM_SCALAR") != nullptr;          // (presence switches it on, as before)
     v.adam_grid_y = std::max(0, geti("TEXIR_ADAM_GRID_Y", 0));
