@@ -63,7 +63,7 @@ TEXIR_API int texir_scene_destroy(texir_scene* scene);
 TEXIR_API int texir_scene_set_texture(texir_scene* scene, const float* tex, int32_t Ht, int32_t Wt, int32_t is_device, void* stream);
 
 /* out[0]=inner nodes of the traversal tree (4-wide quantised by default), [1]=triangles, [2]=max depth, [3]=node bytes,
- * [4]=triangle bytes, [5]=uv bytes, [6]=texture bytes, [7]=device */
+ * [4]=triangle bytes (leaf-order slots + the quad records the 4-wide leaves name), [5]=uv bytes, [6]=texture bytes, [7]=device */
 TEXIR_API int texir_scene_info(const texir_scene* scene, int64_t out[8]);
 /* The traversal's phase scheduler weighs the lanes at inner nodes against the lanes at leaves (csrc/device_common.h); the weight is a property of the
  * scene.  texir_scene_tune decides it ONCE per scene from the measured fullness of the scene's node steps on a sample of the caller's own texel
@@ -86,7 +86,8 @@ TEXIR_API int texir_scene_prefetch(const texir_scene* scene, int32_t what, int32
  * barycentric clip, corner-uv interpolation, bilinear/border/align_corners=False fetch of the radiance
  * texture, misses -> 0.   org,dir [R,3] dev -> radiance [R,3] dev.
  * Optional raw intersection outputs (the cast_rays dict, tracer_o3d_irt.py:245-251): t_hit [R] (inf on miss),
- * prim_id [R] (0xFFFFFFFF on miss), prim_uv [R,2]; pass NULL to skip. */
+ * prim_id [R] (0xFFFFFFFF on miss), prim_uv [R,2] (weights of the CALLER's corners 1 and 2 of triangle prim_id, as Open3D's primitive_uvs: the library
+ * stores a triangle's corners rotated where its leaf record wants the shared edge, csrc/bvh_build.h, and turns the barycentrics back here); pass NULL to skip. */
 TEXIR_API int texir_trace_shade(const texir_scene* scene, const float* org /*dev*/, const float* dir /*dev*/, int64_t R,
                       float t_min, float* radiance /*dev*/, float* t_hit /*dev, nullable*/,
                       uint32_t* prim_id /*dev, nullable*/, float* prim_uv /*dev, nullable*/, void* stream);

@@ -145,6 +145,9 @@ int main(int argc, char** argv)
                     for (int k = 0; k < 4; k++) if (key[k] < INFINITY) stk.push_back(code[k]);
                 } else {
                     uint32_t code = ~(uint32_t)node; int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
+#if TEXIR_QUAD
+                    first *= 2; cnt *= 2;          // the 4-wide leaves name quad records: record r = slots 2 r, 2 r + 1 (an empty slot holds a degenerate triangle)
+#endif
                     for (int i = first; i < first + cnt; i++) {
                         const GpuTri& tr = h.tris[i];
 #if TEXIR_TRI_WATERTIGHT
@@ -275,6 +278,9 @@ int main(int argc, char** argv)
                             const bool from_p = r.pleaf != 0;
                             uint32_t code = ~(uint32_t)(from_p ? r.pleaf : r.node);
                             int first = (int)(code >> 3), cnt = (int)(code & 7u) + 1;
+#if TEXIR_QUAD
+                            first *= 2; cnt *= 2;  // (quad records, as above: the replay still counts per-triangle tests -- the kernel's leaf step covers a record's two at once)
+#endif
                             if (cnt > mx) mx = cnt;
                             pass_leaves.push_back((int)code);
                             for (int i = first; i < first + cnt; i++) {
