@@ -385,4 +385,4 @@ def test_bvh_builder_keeps_every_triangle_point_reachable(tmp_path):
     # a tessellated mesh with shared vertices: its 2-triangle leaves pair up into quad records (bvh_build.h) -- every triangle in exactly one slot, stored
     # as the rotation its record needs, the records' four vertices those of their two triangles
     out = subprocess.check_output([exe, "20000", "5", "grid"]).decode().split()
-    assert out[-2:] == ["0", "0"] and int(out[5]) > 0.8 * int(out[1]) / 2, out
+    assert out[-2:] == ["0", "0"] and int(out[6]) > 0.8 * int(out[1]) / 2, out
