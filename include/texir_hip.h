@@ -45,6 +45,9 @@ TEXIR_API int texir_version(void);
 /* The library's run-time switches (TEXIR_* environment variables, csrc/env.h) are parsed once when the library is loaded; this re-reads them
  * (for test suites that flip a switch between two launches; not to be called while launches are being issued from other threads). */
 TEXIR_API int texir_reload_env(void);
+/* the value the library's snapshot holds for one switch, by variable name ("TEXIR_MIP_PER_LEVEL" ...): host code that must agree with the library
+ * on a switch asks the library instead of parsing the environment a second time with its own rule. */
+TEXIR_API int texir_env_switch(const char* name, int32_t* value);
 
 /* Replaces TracerO3d.__init__ scene part (models/tracer_o3d_irt.py:75-89) and MaterialModel.__init__
  * (models/mat_nvdiffrast.py:87-101): o3d.t.geometry.RaycastingScene().add_triangles(mesh) + the CPU-resident
@@ -345,6 +348,22 @@ TEXIR_API int texir_png_unfilter(const uint8_t* raw /*host*/, int32_t H, int32_t
 /* Radiance .hdr scanlines (flat or new-style RLE, per scanline) after the resolution line -> RGBE bytes [H][W][4]; returns the bytes
  * consumed (< 0: error).  Replaces the decode half of cv2.imread(".hdr", -1) (models/tracer_o3d_irt.py:77, datasets/dataset.py:480). */
 TEXIR_API int64_t texir_hdr_decode_scanlines(const uint8_t* data /*host*/, int64_t n, int32_t W, int32_t H, uint8_t* rgbe /*host*/);
+/* Radiance RGBE pixel codec, float RGB [npix][3] <-> RGBE [npix][4] (host pointers, multi-threaded): the pixel arithmetic of
+ * cv2.imwrite(".hdr") / cv2.imread(".hdr", -1) (trainer/generate_ir_texture.py:82, trainer/train_material.py:350-353,
+ * models/mat_nvdiffrast.py:73).  Byte-identical to io_formats.rgbe_encode / rgbe_decode (numpy, kept as the test reference). */
+TEXIR_API int texir_rgbe_encode(const float* rgb /*host*/, int64_t npix, uint8_t* rgbe /*host*/);
+/* RGBE bytes [H][W][4] -> new-style RLE scanlines laid out as cv2.imwrite(".hdr") writes them (its default IMWRITE_HDR_COMPRESSION_RLE);
+ * returns the bytes written (< 0: error / cap too small; 4 + 4 * (W + W / 64 + 4) bytes per scanline always suffice). */
+TEXIR_API int64_t texir_hdr_encode_rle(const uint8_t* rgbe /*host*/, int32_t W, int32_t H, uint8_t* out /*host*/, int64_t cap);
+TEXIR_API int texir_rgbe_decode(const uint8_t* rgbe /*host*/, int64_t npix, float* rgb /*host*/);
+/* Wavefront OBJ text -> arrays (host pointers, multi-threaded): the parse half of o3d.io.read_triangle_mesh / pyredner.load_obj
+ * (models/tracer_o3d_irt.py:75,85,183-189; models/mat_nvdiffrast.py:87,193-199).  texir_obj_parse classifies lines by their first token
+ * (v / vt / vn / f; LF, CRLF, CR), fan-triangulates polygons, resolves negative indices and fills counts = {n_v, n_vt, n_vn, n_tri};
+ * texir_obj_take copies into caller-owned buffers sized from the counts (v [n_v][3], vt [n_vt][2], vn [n_vn][3] float32 -- a correctly
+ * rounded double rounded once more, as float() + numpy do; fi / ft / fn [n_tri][3] int32, 0-based, -1 = absent) and frees the handle
+ * (all-null outputs: only frees).  Array-identical to io_formats.load_obj_py. */
+TEXIR_API int texir_obj_parse(const char* text /*host*/, int64_t n, void** handle, int64_t counts[4]);
+TEXIR_API int texir_obj_take(void* handle, float* v, float* vt, float* vn, int32_t* fi, int32_t* ft, int32_t* fn);
 
 #ifdef __cplusplus
 }

@@ -85,6 +85,13 @@ def lib():
         sig["texir_png_unfilter"] = [vp, i32, i32, i32, vp]
         L.texir_hdr_decode_scanlines.argtypes = [vp, i64, i32, i32, vp]
         L.texir_hdr_decode_scanlines.restype = i64
+        L.texir_hdr_encode_rle.argtypes = [vp, i32, i32, vp, i64]
+        L.texir_hdr_encode_rle.restype = i64
+        sig["texir_env_switch"] = [C.c_char_p, C.POINTER(i32)]
+        sig["texir_rgbe_encode"] = [vp, i64, vp]
+        sig["texir_rgbe_decode"] = [vp, i64, vp]
+        sig["texir_obj_parse"] = [vp, i64, C.POINTER(vp), vp]
+        sig["texir_obj_take"] = [vp, vp, vp, vp, vp, vp, vp]
         for name, args in sig.items():
             fn = getattr(L, name)
             fn.argtypes = args
@@ -132,6 +139,13 @@ def batch_call(name, jobs):
     rc = getattr(L, name)(arr, len(jobs), stream_ptr())
     if rc != 0:
         raise TexirError("libtexir_hip: %s (code %d)" % (L.texir_batch_last_error().decode(), rc))
+
+
+def env_switch(name):
+    """the library's own (load-time or last texir_reload_env) reading of a TEXIR_* switch"""
+    v = C.c_int32()
+    check(lib().texir_env_switch(name.encode(), C.byref(v)))
+    return int(v.value)
 
 
 def reload_env():

@@ -1,5 +1,7 @@
 // Binned-SAH BVH2 builder (host, multi-threaded over the top subtrees) emitting the 64-byte
 // two-child-box node layout consumed by the gfx950 traversal kernels (see bvh_build.h).
+#include <cstdio>
+#include <cstdlib>
 #include "bvh_build.h"
 #include "env.h"
 #include <cstdlib>
@@ -44,7 +46,17 @@ struct Ctx {
 constexpr int kBins = 32;
 
 // triangles per leaf (leaf codes hold count-1 in 3 bits); TEXIR_MAX_LEAF overrides the default for A/B measurements
-static int max_leaf() { const int v = env().max_leaf; return v ? v : kMaxLeaf; }
+static int max_leaf()
+{
+    const int v = env().max_leaf ? env().max_leaf : kMaxLeaf;
+#if TEXIR_QUAD
+    // quad records own two leaf-order slots each: a leaf of n unpaired triangles spans up to 2 n - 1 slots, and the binary tree's leaf code has 3 bits
+    // for (slots - 1) -- more than 4 triangles per leaf would spill into the first-slot field (the deep-tree fallback and TEXIR_BVH_WIDTH=2 read it)
+    return std::min(v, 4);
+#else
+    return v;
+#endif
+}
 
 std::unique_ptr<Tmp> build(const Ctx& c, int first, int count, int depth, int par_levels)
 {
@@ -117,7 +129,11 @@ std::unique_ptr<Tmp> build(const Ctx& c, int first, int count, int depth, int pa
 }
 
 // leaf codes (bvh_build.h): the binary tree names leaf-order slots, the 4-wide tree names quad records when the library has them
-inline int32_t leaf_code(const Tmp* t) { return ~(int32_t)(((uint32_t)t->slot_first << 3) | (uint32_t)(t->slot_count - 1)); }
+inline int32_t leaf_code(const Tmp* t)
+{
+    if (t->slot_count < 1 || t->slot_count > 8) { fprintf(stderr, "texir bvh: leaf of %d slots does not fit its 3-bit count\n", t->slot_count); abort(); }
+    return ~(int32_t)(((uint32_t)t->slot_first << 3) | (uint32_t)(t->slot_count - 1));
+}
 inline int32_t leaf_code4(const Tmp* t)
 {
 #if TEXIR_QUAD

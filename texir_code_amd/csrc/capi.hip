@@ -32,6 +32,7 @@ struct texir_scene {
     void* d_cnrm = nullptr;              // leaf-ordered corner normals, 3 x float4 per triangle
     float* d_scratch = nullptr;          // texir_scene_reserve_scratch: the IrT partial-sum scratch of RECORDED launches (eager launches allocate stream-ordered)
     size_t scratch_bytes = 0;
+    std::vector<float*> retired_scratch;  // smaller blocks a grown reservation replaced: recorded graphs may still name them, so they live until destroy
     // chunk counters of the persistent IrT kernel: one slot per launch, handed out round-robin so that launches of one scene that
     // overlap on different streams do not share a counter (kWorkSlots launches would have to be in flight at once)
     static constexpr int kWorkSlots = 64;
@@ -156,6 +157,7 @@ int texir_scene_destroy(texir_scene* s)
     if (s->d_tex_tiled) (void)hipFree(s->d_tex_tiled);
     if (s->d_cnrm) (void)hipFree(s->d_cnrm);
     if (s->d_scratch) (void)hipFree(s->d_scratch);
+    for (float* p : s->retired_scratch) (void)hipFree(p);
     if (s->d_work) (void)hipFree(s->d_work);
     delete s;
     return TEXIR_OK;
@@ -235,6 +237,14 @@ int texir_reload_env(void)
     return TEXIR_OK;
 }
 
+int texir_env_switch(const char* name, int32_t* value)
+{
+    int v = 0;
+    if (!name || !value || env_switch(name, &v) != 0) return fail(TEXIR_ERR_INVALID, "texir_env_switch: unknown switch %s", name ? name : "(null)");
+    *value = v;
+    return TEXIR_OK;
+}
+
 int texir_trace_shade(const texir_scene* s, const float* org, const float* dir, int64_t R, float t_min, float* radiance, float* t_hit,
                       uint32_t* prim_id, float* prim_uv, void* stream)
 {
@@ -286,8 +296,12 @@ int texir_scene_reserve_scratch(texir_scene* s, int64_t n_ids, int32_t N)
     const size_t need = irt_scratch_bytes(s->dev, n_ids, N);
     if (need <= s->scratch_bytes) return TEXIR_OK;
     HIP_TRY(hipSetDevice(s->device));
-    if (s->d_scratch) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(s->d_scratch); s->d_scratch = nullptr; s->scratch_bytes = 0; }
-    HIP_TRY(hipMalloc((void**)&s->d_scratch, need));
+    // Growing never frees: hipGraphs recorded against the smaller block have its address baked into their kernel nodes and may still be replayed.
+    // The old block is retired (kept until texir_scene_destroy); launches recorded from now on use the new one.
+    float* grown = nullptr;
+    HIP_TRY(hipMalloc((void**)&grown, need));
+    if (s->d_scratch) s->retired_scratch.push_back(s->d_scratch);
+    s->d_scratch = grown;
     s->scratch_bytes = need;
     return TEXIR_OK;
 }

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 namespace texir {
 
@@ -45,5 +46,19 @@ static Env g_env = parse();          // library load
 
 const Env& env() { return g_env; }
 void env_reload() { g_env = parse(); }
+
+int env_switch(const char* name, int* value)
+{
+    const struct { const char* n; int v; } tab[] = {
+        {"TEXIR_BVH_WIDTH", g_env.bvh_width}, {"TEXIR_BVH_LAYOUT", g_env.bvh_layout}, {"TEXIR_UNIFORM_FLOAT", g_env.uniform_float},
+        {"TEXIR_TEX_LAYOUT", g_env.tex_layout}, {"TEXIR_SCHED_WEIGHT", g_env.sched_weight}, {"TEXIR_MIP_PER_LEVEL", g_env.mip_per_level},
+        {"TEXIR_ADAM_SCALAR", g_env.adam_scalar}, {"TEXIR_ADAM_GRID_Y", g_env.adam_grid_y}, {"TEXIR_MAX_LEAF", g_env.max_leaf},
+        {"TEXIR_BOX_SLACK_LOG2", g_env.box_slack_log2}, {"TEXIR_IRT_TEXELS_PER_WAVE", g_env.irt_texels_per_wave}, {"TEXIR_IRT_REFILL", g_env.irt_refill},
+        {"TEXIR_IRT_MIN_PART_CELLS", g_env.irt_min_part_cells}, {"TEXIR_IRT_LOG2PARTS", g_env.irt_log2parts_cap},
+        {"TEXIR_SPEC_GRID_CAP", g_env.spec_grid_cap}, {"TEXIR_SPEC_LPP", g_env.spec_lpp}};
+    for (const auto& t : tab)
+        if (name && !strcmp(name, t.n)) { *value = t.v; return 0; }
+    return -1;
+}
 
 }  // namespace texir

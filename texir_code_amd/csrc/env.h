@@ -13,7 +13,7 @@ struct Env {
     int mip_per_level;         // TEXIR_MIP_PER_LEVEL        0 | 1 = one launch per mip level (reference form kept for the parity tests)
     int adam_scalar;           // TEXIR_ADAM_SCALAR          0 | 1 = scalar Adam kernel (reference form kept for the parity tests)
     int adam_grid_y;           // TEXIR_ADAM_GRID_Y          0 = full grid | rows of blocks (probe)
-    int max_leaf;              // TEXIR_MAX_LEAF             0 = builder default | 1..8 triangles per leaf
+    int max_leaf;              // TEXIR_MAX_LEAF             0 = builder default | 1..8 triangles per leaf (quad leaves, the default build: capped at 4)
     int box_slack_log2;        // TEXIR_BOX_SLACK_LOG2       -19 (default) | 99 = no slack
     int irt_texels_per_wave;   // TEXIR_IRT_TEXELS_PER_WAVE  0 = automatic | 1 | 64
     int irt_refill;            // TEXIR_IRT_REFILL           0 = lock-step passes (default) | 1..63: refill idle lanes once this many have gathered (irt_stream_kernel)
@@ -24,6 +24,7 @@ struct Env {
 };
 
 const Env& env();          // the current snapshot
+int env_switch(const char* name, int* value);   // the snapshot's value of one switch by its variable name; 0 = known
 void env_reload();         // re-read the process environment (not thread-safe against concurrent launches: test use only)
 
 }  // namespace texir

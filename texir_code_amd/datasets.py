@@ -221,10 +221,11 @@ def parse_roomseg(path):
     return float(s), float(w), float(h), float(xmin), float(zmin), room
 
 
-def write_synthetic_dataset(root, T=20000, texel_res=256, tex_res=256, n_side=2, seed=666):
-    """mesh + radiance texture + index texture + exact texel G-buffer + cameras (no GT images: see render_gt_views)"""
+def write_synthetic_dataset(root, T=20000, texel_res=256, tex_res=256, n_side=2, seed=666, style="room", compress=True):
+    """mesh + radiance texture + index texture + exact texel G-buffer + cameras (no GT images: see render_gt_views).
+    compress=False stores the texel G-buffer un-deflated (4096^2: 400 MB that np.load maps back in a fraction of a second)"""
     from . import synth
-    sc = synth.make_scene(T, seed=seed, tex_res=tex_res)
+    sc = synth.make_scene(T, seed=seed, tex_res=tex_res, style=style)
     d = os.path.join(root, "vrproc", "hdr_texture")
     os.makedirs(d, exist_ok=True)
     os.makedirs(os.path.join(root, "info"), exist_ok=True)
@@ -233,7 +234,7 @@ def write_synthetic_dataset(root, T=20000, texel_res=256, tex_res=256, n_side=2,
     IO.write_obj(os.path.join(d, "out1.obj"), sc["verts"], sc["tris"], sc["tri_uvs"])
     IO.write_hdr(os.path.join(d, "hdr_texture.hdr"), sc["hdr"][::-1])             # file orientation = un-flipped
     pos, nrm, valid = synth.make_texel_gbuffer(sc, texel_res)
-    np.savez_compressed(os.path.join(d, "texel_gbuffer.npz"), position=pos[::-1].copy(), normal=nrm[::-1].copy())
+    (np.savez_compressed if compress else np.savez)(os.path.join(d, "texel_gbuffer.npz"), position=pos[::-1].copy(), normal=nrm[::-1].copy())
     idx = np.zeros((texel_res, texel_res, 3), np.uint16)
     idx[valid[::-1] > 0] = (1, 1, 0)                                               # non-zero code: not a seam; codes unused with texel_gbuffer
     IO.write_png(os.path.join(d, "0.png"), idx[..., ::-1])                        # cv2 stores BGR

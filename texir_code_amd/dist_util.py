@@ -34,6 +34,19 @@ def shard_plan(ids_all, world, block=4096, device=None):
     return [shard_block_cyclic(ids_all, r, world, block).long() for r in range(world)]
 
 
+def _flat_all_gather_ok(t):
+    """all_gather_into_tensor exists for the nccl (= RCCL) backend on device tensors and for gloo from torch 2.x on; anything else takes the list form"""
+    import torch.distributed as dist
+    if not hasattr(dist, "all_gather_into_tensor"):
+        return False
+    be = dist.get_backend()
+    if be == "nccl":
+        return t.is_cuda
+    if be == "gloo":
+        return tuple(int(x) for x in torch.__version__.split("+")[0].split(".")[:2]) >= (2, 1)
+    return False
+
+
 def assemble_shards(tex, ids_all, block=4096, plan=None):
     """Assemble the irradiance texture `tex` [Nt, C] whose rows ids_all[shard r] were computed by rank r (shard_block_cyclic(ids_all, r, world, block)):
     every rank contributes only ITS texels' values, compacted ([n_r, C]: 12 bytes per valid texel instead of a dense all_reduce over the whole
@@ -52,9 +65,11 @@ def assemble_shards(tex, ids_all, block=4096, plan=None):
     mine = torch.zeros((mx, C), device=tex.device, dtype=tex.dtype)
     mine[: shards[rank].numel()] = tex[shards[rank]]
     out = torch.empty((world * mx, C), device=tex.device, dtype=tex.dtype)
-    try:
+    # which form of the collective to issue is decided from the backend BEFORE anything is issued (and so identically on every rank): a fall-back
+    # taken after a failed attempt would leave the ranks issuing different collectives -- real collective errors propagate
+    if _flat_all_gather_ok(tex):
         dist.all_gather_into_tensor(out, mine)
-    except (RuntimeError, NotImplementedError):          # a backend without the flat form
+    else:
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine)
         out = torch.cat(parts, 0)

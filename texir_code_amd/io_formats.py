@@ -9,7 +9,8 @@ import numpy as np
 
 
 # ------------------------------------------------------------------------------------------------- Radiance RGBE
-def rgbe_encode(rgb):
+def rgbe_encode_py(rgb):
+    """numpy statement of the RGBE pixel encode (the test reference of texir_rgbe_encode)"""
     rgb = np.asarray(rgb, np.float32)
     mx = rgb.max(axis=-1)
     out = np.zeros(rgb.shape[:-1] + (4,), np.uint8)
@@ -21,20 +22,49 @@ def rgbe_encode(rgb):
     return out
 
 
-def rgbe_decode(rgbe):
+def rgbe_decode_py(rgbe):
+    """numpy statement of the RGBE pixel decode (the test reference of texir_rgbe_decode)"""
     e = rgbe[..., 3].astype(np.int32)
     f = np.where(e > 0, np.ldexp(1.0, e - (128 + 8)), 0.0).astype(np.float32)
     return rgbe[..., 0:3].astype(np.float32) * f[..., None]
 
 
-def write_hdr(path, rgb):
-    """rgb [H,W,3] float32, RGB order, row 0 = top.  Flat (un-compressed) scanlines."""
-    rgb = np.asarray(rgb, np.float32)
+def rgbe_encode(rgb):
+    """float RGB [...,3] -> RGBE bytes [...,4] through the library's threaded loop (texir_rgbe_encode, csrc/io_native.cpp)"""
+    from . import _lib
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    out = np.empty(rgb.shape[:-1] + (4,), np.uint8)
+    _lib.check(_lib.lib().texir_rgbe_encode(_lib.ptr(rgb), rgb.size // 3, _lib.ptr(out)))
+    return out
+
+
+def rgbe_decode(rgbe):
+    """RGBE bytes [...,4] -> float32 RGB [...,3] (texir_rgbe_decode)"""
+    from . import _lib
+    rgbe = np.ascontiguousarray(rgbe, np.uint8)
+    out = np.empty(rgbe.shape[:-1] + (3,), np.float32)
+    _lib.check(_lib.lib().texir_rgbe_decode(_lib.ptr(rgbe), rgbe.size // 4, _lib.ptr(out)))
+    return out
+
+
+def write_hdr(path, rgb, rle=True):
+    """rgb [H,W,3] float32, RGB order, row 0 = top.  The file cv2.imwrite(path, rgb[..., ::-1]) writes (trainer/generate_ir_texture.py:82):
+    header "#?RADIANCE / FORMAT=32-bit_rle_rgbe / -Y H +X W", new-style RLE scanlines (cv2's default); rle=False writes flat scanlines."""
+    from . import _lib
+    rgb = np.ascontiguousarray(rgb, np.float32)
     H, W, _ = rgb.shape
+    body = rgbe_encode(rgb)
+    if rle:
+        cap = H * (4 + 4 * (W + W // 64 + 4)) + 16
+        buf = np.empty(cap, np.uint8)
+        n = _lib.lib().texir_hdr_encode_rle(_lib.ptr(body), W, H, _lib.ptr(buf), cap)
+        if n < 0:
+            raise ValueError("%s: RLE encode failed" % path)
+        body = buf[:n]
     with open(path, "wb") as f:
         f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n")
         f.write(("-Y %d +X %d\n" % (H, W)).encode())
-        f.write(rgbe_encode(rgb).tobytes())
+        f.write(memoryview(body).cast("B") if body.flags.c_contiguous else body.tobytes())
 
 
 def read_hdr(path):
@@ -139,22 +169,24 @@ def read_index_texture(path):
 
 
 # ------------------------------------------------------------------------------------------------- Wavefront OBJ
-def load_obj(path):
-    """-> dict(vertices [V,3], indices [T,3], uvs [Vt,2] (as written in the file), uv_indices [T,3], normals [Vn,3] | None,
-    normal_indices [T,3] | None).  Faces with more than 3 corners are fan-triangulated; negative indices resolved."""
+def load_obj_py(path):
+    """pure-Python statement of the OBJ reader (the test reference of texir_obj_parse): lines are classified by their first token."""
     v, vt, vn, fi, ft, fn = [], [], [], [], [], []
-    with open(path, "r") as f:
+    with open(path, "r", newline=None) as f:
         for line in f:
-            if line.startswith("v "):
-                v.append([float(x) for x in line.split()[1:4]])
-            elif line.startswith("vt "):
-                vt.append([float(x) for x in line.split()[1:3]])
-            elif line.startswith("vn "):
-                vn.append([float(x) for x in line.split()[1:4]])
-            elif line.startswith("f "):
+            tok = line.split()
+            if not tok:
+                continue
+            if tok[0] == "v":
+                v.append([float(x) for x in tok[1:4]])
+            elif tok[0] == "vt":
+                vt.append([float(x) for x in tok[1:3]])
+            elif tok[0] == "vn":
+                vn.append([float(x) for x in tok[1:4]])
+            elif tok[0] == "f":
                 corners = []
-                for tok in line.split()[1:]:
-                    parts = tok.split("/")
+                for t in tok[1:]:
+                    parts = t.split("/")
                     a = int(parts[0]); a = a - 1 if a > 0 else len(v) + a
                     b = -1
                     if len(parts) > 1 and parts[1]:
@@ -166,11 +198,49 @@ def load_obj(path):
                 for k in range(1, len(corners) - 1):
                     tri = (corners[0], corners[k], corners[k + 1])
                     fi.append([t[0] for t in tri]); ft.append([t[1] for t in tri]); fn.append([t[2] for t in tri])
-    out = {"vertices": np.asarray(v, np.float32).reshape(-1, 3), "indices": np.asarray(fi, np.int32).reshape(-1, 3),
-           "uvs": np.asarray(vt, np.float32).reshape(-1, 2), "uv_indices": np.asarray(ft, np.int32).reshape(-1, 3),
-           "normals": np.asarray(vn, np.float32).reshape(-1, 3) if vn else None,
-           "normal_indices": np.asarray(fn, np.int32).reshape(-1, 3) if vn else None}
-    return out
+    return {"vertices": np.asarray(v, np.float32).reshape(-1, 3), "indices": np.asarray(fi, np.int32).reshape(-1, 3),
+            "uvs": np.asarray(vt, np.float32).reshape(-1, 2), "uv_indices": np.asarray(ft, np.int32).reshape(-1, 3),
+            "normals": np.asarray(vn, np.float32).reshape(-1, 3) if vn else None,
+            "normal_indices": np.asarray(fn, np.int32).reshape(-1, 3) if vn else None}
+
+
+_OBJ_CACHE = {}
+
+
+def load_obj(path, cache=True):
+    """-> dict(vertices [V,3], indices [T,3], uvs [Vt,2] (as written in the file), uv_indices [T,3], normals [Vn,3] | None,
+    normal_indices [T,3] | None).  Faces with more than 3 corners are fan-triangulated; negative indices resolved.
+    Parsed by the library (texir_obj_parse: threaded C++, 1 M triangles in well under a second).  One run of a runner opens the same
+    mesh from the dataset AND from the model (datasets.py, models.py -- as the reference does, datasets/dataset.py:385 and
+    models/tracer_o3d_irt.py:75): the parsed arrays are kept per (path, size, mtime) and handed out read-only."""
+    import ctypes as C
+    import os
+    from . import _lib
+    st = os.stat(path)
+    key = (os.path.abspath(path), st.st_size, st.st_mtime_ns)
+    if cache and key in _OBJ_CACHE:
+        return dict(_OBJ_CACHE[key])
+    with open(path, "rb") as f:
+        text = f.read()
+    L = _lib.lib()
+    h = C.c_void_p()
+    counts = np.zeros(4, np.int64)
+    if L.texir_obj_parse(text, len(text), C.byref(h), _lib.ptr(counts)) != 0:
+        raise ValueError("%s: malformed OBJ (a v / vt / vn / f line could not be parsed)" % path)
+    nv, nvt, nvn, nt = (int(x) for x in counts)
+    v, vt = np.empty((nv, 3), np.float32), np.empty((nvt, 2), np.float32)
+    vn = np.empty((nvn, 3), np.float32) if nvn else None
+    fi, ft = np.empty((nt, 3), np.int32), np.empty((nt, 3), np.int32)
+    fn = np.empty((nt, 3), np.int32) if nvn else None
+    _lib.check(L.texir_obj_take(h, _lib.ptr(v), _lib.ptr(vt), _lib.ptr(vn), _lib.ptr(fi), _lib.ptr(ft), _lib.ptr(fn)))
+    out = {"vertices": v, "indices": fi, "uvs": vt, "uv_indices": ft, "normals": vn, "normal_indices": fn}
+    for a in out.values():
+        if a is not None:
+            a.setflags(write=False)
+    if cache:
+        _OBJ_CACHE.clear()                      # one mesh per run: keep the latest only
+        _OBJ_CACHE[key] = out
+    return dict(out)
 
 
 def triangle_uvs_open3d(obj):

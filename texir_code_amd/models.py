@@ -15,6 +15,7 @@ import torch
 from torch import nn
 
 from . import dist_util, gbuffer as GB, io_formats as IO
+from .runlog import phases
 from .cube2pano import Cube2Pano
 from .scene import Scene, generate_dir, spec_render
 from .texture import texture as tex_fetch, texture_batch as tex_fetch_batch
@@ -50,14 +51,30 @@ def _sibling(path_mesh, name):
 def _load_scene(conf, device):
     """mesh + radiance texture -> Scene (tracer_o3d_irt.py:75-89 / mat_nvdiffrast.py:87-101)"""
     path_mesh = conf.get_string("train.path_mesh_open3d")
-    obj = IO.load_obj(path_mesh)
-    tri_uvs = IO.triangle_uvs_open3d(obj)
-    tex = IO.read_hdr(_sibling(path_mesh, "hdr_texture.hdr"))           # RGB
-    tex = np.ascontiguousarray(tex[::-1])                                # cv2.flip(texture, 0)
-    tex = tex * np.float32(2 ** conf.get_float("train.hdr_exposure"))
-    scene = Scene(obj["vertices"], obj["indices"], tri_uvs, tex, device=device)
-    GB.set_corner_normals(scene, IO.corner_normals(obj))
+    with phases.phase("load_obj", sync=False):
+        obj = IO.load_obj(path_mesh)                                         # (parsed once per run: the dataset's load is served from the same cache)
+        tri_uvs = IO.triangle_uvs_open3d(obj)
+    with phases.phase("load_hdr_texture", sync=False):
+        tex = IO.read_hdr(_sibling(path_mesh, "hdr_texture.hdr"))           # RGB
+        expo = np.float32(2 ** conf.get_float("train.hdr_exposure"))
+        tex = np.ascontiguousarray(tex[::-1])                                # cv2.flip(texture, 0)
+        if expo != 1.0:
+            tex *= expo
+    with phases.phase("scene_build"):
+        scene = Scene(obj["vertices"], obj["indices"], tri_uvs, tex, device=device)
+        GB.set_corner_normals(scene, IO.corner_normals(obj))
     return scene, obj, torch.from_numpy(tex)
+
+
+def seam_texels(index_texture):
+    """texels the reference zeroes: `index_texture[:,:,0] + index_texture[:,:,1] + index_texture[:,:,2] == 0` evaluated in the image's own
+    uint16 arithmetic (tracer_o3d_irt.py:137,176): a code triple whose sum wraps to 65536 counts as a seam there, and so it does here"""
+    idx = np.asarray(index_texture)
+    if idx.dtype == np.uint16:
+        return ((idx[..., 0].astype(np.uint32) + idx[..., 1] + idx[..., 2]) & 0xFFFF) == 0
+    if idx.dtype == np.uint8:
+        return ((idx[..., 0].astype(np.uint32) + idx[..., 1] + idx[..., 2]) & 0xFF) == 0
+    return idx.astype(np.int64).sum(-1) == 0
 
 
 class TracerO3d(nn.Module):
@@ -77,7 +94,8 @@ class TracerO3d(nn.Module):
         # The reference resizes 0.png to 1024 x 1024 (tracer_o3d_irt.py:95) -- train.irt_res keeps that default size; `native` (or 0) opts
         # out.  The resize here is NEAREST, the flag the reference passes: its call puts cv2.INTER_NEAREST in the `dst` slot, so it
         # actually interpolates the uint16 row/col/panorama codes bilinearly -- an accident that is not reproduced.
-        idx = IO.read_index_texture(_sibling(self.path_traced_mesh, "0.png"))
+        with phases.phase("load_index_texture", sync=False):
+            idx = IO.read_index_texture(_sibling(self.path_traced_mesh, "0.png"))
         res = conf.get("train.irt_res", 1024)
         if res not in (None, 0, "0", "native"):
             res = int(res)
@@ -117,7 +135,7 @@ class TracerO3d(nn.Module):
             row = torch.clamp((idx[..., 0][sel].double() / 50000 * h).long(), 0, h - 1)
             pos[sel] = pano[row, col, 0:3]
             nrm[sel] = pano[row, col, 3:6]
-        seam = idx.sum(-1) == 0
+        seam = torch.from_numpy(seam_texels(self.index_texture)).to(self.device)
         pos[seam] = 0
         nrm[seam] = 0
         self.position_texture, self.normal_texture = pos, nrm
@@ -130,27 +148,31 @@ class TracerO3d(nn.Module):
     # -- tracer_o3d_irt.py:145-180 ----------------------------------------------------------------------------------
     def forward(self):
         use_file = self.use_texel_gbuffer in (True, "file") or (self.use_texel_gbuffer == "auto" and os.path.exists(self.texel_gbuffer_path))
-        if use_file:
-            self._load_texel_gbuffer()
-        else:
-            self.generate_positions()
-            self.calcute_position_normal_texture()
+        with phases.phase("texel_gbuffer"):
+            if use_file:
+                self._load_texel_gbuffer()
+            else:
+                self.generate_positions()
+                self.calcute_position_normal_texture()
         print("Finish precomputing model!")
         H, W, _ = self.position_texture.shape
-        pos = self.position_texture.reshape(-1, 3).contiguous()
-        nrm = self.normal_texture.reshape(-1, 3).contiguous()
-        nt = pos.shape[0]
-        # shifts: the reference draws torch.rand(512,1,2) per 512-texel batch from the CPU generator (sample_util.py:102);
-        # one [nt,1,2] draw consumes the same stream in the same order
-        shift = torch.rand(nt, 1, 2).reshape(nt, 2).to(self.device)
-        seam = torch.from_numpy((self.index_texture.astype(np.int64).sum(-1) == 0).reshape(-1)).to(self.device)
-        ids = dist_util.morton_order(torch.nonzero(~seam)[:, 0].to(torch.int32), W)
-        rank, world, _ = dist_util.world_info()
-        ids_all = ids
-        ids = dist_util.shard_block_cyclic(ids_all, rank, world)
-        irr = torch.zeros((nt, 3), device=self.device)
-        self.scene.irt_generate(pos, nrm, shift, int(self.sample_l[0]), self.sample_type[0], texel_ids=ids, out=irr)
-        dist_util.assemble_shards(irr, ids_all)             # (one all_gather of the ranks' own texel values; no-op for one rank)
+        with phases.phase("shifts_and_texel_list"):
+            pos = self.position_texture.reshape(-1, 3).contiguous()
+            nrm = self.normal_texture.reshape(-1, 3).contiguous()
+            nt = pos.shape[0]
+            # shifts: the reference draws torch.rand(512,1,2) per 512-texel batch from the CPU generator (sample_util.py:102);
+            # one [nt,1,2] draw consumes the same stream in the same order
+            shift = torch.rand(nt, 1, 2).reshape(nt, 2).to(self.device, non_blocking=True)
+            seam = torch.from_numpy(seam_texels(self.index_texture).reshape(-1)).to(self.device)
+            ids = dist_util.morton_order(torch.nonzero(~seam)[:, 0].to(torch.int32), W)
+            rank, world, _ = dist_util.world_info()
+            ids_all = ids
+            ids = dist_util.shard_block_cyclic(ids_all, rank, world)
+            irr = torch.zeros((nt, 3), device=self.device)
+        with phases.phase("irt_kernel"):
+            self.scene.irt_generate(pos, nrm, shift, int(self.sample_l[0]), self.sample_type[0], texel_ids=ids, out=irr)
+        with phases.phase("assemble_shards"):
+            dist_util.assemble_shards(irr, ids_all)             # (one all_gather of the ranks' own texel values; no-op for one rank)
         self.ir_texture = irr.reshape(H, W, 3)
         return self.ir_texture
 

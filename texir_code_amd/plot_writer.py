@@ -1,0 +1,97 @@
+"""Texture plots off the critical path.
+
+The reference's plot_to_disk_cube ends with `plt.plot_mat(..., self.model.materials_a.cpu().detach()[:,:,0:3], ...)` (trainer/train_material.py:350-353):
+a synchronous device -> host copy and a cv2.imwrite('.hdr') of both material textures every `plot_freq` epochs, with the optimisation
+stopped meanwhile.  At 4096^2 textures that is ~270 MB over PCIe plus two RGBE encodes per event against 0.6 ms optimiser steps.
+
+AsyncPlotWriter keeps the same files and contents but takes them off the step loop: submit() snapshots the tensor on the device (one
+D2D copy ordered on the caller's stream -- the optimiser overwrites the parameters in place right after), copies the snapshot to pinned host
+memory on a side stream, and hands (event, buffer, path) to one worker thread that waits for the copy, encodes (io_formats.write_hdr:
+the library's threaded RGBE + RLE loops, GIL released) and writes.  The caller's cost is the snapshot launch; flush() waits for everything
+(end of run, or a test that reads a plot back)."""
+import queue
+import threading
+
+import numpy as np
+import torch
+
+from . import io_formats as IO
+
+
+class AsyncPlotWriter:
+    def __init__(self, max_pending=4):
+        self._q = queue.Queue()
+        self._pool = {}                 # (shape, dtype) -> [pinned tensors]
+        self._lock = threading.Lock()
+        self._stream = None
+        self._worker = None
+        self._errors = []
+        self._pending = threading.Semaphore(max_pending)        # bounds pinned memory: submit() blocks when the disk is that far behind
+
+    def _pinned(self, shape, dtype):
+        key = (tuple(shape), dtype)
+        with self._lock:
+            free = self._pool.setdefault(key, [])
+            if free:
+                return free.pop()
+        return torch.empty(shape, dtype=dtype).pin_memory()
+
+    def _run(self):
+        while True:
+            job = self._q.get()
+            if job is None:
+                self._q.task_done()
+                return
+            path, host, ev, repeat3, snap = job
+            try:
+                if ev is not None:
+                    ev.synchronize()
+                del snap
+                a = host.numpy()
+                if repeat3:
+                    a = np.repeat(a, 3, axis=2)
+                IO.write_hdr(path, a)
+            except Exception as e:              # surfaced by flush()
+                self._errors.append((path, e))
+            finally:
+                if host.is_pinned():
+                    with self._lock:
+                        self._pool.setdefault((tuple(host.shape), host.dtype), []).append(host)
+                self._pending.release()
+                self._q.task_done()
+
+    def submit(self, path, tensor, repeat3=False):
+        """write `tensor` [H,W,C] (C = 3, or 1 with repeat3) as a Radiance .hdr; returns at once"""
+        if self._worker is None:
+            self._worker = threading.Thread(target=self._run, name="texir-plot-writer", daemon=True)
+            self._worker.start()
+        self._pending.acquire()
+        t = tensor.detach()
+        if t.is_cuda:
+            snap = t.to(torch.float32).clone(memory_format=torch.contiguous_format)          # ordered before the next optimiser step
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=t.device)
+            host = self._pinned(snap.shape, snap.dtype)
+            self._stream.wait_stream(torch.cuda.current_stream(t.device))
+            with torch.cuda.stream(self._stream):
+                host.copy_(snap, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._stream)
+            snap.record_stream(self._stream)
+            self._q.put((path, host, ev, repeat3, snap))
+        else:
+            self._q.put((path, t.to(torch.float32).contiguous().clone(), None, repeat3, None))
+
+    def flush(self):
+        self._q.join()
+        if self._errors:
+            path, e = self._errors[0]
+            self._errors = []
+            raise RuntimeError("plot writer failed on %s: %s" % (path, e))
+
+    def close(self):
+        if self._worker is not None:
+            self.flush()
+            self._q.put(None)
+            self._worker.join()
+            self._worker = None

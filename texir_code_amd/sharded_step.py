@@ -218,6 +218,10 @@ class ShardedMatStep:
         self._p2(st)
         self._gather(st["recv2"], st["send2"])
         self._p3(st, "eager")
+        # the pinned shift buffer is read zero-copy by the specular forward (and by the backward when it has no saved workspace): the next step() may
+        # not overwrite it before those kernels have run -- a host that does not .item() every step (train.log_lag > 0) would otherwise run ahead
+        st["shift_ev"].record()
+        st["shift_pending"] = True
 
     def step(self, key, stage, shift=None):
         """one optimiser step on a captured view; returns the loss tensor.  The step's GGX shifts are the reference's full-view draw from the CPU generator

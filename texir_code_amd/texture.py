@@ -21,7 +21,13 @@ _GRAD_MASK = __import__("os").environ.get("TEXIR_GRAD_MASK", "1") != "0"
 
 def _mask_enabled():
     # (the per-level reference folds, TEXIR_MIP_PER_LEVEL=1, read a cleared stack: no masks there)
-    return _BATCH and _GRAD_MASK and __import__("os").environ.get("TEXIR_MIP_PER_LEVEL") != "1"
+    return _BATCH and _GRAD_MASK and not _per_level()
+
+
+def _per_level():
+    """TEXIR_MIP_PER_LEVEL as the LIBRARY reads it (its snapshot and its parsing rule, csrc/env.cpp): the two sides must never disagree on who clears
+    the gradient stack"""
+    return _lib.env_switch("TEXIR_MIP_PER_LEVEL") != 0
 
 
 def _multi_rank(owner):
@@ -369,7 +375,7 @@ class _TexFetchBatch(torch.autograd.Function):
             if not ds or not ctx.needs_input_grad[3 + i]:
                 continue
             owner, taps = inf[4], inf[5]
-            if len(ds) == 2 and (taps is None or not _BATCH or __import__("os").environ.get("TEXIR_MIP_PER_LEVEL") == "1"):
+            if len(ds) == 2 and (taps is None or not _BATCH or _per_level()):
                 ds = [ds[0] + ds[1]]                # (no gather to add them in: the float-atomic scatter and the per-level reference folds take one gradient)
             st = _bwd_prepare(ctx.metas[i], owner, taps, ds[0], uv.shape[0] == 0)
             if "early" in st:

@@ -41,6 +41,9 @@ class RunnerBase:
                     shutil.copy(kwargs["conf"], os.path.join(self.expdir, self.timestamp, "runconf.conf"))
                 except OSError:
                     pass
+        # the reference's `self.writer = SummaryWriter(os.path.join(self.expdir, self.timestamp))` (trainer/train_material.py:82): scalars.jsonl there
+        from ..runlog import ScalarLog
+        self.writer = ScalarLog(os.path.join(self.expdir, self.timestamp) if make_dirs else None)
         print("shell command : {0}".format(" ".join(sys.argv)))
 
     def save_checkpoints(self, epoch):

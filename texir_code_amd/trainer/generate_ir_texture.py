@@ -8,6 +8,7 @@ import torch
 from .. import io_formats as IO
 from ..conf import ConfigFactory
 from ..plugin import get_class
+from ..runlog import phases
 
 
 class IrrTextureRunner:
@@ -26,12 +27,14 @@ class IrrTextureRunner:
         np.random.seed(666)
         print("shell command : {0}".format(" ".join(sys.argv)))
         print("Loading data ...")
-        self.train_dataset = get_class(self.conf.get_string("train.dataset_class"))(
-            self.conf.get_string("train.path_mesh_open3d"), self.conf.get_list("train.pano_img_res"), self.conf.get_float("train.hdr_exposure"))
+        with phases.phase("dataset", sync=False):
+            self.train_dataset = get_class(self.conf.get_string("train.dataset_class"))(
+                self.conf.get_string("train.path_mesh_open3d"), self.conf.get_list("train.pano_img_res"), self.conf.get_float("train.hdr_exposure"))
         print("Finish loading data ...")
-        self.model = get_class(self.conf.get_string("train.model_class"))(
-            conf=self.conf, ids=self.train_dataset.ids, extrinsics=self.train_dataset.extrinsics_list, optim_cam=self.conf.get_bool("train.optim_cam"))
-        self.model.cuda()
+        with phases.phase("model_init"):
+            self.model = get_class(self.conf.get_string("train.model_class"))(
+                conf=self.conf, ids=self.train_dataset.ids, extrinsics=self.train_dataset.extrinsics_list, optim_cam=self.conf.get_bool("train.optim_cam"))
+            self.model.cuda()
         self.start_epoch = 0
 
     def run(self):
@@ -39,8 +42,13 @@ class IrrTextureRunner:
         irr_texture = self.model()
         target = self.conf.get_string("train.path_mesh_open3d").replace("out1.obj", "0_irr_texture.hdr")
         rank = int(os.environ.get("RANK", "0"))
-        arr = irr_texture.cpu().numpy()
+        with phases.phase("download", sync=False):
+            # pinned staging: the 4096^2 texture is 201 MB; a pageable .cpu() goes through the driver's bounce buffers at a fraction of the link rate
+            host = torch.empty(irr_texture.shape, dtype=irr_texture.dtype, pin_memory=True)
+            host.copy_(irr_texture)
+            arr = host.numpy()
         print(arr.shape)
         if rank == 0:
-            IO.write_hdr(target, arr)          # Radiance RGBE like cv2.imwrite('.hdr') (generate_ir_texture.py:82)
+            with phases.phase("write_hdr", sync=False):
+                IO.write_hdr(target, arr)          # Radiance RGBE (RLE scanlines) like cv2.imwrite('.hdr') (generate_ir_texture.py:82)
         return irr_texture

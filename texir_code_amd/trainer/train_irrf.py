@@ -104,6 +104,7 @@ class IRRFTrainRunner(RunnerBase):
                 print("{0} [{1}] ({2}/{3}): radiance_loss = {4}, batch cost time : {5:.4f}s".format(
                     self.expname, epoch, data_index, self.n_batches, radiance_loss.item(), time.time() - t0[0]))
                 self.losses.append(radiance_loss.item())
+                self.writer.add_scalar("radiance_loss", self.losses[-1], self.cur_iter - 1)       # trainer/train_irrf.py:272
             if self.cur_iter >= self.max_niters:
                 self.save_checkpoints(epoch)
                 return True
@@ -113,3 +114,4 @@ class IRRFTrainRunner(RunnerBase):
                          before_step=before_step, after_step=after_step, epoch_end=lambda epoch: self.irf_scheduler.step())
         if not ended:
             self.save_checkpoints(self.nepochs)
+        self.writer.flush()

@@ -15,6 +15,7 @@ from ..datasets import parse_roomseg
 from ..models import rgb_to_intensity
 from ..optim import FusedAdam
 from ..plugin import get_class
+from ..runlog import phases
 from .base import RunnerBase
 
 N_SEG_CLASSES = 49          # trainer/train_material.py:188
@@ -52,13 +53,15 @@ class MatTrainRunner(RunnerBase):
         torch.cuda.manual_seed(666)
         np.random.seed(666)
         print("Loading data ...")
-        self.train_dataset = get_class(self.conf.get_string("train.dataset_class"))(
-            self.conf.get_string("train.path_mesh_open3d"), self.conf.get_list("train.pano_img_res"), self.conf.get_float("train.hdr_exposure"))
+        with phases.phase("dataset", sync=False):
+            self.train_dataset = get_class(self.conf.get_string("train.dataset_class"))(
+                self.conf.get_string("train.path_mesh_open3d"), self.conf.get_list("train.pano_img_res"), self.conf.get_float("train.hdr_exposure"))
         print("Finish loading data ...")
         self.train_dataloader = torch.utils.data.DataLoader(self.train_dataset, batch_size=1, shuffle=True)
-        self.model = get_class(self.conf.get_string("train.model_class"))(
-            conf=self.conf, ids=self.train_dataset.ids, extrinsics=self.train_dataset.extrinsics_list, optim_cam=self.conf.get_bool("train.optim_cam"))
-        self.model.cuda()
+        with phases.phase("model_init"):
+            self.model = get_class(self.conf.get_string("train.model_class"))(
+                conf=self.conf, ids=self.train_dataset.ids, extrinsics=self.train_dataset.extrinsics_list, optim_cam=self.conf.get_bool("train.optim_cam"))
+            self.model.cuda()
         self.model.lean_outputs = True        # the step's only consumer of the forward dict is the loss: skip what it does not read (models.py forward)
         self.mat_loss = get_class(self.conf.get_string("train.irf_loss_class"))(**self.conf.get_config("render_loss"))
         self._new_optimizer()
@@ -166,10 +169,13 @@ class MatTrainRunner(RunnerBase):
         plots = getattr(self, "plots_dir", None)
         if int(os.environ.get("RANK", "0")) != 0 or not plots or not os.path.isdir(plots):
             return
-        a = self.model.materials_a.detach().cpu().numpy()[:, :, 0:3]
-        r = self.model.materials_r.detach().cpu().numpy()[:, :, 0:1]
-        IO.write_hdr(os.path.join(self.plots_dir, "mat_albedo-1_%d.hdr" % self.cur_iter), np.ascontiguousarray(a, np.float32))
-        IO.write_hdr(os.path.join(self.plots_dir, "mat_roughness-1_%d.hdr" % self.cur_iter), np.ascontiguousarray(np.repeat(r, 3, axis=2), np.float32))
+        # device snapshot + pinned copy + encode + write on a worker thread (plot_writer.py): the step loop keeps queuing meanwhile
+        from ..plot_writer import AsyncPlotWriter
+        if getattr(self, "_plots", None) is None:
+            self._plots = AsyncPlotWriter()
+        with phases.phase("in_stages:plot_submit", sync=False):
+            self._plots.submit(os.path.join(self.plots_dir, "mat_albedo-1_%d.hdr" % self.cur_iter), self.model.materials_a.detach()[:, :, 0:3])
+            self._plots.submit(os.path.join(self.plots_dir, "mat_roughness-1_%d.hdr" % self.cur_iter), self.model.materials_r.detach()[:, :, 0:1], repeat3=True)
 
     # first-validation branch of plot_to_disk_cube (train_material.py:251-296): per-view masks from a stage -1 render
     def build_view_masks(self):
@@ -224,7 +230,7 @@ class MatTrainRunner(RunnerBase):
         plots are debug output (not reproduced), but the forward draws GGX shifts from the global CPU generator, so it is
         kept to consume the random stream exactly like the reference does."""
         self.model.eval()
-        with torch.no_grad():
+        with phases.phase("in_stages:validation_forward"), torch.no_grad():
             for i, vid in enumerate(self.train_dataset.ids):
                 self.model(self.train_dataset.extrinsics_list[i], vid, self.train_dataset.cam_position_list[i].cuda(), stage)
         self.model.train()
@@ -251,16 +257,22 @@ class MatTrainRunner(RunnerBase):
 
         pending = []             # log_lag > 0: (epoch, data_index, pinned [2] buffer, event, seconds the step's launch took)
 
-        def report(epoch, data_index, loss_v, seg_v, dt):
+        def report(epoch, data_index, loss_v, seg_v, dt, it):
             self.log.append((stage, epoch, data_index, float(loss_v), float(seg_v)))     # the reference prints .item() every step too
+            # scalars under the reference's names at the step's own (pre-increment) iteration index (train_material.py:465-468, 532-536, 600-604)
+            lt = self.conf.get_string("render_loss.loss_type")
+            self.writer.add_scalar("img_loss_%s_stage%d" % (lt, stage), loss_v, it)
+            self.writer.add_scalar("seg_loss_%s_stage%d" % (lt, stage), seg_v, it)
+            if stage > 0:
+                self.writer.add_scalar("tv_loss_%s_stage%d" % (lt, stage), 0.0, it)       # (always 0 in the reference: models/loss.py:105,115)
             print("{0} [{1}] ({2}/{3}): img_loss_stage{7} ({5}) = {4}, seg_loss = {6}, batch cost time : {8:.4f}s".format(
                 self.expname, epoch, data_index, self.n_batches, loss_v, self.conf.get_string("render_loss.loss_type"), seg_v, stage, dt))
 
         def drain(keep):
             while len(pending) > keep:
-                epoch, data_index, host, ev, dt = pending.pop(0)
+                epoch, data_index, host, ev, dt, it = pending.pop(0)
                 ev.synchronize()
-                report(epoch, data_index, float(host[0]), float(host[1]), dt)
+                report(epoch, data_index, float(host[0]), float(host[1]), dt, it)
 
         def after_step(epoch, data_index, out):
             loss, seg_item = out
@@ -274,10 +286,10 @@ class MatTrainRunner(RunnerBase):
                     host[1] = float(seg_item)
                 ev = torch.cuda.Event()
                 ev.record()
-                pending.append((epoch, data_index, host, ev, time.time() - t0[0]))
+                pending.append((epoch, data_index, host, ev, time.time() - t0[0], self.cur_iter - 1))
                 drain(getattr(self, "log_lag", 0))
             else:
-                report(epoch, data_index, loss.item(), seg_item, time.time() - t0[0])
+                report(epoch, data_index, loss.item(), seg_item, time.time() - t0[0], self.cur_iter - 1)
             return max_steps is not None and self.cur_iter >= max_steps
 
         try:
@@ -289,26 +301,40 @@ class MatTrainRunner(RunnerBase):
     def run(self):
         print("training...")
         self.cur_iter = self.start_epoch * len(self.train_dataloader)
-        self.build_view_masks()                                  # "generate vhl mask" (train_material.py:413)
+        with phases.phase("view_masks"):
+            self.build_view_masks()                              # "generate vhl mask" (train_material.py:413)
         # stage 0: albedo only (:416-469)
         self.model.materials_r.requires_grad = False
         self.model.materials_a.requires_grad = True
-        self._stage(0)
+        with phases.phase("stage0"):
+            self._stage(0)
         # stage 1: roughness on highlights (:472-536)
         self._new_optimizer()
         self.model.materials_a.data = torch.clamp(self.model.materials_a.data, 0.)
         self.model.materials_a.requires_grad = False
         self.model.materials_r.requires_grad = True
-        self._stage(1)
+        with phases.phase("stage1"):
+            self._stage(1)
         # stage 2: joint (:539-605); materials_a >= 0 after every step (:592)
         self._new_optimizer()
         self.mat_optimizer.set_clamp(self.model.materials_a, 0.0, float("inf"))
         self.model.materials_a.requires_grad = True
         self.model.materials_r.requires_grad = True
-        self._stage(2)
+        with phases.phase("stage2"):
+            self._stage(2)
         if int(os.environ.get("RANK", "0")) == 0 and os.path.isdir(os.path.join(self.checkpoints_path, "ModelParameters")):
-            self.save_checkpoints(self.nepochs)
+            with phases.phase("checkpoint", sync=False):
+                self.save_checkpoints(self.nepochs)
         self.plot_materials()                                    # final textures (the reference's last plot is one plot_freq earlier)
+        self.finish_outputs()
+
+    def finish_outputs(self):
+        """every queued plot on disk, the scalar log flushed"""
+        with phases.phase("plot_drain", sync=False):
+            if getattr(self, "_plots", None) is not None:
+                self._plots.close()
+                self._plots = None
+        self.writer.flush()
 
 
 class MatTrainSynRunner(MatTrainRunner):

@@ -1,0 +1,155 @@
+"""End-to-end wall-clock of the reference's units of use -- `exp_runner.py --trainstage IrrT` and `--trainstage Mat`
+(trainer/exp_runner.py:54-80, trainer/generate_ir_texture.py:75-82, trainer/train_material.py:408-605) -- at BASELINE.json's sizes,
+from files on disk to files on disk, with the per-phase breakdown (load, BVH, G-buffer, kernel, download, write ...).
+
+    python tools/stage_time.py [--workload c4] [--root DIR] [--mat-epochs 40] [--json]         (also: python bench.py --e2e)
+
+The asset set is written first (not timed): a 1 M-triangle out1.obj, a 4096^2 16-bit index PNG, a 4096^2 Radiance hdr_texture.hdr, the exact
+texel G-buffer, 16 cameras, and -- for Mat -- the 16 ground-truth cube views rendered by the product's own forward.  What is timed is what a
+user of the reference waits for: runner construction + run(), in this process (interpreter start and `import torch` excluded: they are the
+same for the reference).  Every phase is closed by a device synchronisation, so the phases add up to the total."""
+import argparse
+import contextlib
+import io
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+SIZES = {
+    # name: (triangles, texel res, radiance-texture res, IrT spp, cube res, specular spp, material-texture res, views per side)
+    "c4": (1000000, 4096, 4096, 2048, 128, 16, 4096, 4),
+    "c2": (200000, 2048, 2048, 2048, 128, 16, 2048, 4),
+    "tiny": (2000, 64, 64, 64, 16, 16, 128, 2),
+}
+
+
+def make_assets(root, workload, style="room"):
+    """-> (scene dict, conf paths) ; everything the two stages read, written once (asset preparation is not a stage)"""
+    from texir_code_amd import datasets as D
+    T, res, tex_res, spp, cube, S, mres, side = SIZES[workload]
+    t0 = time.perf_counter()
+    sc = D.write_synthetic_dataset(root, T=T, texel_res=res, tex_res=tex_res, n_side=side, style=style, compress=False)
+    conf_irt, conf_mat = os.path.join(root, "irt.conf"), os.path.join(root, "mat.conf")
+    D.write_conf(conf_irt, root, cube_res=cube, spp=(spp, S), model="irt")
+    return sc, conf_irt, conf_mat, time.perf_counter() - t0
+
+
+def _quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def time_irrt(conf_irt):
+    import torch
+    from texir_code_amd.runlog import phases
+    from texir_code_amd.trainer.generate_ir_texture import IrrTextureRunner
+    from texir_code_amd import io_formats as IO
+    IO._OBJ_CACHE.clear()
+    torch.cuda.synchronize()
+    phases.reset(True)
+    t0 = time.perf_counter()
+    with _quiet():
+        runner = IrrTextureRunner(conf=conf_irt, exps_folder_name="exps", expname="e2e", max_niters=1, gpu_index=0)
+        runner.run()
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    ph = phases.report()
+    phases.reset(False)
+    # model_init wraps load_obj / load_hdr_texture / scene_build / load_index_texture: report the remainder as its own entry
+    inner = sum(ph.get(k, 0.0) for k in ("load_obj", "load_hdr_texture", "scene_build", "load_index_texture"))
+    if "model_init" in ph:
+        ph["model_init_other"] = round(max(0.0, ph.pop("model_init") - inner), 4)
+    ph["unattributed"] = round(total - sum(ph.values()), 4)
+    return {"total_s": round(total, 3), "phases_s": ph}
+
+
+def time_mat(conf_mat, exps, epochs, log_lag):
+    import torch
+    from texir_code_amd.runlog import phases
+    from texir_code_amd.trainer.train_material import MatTrainRunner
+    from texir_code_amd import io_formats as IO
+    IO._OBJ_CACHE.clear()
+    torch.cuda.synchronize()
+    phases.reset(True)
+    t0 = time.perf_counter()
+    with _quiet():
+        runner = MatTrainRunner(conf=conf_mat, exps_folder_name=exps, expname="e2e", frame_skip=1, max_niters=10 ** 9, is_continue=False,
+                                timestamp="latest", checkpoint="latest", gpu_index=0)
+        t_init = time.perf_counter() - t0
+        runner.run()
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    ph = phases.report()
+    phases.reset(False)
+    nested = {k.split(":", 1)[1]: ph.pop(k) for k in list(ph) if k.startswith("in_stages:")}
+    inner = sum(ph.pop(k, 0.0) for k in ("load_obj", "load_hdr_texture", "scene_build"))
+    ph["model_init"] = round(ph.get("model_init", 0.0), 4)
+    ph["unattributed"] = round(total - sum(ph.values()), 4)
+    ph["inside_model_init"] = {"obj_hdr_bvh": round(inner, 4)}
+    ph["inside_stages"] = nested
+    steps = len(runner.log)
+    plots = [f for f in os.listdir(runner.plots_dir) if f.endswith(".hdr")]
+    out = {"total_s": round(total, 3), "init_s": round(t_init, 3), "steps": steps, "plot_files": len(plots), "plot_events": len(plots) // 2,
+           "phases_s": ph, "log_lag": log_lag}
+    if "plot_submit" in nested and plots:
+        out["plot_submit_s_per_event"] = round(nested["plot_submit"] / max(1, len(plots) // 2), 4)
+    out["scalars_jsonl"] = os.path.exists(os.path.join(os.path.dirname(runner.plots_dir), "scalars.jsonl"))
+    return out
+
+
+def run(workload="c4", root=None, mat_epochs=40, keep=False, style="room", do_mat=True, log_lag=0):
+    import torch
+    from texir_code_amd import conf as C, datasets as D
+    made = root is None
+    root = root or tempfile.mkdtemp(prefix="texir_e2e_")
+    T, res, tex_res, spp, cube, S, mres, side = SIZES[workload]
+    out = {"workload": "%s: %d-tri %s mesh (out1.obj), %d^2 index PNG + texel G-buffer, %d^2 hdr_texture.hdr, IrT %d spp; Mat %d^2 x (3+1) textures, "
+                       "%d views, cube %d, %d spp, mat_epoch %d, plot_freq 10" % (workload, T, style, res, tex_res, spp, mres, side * side, cube, S, mat_epochs)}
+    try:
+        sc, conf_irt, conf_mat, prep = make_assets(root, workload, style)
+        mesh_dir = os.path.join(root, "vrproc", "hdr_texture")
+        out["asset_prep_s"] = round(prep, 2)
+        out["asset_bytes"] = {f: os.path.getsize(os.path.join(mesh_dir, f)) for f in ("out1.obj", "0.png", "hdr_texture.hdr", "texel_gbuffer.npz")}
+        torch.zeros(1, device="cuda")                     # context creation is not a phase of the stage
+        from texir_code_amd import _lib
+        _lib.lib()
+        out["irrt"] = time_irrt(conf_irt)
+        out["irrt"]["output"] = os.path.getsize(os.path.join(mesh_dir, "0_irr_texture.hdr"))
+        if do_mat:
+            shutil.copy(os.path.join(mesh_dir, "0_irr_texture.hdr"), os.path.join(mesh_dir, "irt.hdr"))
+            D.write_conf(conf_mat, root, cube_res=cube, spp=(spp, S), albedo_res=mres, rough_res=mres, epochs=mat_epochs, model="mat")
+            txt = open(conf_mat).read().replace("plot_freq = 1000", "plot_freq = 10")
+            if log_lag:
+                txt = txt.replace("batch_size = 1", "batch_size = 1\n    log_lag = %d" % log_lag)
+            open(conf_mat, "w").write(txt)
+            t0 = time.perf_counter()
+            with _quiet():
+                D.render_gt_views(root, C.parse_file(conf_mat), sc, mres, mres)
+            out["gt_views_prep_s"] = round(time.perf_counter() - t0, 2)
+            out["mat"] = time_mat(conf_mat, os.path.join(root, "exps"), mat_epochs, log_lag)
+    finally:
+        if made and not keep:
+            shutil.rmtree(root, ignore_errors=True)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c4", choices=sorted(SIZES))
+    ap.add_argument("--root", default=None)
+    ap.add_argument("--mat-epochs", type=int, default=40)
+    ap.add_argument("--style", default="room")
+    ap.add_argument("--no-mat", action="store_true")
+    ap.add_argument("--log-lag", type=int, default=0)
+    ap.add_argument("--keep", action="store_true")
+    a = ap.parse_args()
+    print(json.dumps(run(a.workload, a.root, a.mat_epochs, a.keep, a.style, not a.no_mat, a.log_lag)))
+
+
+if __name__ == "__main__":
+    main()
