@@ -50,6 +50,10 @@ WORKLOADS = {
     # hostile sibling of c4 (never the headline): rotated clutter, thin slats, two openings (p_hit < 1), noisy "scanned" surfaces
     "c4_scan": (1000000, 4096, 4096, 2048, "scan"),
     "tiny_scan": (20000, 128, 256, 64, "scan"),
+    # third family (never the headline): the shape of the reference's data -- a 3 x 3-room house, rooms joined by doors, large untessellated shell triangles
+    # next to millimetre-scale clutter, windows (p_hit < 1)  (synth._house; /root/reference README.md:21-34)
+    "house": (1000000, 4096, 4096, 2048, "house"),
+    "tiny_house": (20000, 128, 256, 64, "house"),
     # experiment: c4 with a 1k^2 radiance texture (12.6 MB: L2/Infinity-Cache resident) -- how much of c4's time is texture traffic
     "c4_tex1k": (1000000, 4096, 1024, 2048, "room"),
 }
@@ -295,6 +299,7 @@ def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5, cube=12
     view_of = lambda it: (it * world + rank) % len(views)
     if gs is not None:
         gs.stage_shift(view_of(0), gs.draw_shift())
+    dist_util.comm_reset()
     for it in range(warmup + steps):
         v = view_of(it)
         torch.cuda.synchronize()
@@ -309,6 +314,7 @@ def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5, cube=12
         if it >= warmup:
             times.append((time.perf_counter() - t0) * 1e3)
     med = float(np.median(times))
+    comm_bytes = dist_util.COMM["bytes"] / float(warmup + steps)
     # The same steps queued back to back, as the trainer's loop issues them (no host synchronisation per step: the next step's shifts are drawn and
     # staged while the current one runs): total time / steps.  `ms` above is the LATENCY of one step (launch + run + the host noticing the end), the
     # figure of the earlier rounds; this is the step PERIOD of a running optimisation.
@@ -347,7 +353,8 @@ def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5, cube=12
         else:
             tnote = "profiles/pmc_mat_step.json was taken with other sources"
     return {"ms": round(med, 3), "ms_back_to_back": None if b2b is None else round(b2b, 3), "host_ms_per_step": None if host_ms is None else round(host_ms, 3),
-            "views_per_step": world, "ms_per_view": round(med / world, 3),
+            "views_per_step": world, "ms_per_view": round(med / world, 3), "mat_shard": "view" if world > 1 else None,
+            "collective_bytes_per_step": int(comm_bytes) if world > 1 else 0,
             "stage": 2, "steps": steps, "warmup": warmup, "hipgraph": bool(graphs),
             "roofline": {"bound": "hbm", "achieved": round(step_bytes / (med * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(step_bytes / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_step": int(step_bytes),
@@ -356,6 +363,57 @@ def mat_leg(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5, cube=12
                                  "rays are cache-served BVH traffic and are not counted" % (n_par / 1e6, P, S)},
             "config": "stage-2 step: albedo %d^2x3 + roughness %d^2x1 (%.1f M params), %d px x %d spp, %d-tri mesh, %d views%s"
                       % (tres, tres, (tres * tres * 4) / 1e6, 6 * cube * cube, S, sc0["T"], len(views), ", view-sharded + grad all_reduce" if world > 1 else "")}
+
+
+def mat_leg_pixel(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5, cube=128, tres=4096):
+    """N > 1, train.mat_shard = pixel (the trainer's default, SURVEY.md 8e(i) parity mode): ONE view per step, its pixels split across the ranks for the
+    specular trace and its backward, the texture side replicated (sharded_step.ShardedMatStep): two all_gathers of per-pixel data per step, nothing reduced.
+    The trajectory is the single-GPU one bit for bit, so the step's loss must be equal on every rank: checked here on the timed steps."""
+    import torch.distributed as dist
+    from texir_code_amd import dist_util
+    from texir_code_amd.sharded_step import ShardedMatStep
+    S = 16
+    model, views, data, loss_fn, opt = mat_setup(sc, sc0, irr_tex, res, dev, cube, S, tres)
+    for p in (model.materials_a, model.materials_r):
+        p.grad = None
+    ss = ShardedMatStep(model, loss_fn, opt, [model.materials_a, model.materials_r], use_graph=os.environ.get("TEXIR_MAT_GRAPH", "1") == "1")
+    for v in range(len(views)):
+        mvp, cam, gt, gmask, seg, fm, room = data[v]
+        ss.capture(v, mvp, cam, gt, gmask, seg, fm, room, 2)
+    torch.manual_seed(666)                 # every rank draws the same full-view shifts from the CPU generator, like the single-GPU run
+    dist_util.comm_reset()
+    times, losses = [], []
+    for it in range(warmup + steps):
+        v = it % len(views)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss = ss.step(v, 2)
+        torch.cuda.synchronize()
+        if it >= warmup:
+            times.append((time.perf_counter() - t0) * 1e3)
+            losses.append(loss.detach().reshape(1).clone())
+    comm_bytes = dist_util.COMM["bytes"] / float(warmup + steps)
+    med = float(np.median(times))
+    tt = torch.tensor([med], device=dev, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    mine = torch.cat(losses)
+    every = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    agree = all(bool(torch.equal(every[0], e)) for e in every[1:])
+    # back to back (no host synchronisation per step), as the trainer with train.log_lag > 0 queues them
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for it in range(steps):
+        ss.step(it % len(views), 2)
+    torch.cuda.synchronize()
+    b2b = torch.tensor([(time.perf_counter() - t0) * 1e3 / steps], device=dev, dtype=torch.float64)
+    dist.all_reduce(b2b, op=dist.ReduceOp.MAX)
+    return {"ms": round(float(tt.item()), 3), "ms_back_to_back": round(float(b2b.item()), 3), "views_per_step": 1, "mat_shard": "pixel",
+            "collective_bytes_per_step": int(comm_bytes), "collectives_per_step": 2, "ranks_agree_on_every_loss": agree,
+            "stage": 2, "steps": steps, "warmup": warmup, "hipgraph": "graphs" in next(iter(ss.views.values())),
+            "config": "stage-2 step: albedo %d^2x3 + roughness %d^2x1, %d px x %d spp split over %d ranks (pixel slices), texture side replicated"
+                      % (tres, tres, 6 * cube * cube, S, world)}
 
 
 def load_pmc(workload, kernel):
@@ -428,6 +486,56 @@ def roofline(workload, kernel, kern_ms, rays_this_rank, world, alg):
     return out
 
 
+XGMI_LINK_GBS = 153.0         # per xGMI link and direction (7 links x ~153 GB/s per GPU, point to point)
+
+
+def project_scaling(sc, d_pos, d_nrm, d_shift, ids_all, spp, res, dev, t1_ms, worlds=(2, 4, 8)):
+    """The 1 -> N curve of ONE texture as far as one GPU can measure it: every block-cyclic shard of the N-rank partition (dist_util.shard_block_cyclic,
+    the lists the N ranks would trace) is launched ALONE on this GPU and timed with HIP events; a rank's step is its kernel + the all_gather of the
+    compacted texel values (modelled: ring over one xGMI link per neighbour, (N-1)/N x 12 B x valid texels / 153 GB/s) + the scatter of the other ranks'
+    rows into its texture (measured here).  projected_speedup = T(1) / (max_r T(shard r) + t_all_gather + t_scatter).  What this cannot see: RCCL launch
+    latency, clock differences between GPUs, host jitter of 8 processes."""
+    from texir_code_amd import dist_util
+    out = {}
+    irr = torch.zeros((res * res, 3), device=dev)
+    n_all = int(ids_all.numel())
+    for w in worlds:
+        plan = dist_util.shard_plan(ids_all, w, BLOCK, dev)
+        ms = []
+        for r in range(w):
+            ids = plan[r].to(torch.int32)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            sc.irt_generate(d_pos, d_nrm, d_shift, spp, "uniform", texel_ids=ids, out=irr)
+            b.record()
+            torch.cuda.synchronize()
+            ms.append(a.elapsed_time(b))
+        # the receiving side of assemble_shards on rank 0: scatter of the other ranks' rows
+        mx = max(int(p_.numel()) for p_ in plan)
+        fake = torch.zeros((w * mx, 3), device=dev)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        mine = torch.zeros((mx, 3), device=dev)
+        mine[: plan[0].numel()] = irr[plan[0]]
+        for r in range(1, w):
+            irr[plan[r]] = fake[r * mx: r * mx + plan[r].numel()]
+        b.record()
+        torch.cuda.synchronize()
+        scatter_ms = a.elapsed_time(b)
+        ag_bytes = 12.0 * mx * w
+        ag_ms = (w - 1) / w * ag_bytes / (XGMI_LINK_GBS * 1e9) * 1e3
+        step = max(ms) + ag_ms + scatter_ms
+        out[str(w)] = {"shard_kernel_ms": [round(x, 2) for x in ms], "shard_kernel_ms_max": round(max(ms), 2), "shard_kernel_ms_mean": round(float(np.mean(ms)), 2),
+                       "imbalance": round(max(ms) / float(np.mean(ms)), 4), "sum_over_shards_vs_one_launch": round(sum(ms) / t1_ms, 4),
+                       "all_gather_bytes": int(ag_bytes), "all_gather_ms_model": round(ag_ms, 3), "scatter_ms": round(scatter_ms, 3),
+                       "projected_step_ms": round(step, 2), "projected_speedup": round(t1_ms / step, 3), "projected_mrays_s": round(n_all * spp / step / 1e3, 1)}
+    out["note"] = ("each shard of the N-rank block-cyclic partition (%d-texel blocks of the Morton-ordered valid list) traced alone on ONE GPU; all_gather modelled as a ring over one "
+                   "xGMI link (%.0f GB/s); T(1) = %.2f ms (this run's kernel average).  sum_over_shards_vs_one_launch > 1 = what splitting costs (fewer texels per launch: tail + cold caches)"
+                   % (BLOCK, XGMI_LINK_GBS, t1_ms))
+    return out
+
+
 def spawn(args):
     """--gpus N without a launcher: re-execute under torch.distributed.run, one rank per GPU"""
     n_dev = torch.cuda.device_count()
@@ -459,8 +567,12 @@ def main():
     ap.add_argument("--mat-steps", type=int, default=50)
     ap.add_argument("--mat-res", type=int, default=4096, help="albedo / roughness texture size of the material leg (4096 = BASELINE.json's)")
     ap.add_argument("--mat-cube", type=int, default=128)
+    ap.add_argument("--no-project", dest="project", action="store_false", help="skip the per-shard timing of the 2/4/8-rank partitions (N = 1 only; `ranks.projected`)")
+    ap.add_argument("--e2e", dest="e2e", action="store_true", default=None, help="time the stages end to end from files on disk (tools/stage_time.py): `e2e` in the line; "
+                    "default: on with the full c4 headline line, off otherwise")
+    ap.add_argument("--no-e2e", dest="e2e", action="store_false")
     ap.add_argument("--extra", default=None, help="comma-separated extra workloads timed after the headline (IrT only), reported under extra_workloads; "
-                    "default: c4_scan (the hostile sibling) next to the full c4 headline line, nothing otherwise or with --no-cpu / --no-mat; `none` switches it off")
+                    "default: c4_scan (the hostile sibling) and house (the multi-room family) next to the full c4 headline line, nothing otherwise or with --no-cpu / --no-mat; `none` switches it off")
     args = ap.parse_args()
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
@@ -576,19 +688,30 @@ def main():
                      "assembled_ok": ok, "assembled_check": "rank 0 alone re-traced every 100th %d-texel block of the list; bit-equal to the assembled (all-gathered) texture" % BLOCK}
         T, _, tex_res, _, style = WORKLOADS[name]
         n_valid = int(ids_all.numel())
+        if world == 1 and args.project:
+            ranks = {"projected": project_scaling(sc, d_pos, d_nrm, d_shift, ids_all, spp, res, dev, kern_ms)}
         return {"sc": sc, "sc0": sc0, "pos": pos, "nrm": nrm, "valid": valid, "shift": shift, "res": res, "spp": spp, "irr": irr, "ids": ids,
                 "dt": dt, "kern_ms": kern_ms, "ranks": ranks, "n_valid": n_valid, "build_s": build_s, "kernel": sc.irt_kernel_name(int(ids.numel()), spp),
                 "value": n_valid * spp * steps / dt / 1e6,
                 "desc": "%s: IrT %d spp, %dx%d texels (%d valid), %d-tri synthetic %s mesh, %dx%d RGB32F radiance texture"
-                        % (name, spp, res, res, n_valid, T, "indoor" if style == "room" else "scan-like (rotated clutter, slats, openings)", tex_res, tex_res)}
+                        % (name, spp, res, res, n_valid, T, {"room": "indoor", "scan": "scan-like (rotated clutter, slats, openings)", "house": "3x3-room house (doors, untessellated shell + dense clutter, windows)"}[style], tex_res, tex_res)}
 
     r = run_irt(args.workload, args.steps, args.warmup)
-    mat = None
+    mat = mat_view = None
     if not args.no_mat and (args.workload == "c4" or args.mat):
         import contextlib
         with contextlib.redirect_stdout(sys.stderr):          # (constructors print like the reference's; stdout carries the JSON line only)
-            mat = mat_leg(r["sc"], r["sc0"], r["irr"], r["res"], dev, rank, world, steps=args.mat_steps, warmup=min(5, args.mat_steps),
-                          cube=args.mat_cube, tres=args.mat_res)
+            if world > 1:
+                # both shardings of the material step: pixel = the trainer's default and the parity mode (one view per step, small all_gathers),
+                # view = throughput mode (one view per rank per step, texture-gradient all_reduce).  `material_step` is the default mode's.
+                mat = mat_leg_pixel(r["sc"], r["sc0"], r["irr"], r["res"], dev, rank, world, steps=args.mat_steps, warmup=min(5, args.mat_steps),
+                                    cube=args.mat_cube, tres=args.mat_res)
+                torch.cuda.empty_cache()
+                mat_view = mat_leg(r["sc"], r["sc0"], r["irr"], r["res"], dev, rank, world, steps=args.mat_steps, warmup=min(5, args.mat_steps),
+                                   cube=args.mat_cube, tres=args.mat_res)
+            else:
+                mat = mat_leg(r["sc"], r["sc0"], r["irr"], r["res"], dev, rank, world, steps=args.mat_steps, warmup=min(5, args.mat_steps),
+                              cube=args.mat_cube, tres=args.mat_res)
 
     out = None
     if rank == 0:
@@ -602,6 +725,8 @@ def main():
         }
         if mat is not None:
             out["material_step"] = mat
+        if mat_view is not None:
+            out["material_step_view_mode"] = mat_view
         if r["ranks"] is not None:
             out["ranks"] = r["ranks"]
             out["assembled_ok"] = r["ranks"]["assembled_ok"]
@@ -626,23 +751,40 @@ def main():
             out["cpu_baseline"] = cpu
     # further workloads (IrT only), never the headline
     if args.extra is None:          # the full default line (what the driver runs) carries the hostile sibling; tool invocations (--no-cpu / --no-mat) stay lean
-        args.extra = "c4_scan" if (args.workload == "c4" and not args.no_cpu and not args.no_mat) else ""
+        args.extra = "c4_scan,house" if (args.workload == "c4" and not args.no_cpu and not args.no_mat) else ""
     extras = [w for w in args.extra.split(",") if w and w != "none"]
     if extras:
         del r
         torch.cuda.empty_cache()
         ex = {}
         for w in extras:
-            e = run_irt(w, args.steps, args.warmup)
+            xs, xw = min(args.steps, 5), min(args.warmup, 1)       # (the kernel's time is stable after one pass: the siblings need not repeat the headline's step count)
+            e = run_irt(w, xs, xw)
             if rank == 0:
-                ex[w] = {"value": round(e["value"], 2), "unit": "Mrays/s", "ms_per_step": round(e["dt"] / args.steps * 1e3, 3), "workload": e["desc"],
+                ex[w] = {"value": round(e["value"], 2), "unit": "Mrays/s", "ms_per_step": round(e["dt"] / xs * 1e3, 3), "steps": xs, "warmup": xw, "workload": e["desc"],
                          "kernel": e["kernel"], "scene": e["sc"].info()}
+                if e["ranks"] is not None:
+                    ex[w]["ranks"] = e["ranks"]
                 if load_pmc(w, e["kernel"])[0] is not None:         # (measured bounds where tools/profile_round.sh has profiled this workload too)
                     ex[w]["roofline"] = roofline(w, e["kernel"], e["kern_ms"], int(e["ids"].numel()) * e["spp"], world, None)
             del e
             torch.cuda.empty_cache()
         if rank == 0:
             out["extra_workloads"] = ex
+    # the stages end to end, files on disk to files on disk (tools/stage_time.py): default with the full headline line, --e2e / --no-e2e force it
+    if args.e2e is None:
+        args.e2e = args.workload == "c4" and not args.no_cpu and not args.no_mat and world == 1
+    if args.e2e and rank == 0 and world == 1:
+        r = None
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        try:
+            import contextlib
+            import stage_time
+            with contextlib.redirect_stdout(sys.stderr):
+                out["e2e"] = stage_time.run(args.workload if args.workload in stage_time.SIZES else "c4")
+        except Exception as e:                # the headline line must survive a failing stage run; the failure is in the line
+            out["e2e"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -52,6 +52,49 @@ def test_block_cyclic_shard_and_assemble_world2():
     mp.spawn(_worker, args=(2, _free_port(), 1000), nprocs=2, join=True)
 
 
+def test_block_cyclic_shard_and_assemble_world8_ragged():
+    """8 ranks (the node the path is sharded for): a list whose last block is ragged (8 x 3 full rounds of 64-texel blocks + 37 entries) ..."""
+    mp.spawn(_worker, args=(8, _free_port(), 64 * 8 * 3 + 37), nprocs=8, join=True)
+
+
+def test_block_cyclic_shard_and_assemble_world8_fewer_blocks_than_ranks():
+    """... and a list shorter than one round (4 blocks, the last one ragged): ranks 4..7 own nothing and must still take part in the collective"""
+    mp.spawn(_worker, args=(8, _free_port(), 64 * 3 + 5), nprocs=8, join=True)
+
+
+def _plan_worker(rank, world, port):
+    """shard_plan + assemble_shards with a plan, on a Morton-ordered list (what the model and the bench use), incl. an all-empty list"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from texir_code_amd import dist_util
+    W = 96
+    g = torch.Generator().manual_seed(5)
+    valid = torch.rand(W * W, generator=g) > 0.35
+    ids = dist_util.morton_order(torch.nonzero(valid)[:, 0].to(torch.int32), W)
+    plan = dist_util.shard_plan(ids, world, block=256)
+    assert sum(int(p.numel()) for p in plan) == ids.numel() and torch.equal(torch.sort(torch.cat(plan))[0], torch.sort(ids.long())[0])
+    mine = dist_util.shard_block_cyclic(ids, rank, world, block=256)
+    assert torch.equal(mine.long(), plan[rank])
+    val = lambda i: torch.stack([i.float(), i.float() * 0.5, -i.float()], -1)
+    tex = torch.zeros(W * W, 3)
+    tex[mine.long()] = val(mine)
+    dist_util.comm_reset()
+    dist_util.assemble_shards(tex, ids, block=256, plan=plan)
+    ref = torch.zeros(W * W, 3)
+    ref[ids.long()] = val(ids)
+    assert torch.equal(tex, ref)
+    mx = max(int(p.numel()) for p in plan)
+    assert dist_util.COMM["bytes"] == world * mx * 12 and dist_util.COMM["calls"] == 1
+    empty = torch.zeros(0, dtype=torch.int32)
+    t0 = torch.full((16, 3), 2.0)
+    assert torch.equal(dist_util.assemble_shards(t0.clone(), empty, block=256), t0)              # nothing listed anywhere: no collective, texture untouched
+    dist.destroy_process_group()
+
+
+def test_shard_plan_and_assemble_morton_world8():
+    mp.spawn(_plan_worker, args=(8, _free_port()), nprocs=8, join=True)
+
+
 def test_shard_world1_identity():
     from texir_code_amd import dist_util
     ids = torch.arange(10)

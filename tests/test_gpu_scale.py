@@ -76,9 +76,28 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert d["ranks"]["assembled_ok"] is True and len(d["ranks"]["kernel_ms"]) == 2 and d["ranks"]["kernel_ms_max"] >= d["ranks"]["kernel_ms_min"] > 0
     fp = d["ranks"]["footprint_per_rank"]
     assert fp["replicated_scene_bytes"] > 0 and fp["irt_scratch_bytes"] >= 0 and fp["texel_gbuffers_bytes"] > 0
-    # the material leg of the N > 1 line: one view per rank per optimiser step, texture gradients summed over the ranks
+    # the material legs of the N > 1 line, both shardings: `material_step` = the trainer's default, pixel mode -- one view per step, two small
+    # all_gathers of per-pixel data, every rank on the same trajectory; `material_step_view_mode` = one view per rank per step, texture gradients summed
     m = d["material_step"]
-    assert m["views_per_step"] == 2 and m["ms"] > 0 and abs(m["ms_per_view"] - m["ms"] / 2) < 2e-3
+    P = 6 * 32 * 32
+    assert m["mat_shard"] == "pixel" and m["views_per_step"] == 1 and m["ms"] > 0 and m["ranks_agree_on_every_loss"] is True
+    assert m["collective_bytes_per_step"] == 2 * (P // 2) * (12 + 16)               # rgb [P_r,3] + (d albedo, d roughness) [P_r,4], gathered from 2 ranks
+    v = d["material_step_view_mode"]
+    assert v["mat_shard"] == "view" and v["views_per_step"] == 2 and v["ms"] > 0 and abs(v["ms_per_view"] - v["ms"] / 2) < 2e-3
+    assert v["collective_bytes_per_step"] > m["collective_bytes_per_step"]
+
+
+def test_bench_eight_ranks_on_one_gpu_over_gloo_c2_shape():
+    """the driver's 8-GPU command shape on the one GPU there is: 8 ranks over gloo trace the 8 block-cyclic shards of a c2-shaped workload (200 k triangles,
+    2048^2 texels) at 64 spp, assemble them through the all_gather, and rank 0's re-trace of sampled blocks of every rank must equal the assembled texture"""
+    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29561",
+              "bench.py", "--gpus", "8", "--workload", "c2", "--spp", "64", "--steps", "1", "--warmup", "1", "--no-cpu", "--no-mat"],
+             timeout=1500, env={"TEXIR_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks"]["assembled_ok"] is True and len(d["ranks"]["kernel_ms"]) == 8
 
 
 def test_pixel_sharded_material_step_is_the_single_gpu_step_bit_for_bit(tmp_path):

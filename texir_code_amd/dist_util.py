@@ -4,6 +4,20 @@ the texture gradients."""
 import torch
 
 
+# payload accounting of the data-path collectives this module (and sharded_step) issues: bytes of the tensors handed to RCCL, per call site.
+# bench.py resets it around a timed loop and reports bytes per step; nothing on the device path reads it.
+COMM = {"bytes": 0, "calls": 0}
+
+
+def account(t, times=1):
+    COMM["bytes"] += int(t.numel()) * t.element_size() * times
+    COMM["calls"] += 1
+
+
+def comm_reset():
+    COMM["bytes"], COMM["calls"] = 0, 0
+
+
 def shard_block_cyclic(ids, rank, world, block=4096):
     """rank's share of the compacted valid-texel list: blocks of `block` consecutive entries, block b -> rank b % world.
     Interleaving balances load (occupancy and ray cost vary over the atlas).  The shares are disjoint and cover ids."""
@@ -67,6 +81,7 @@ def assemble_shards(tex, ids_all, block=4096, plan=None):
     out = torch.empty((world * mx, C), device=tex.device, dtype=tex.dtype)
     # which form of the collective to issue is decided from the backend BEFORE anything is issued (and so identically on every rank): a fall-back
     # taken after a failed attempt would leave the ranks issuing different collectives -- real collective errors propagate
+    account(mine, world)
     if _flat_all_gather_ok(tex):
         dist.all_gather_into_tensor(out, mine)
     else:
@@ -120,13 +135,16 @@ def reduce_texture_grads(params):
                 p._texir_grad_l2 = zeros(e1, e2)
             if getattr(p, "_texir_grad_l1", None) is None:
                 p._texir_grad_l1 = zeros(0, e1)
+            account(p._texir_grad_l1)
             dist.all_reduce(p._texir_grad_l1)
             p._texir_l1_zero = False            # (another rank's view may have written level 1: the summed stack must be read)
             if n2 > 0:                         # (the fold level 2 -> 1 is left to the optimiser step as well: both parts are linear in the ranks' sums)
+                account(p._texir_grad_l2)
                 dist.all_reduce(p._texir_grad_l2)
         if n0 > 0:
             if p.grad is None:                 # this rank's pixels touched no level-0 texel (the tensor was never made), another rank's did
                 p.grad = torch.zeros_like(p)
+            account(p.grad)
             dist.all_reduce(p.grad)
 
 

@@ -146,6 +146,7 @@ class ShardedMatStep:
     def _gather(self, recv, send):
         import torch.distributed as dist
         if self.world > 1:
+            dist_util.account(send, self.world)
             dist.all_gather(recv, send)
         else:
             recv[0].copy_(send)

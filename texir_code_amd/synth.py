@@ -19,7 +19,7 @@ GUTTER = 3.0 / 1024.0
 
 
 class Patch:
-    __slots__ = ("o", "eu", "ev", "n", "lu", "lv", "gu", "gv", "rect", "cls", "vbase", "tbase", "ntri", "amp", "phase")
+    __slots__ = ("o", "eu", "ev", "n", "lu", "lv", "gu", "gv", "rect", "cls", "vbase", "tbase", "ntri", "amp", "phase", "fixed", "flat")
 
     def __init__(self, o, eu, ev, cls):
         self.o = np.asarray(o, np.float64)
@@ -30,6 +30,8 @@ class Patch:
         self.lv = float(np.linalg.norm(self.ev))
         self.n = n / np.linalg.norm(n)
         self.cls = cls
+        self.fixed = None               # (gu, gv) when the generator fixes the tessellation of this patch (house style: the untessellated shell)
+        self.flat = False               # no displacement (large planar triangles)
 
 
 def _room_and_boxes(rng, n_boxes):
@@ -124,8 +126,135 @@ def _scan_clutter(rng):
     return P
 
 
+HOUSE = (16.0, 3.0, 12.0)            # footprint of the `house` style: 3 x 3 rooms
+HOUSE_WALL = 0.12
+
+
+def _wall(o, eu_dir, length, height, cls, hole=None):
+    """vertical wall rectangle from corner o along the horizontal unit vector eu_dir (normal = eu_dir x +y), optionally with a rectangular hole
+    (a0, a1, b0, b1) in wall coordinates: the patches around the hole"""
+    o, e = np.asarray(o, np.float64), np.asarray(eu_dir, np.float64)
+    up = np.array([0.0, 1.0, 0.0])
+    if hole is None:
+        return [Patch(o, e * length, up * height, cls)]
+    a0, a1, b0, b1 = hole
+    out = []
+    if a0 > 1e-6:
+        out.append(Patch(o, e * a0, up * height, cls))
+    if length - a1 > 1e-6:
+        out.append(Patch(o + e * a1, e * (length - a1), up * height, cls))
+    if b0 > 1e-6:
+        out.append(Patch(o + e * a0, e * (a1 - a0), up * b0, cls))
+    if height - b1 > 1e-6:
+        out.append(Patch(o + e * a0 + up * b1, e * (a1 - a0), up * (height - b1), cls))
+    return out
+
+
+def _house(rng):
+    """`house` style (bench workload `house`): what the reference's data looks like (README.md:21-34: whole multi-room houses reconstructed from scans) --
+    a 16 x 3 x 12 m footprint cut into 3 x 3 rooms by 12 cm walls, nine door openings between rooms (rays cross rooms through them; most of the
+    house is occluded from any one texel), six windows and an entrance to the outside (p_hit < 1), every room's shell left as a handful of LARGE flat
+    triangles (fixed coarse grids: what mesh simplification leaves of planar walls), and ~25 rotated / stacked clutter boxes plus furniture per room that
+    receive all the remaining triangles (millimetre-scale, displaced like scanned surfaces).  Returns (patches, emissive rectangles)."""
+    X, Y, Z = HOUSE
+    t = HOUSE_WALL
+    nx, nz = 3, 3
+    xs, zs = np.linspace(0, X, nx + 1), np.linspace(0, Z, nz + 1)
+    P, emissive, clutter = [], [], []
+    door_w, door_h = 1.0, 2.1
+
+    def shell(ps):
+        for p in ps:
+            p.fixed = (max(1, int(round(p.lu / 2.5))), max(1, int(round(p.lv / 2.5))))
+            p.flat = True
+        P.extend(ps)
+
+    for i in range(nx):
+        for j in range(nz):
+            x0 = xs[i] + (t / 2 if i > 0 else 0.0)
+            x1 = xs[i + 1] - (t / 2 if i < nx - 1 else 0.0)
+            z0 = zs[j] + (t / 2 if j > 0 else 0.0)
+            z1 = zs[j + 1] - (t / 2 if j < nz - 1 else 0.0)
+            dx, dz = x1 - x0, z1 - z0
+            zc, xc = 0.5 * (z0 + z1), 0.5 * (x0 + x1)
+            shell([Patch((x0, 0, z0), (0, 0, dz), (dx, 0, 0), 46)])                           # floor   n = +y
+            ceil_index = len(P)
+            shell([Patch((x0, Y, z0), (dx, 0, 0), (0, 0, dz), 44)])                           # ceiling n = -y
+            emissive.append((ceil_index, 0.4, 0.4, 0.2, 0.2))
+            door_x = (zc - door_w / 2, zc + door_w / 2, 0.0, door_h)                          # door in a wall running along z (world z range)
+            door_z = (xc - door_w / 2, xc + door_w / 2, 0.0, door_h)
+            win = (0.9, 2.2)
+            # z = z0 wall (n = +z), eu = +x from (x0, 0, z0)
+            if j == 0:
+                hole = (dx / 2 - 0.8, dx / 2 + 0.8, win[0], win[1])                            # window to the outside
+            else:
+                hole = (door_z[0] - x0, door_z[1] - x0, 0.0, door_h) if (i + (j - 1)) % 2 == 0 else None
+            shell(_wall((x0, 0, z0), (1, 0, 0), dx, Y, 45, hole))
+            # z = z1 wall (n = -z), eu = -x from (x1, 0, z1)
+            if j == nz - 1:
+                hole = (x1 - door_z[1], x1 - door_z[0], 0.0, door_h) if i == 1 else None      # the entrance
+            else:
+                hole = (x1 - door_z[1], x1 - door_z[0], 0.0, door_h) if (i + j) % 2 == 0 else None
+            shell(_wall((x1, 0, z1), (-1, 0, 0), dx, Y, 45, hole))
+            # x = x0 wall (n = +x), eu = -z from (x0, 0, z1)
+            hole = (z1 - door_x[1], z1 - door_x[0], 0.0, door_h) if i > 0 else None
+            w_first = len(P)
+            shell(_wall((x0, 0, z1), (0, 0, -1), dz, Y, 45, hole))
+            if i == 0 and j == 1:
+                emissive.append((w_first, 0.35, 0.4, 0.3, 0.4))                                # a bright wall panel
+            # x = x1 wall (n = -x), eu = +z from (x1, 0, z0)
+            if i == nx - 1:
+                hole = (dz / 2 - 0.8, dz / 2 + 0.8, win[0], win[1])                            # window
+            else:
+                hole = (door_x[0] - z0, door_x[1] - z0, 0.0, door_h)
+            shell(_wall((x1, 0, z0), (0, 0, 1), dz, Y, 45, hole))
+            # door frames through the wall's thickness (each door once: from the room on its low side): two jambs, lintel underside, threshold
+            if i < nx - 1:
+                xa, xb = x1, x1 + t
+                shell([Patch((xa, 0, door_x[0]), (t, 0, 0), (0, door_h, 0), 45),                # jamb at z = door low, n = +z
+                       Patch((xb, 0, door_x[1]), (-t, 0, 0), (0, door_h, 0), 45),               # jamb at z = door high, n = -z
+                       Patch((xa, door_h, door_x[0]), (t, 0, 0), (0, 0, door_w), 45),           # lintel underside, n = -y
+                       Patch((xa, 0, door_x[0]), (0, 0, door_w), (t, 0, 0), 46)])               # threshold, n = +y
+            if j < nz - 1 and (i + j) % 2 == 0:
+                za, zb = z1, z1 + t
+                shell([Patch((door_z[0], 0, zb), (0, 0, -t), (0, door_h, 0), 45),               # jamb at x = door low, n = +x
+                       Patch((door_z[1], 0, za), (0, 0, t), (0, door_h, 0), 45),                # jamb at x = door high, n = -x
+                       Patch((door_z[0], door_h, za), (door_w, 0, 0), (0, 0, t), 45),           # lintel underside, n = -y
+                       Patch((door_z[0], 0, za), (0, 0, t), (door_w, 0, 0), 46)])               # threshold, n = +y
+            # clutter: rotated boxes anywhere in the room's volume, clear of the door axes' first 60 cm
+            for _ in range(22):
+                half = rng.uniform(0.05, 0.45, 3) * rng.uniform(0.3, 1.0)
+                c = np.array([rng.uniform(x0 + 0.7, x1 - 0.7), rng.uniform(0.1, Y - 0.3), rng.uniform(z0 + 0.7, z1 - 0.7)])
+                clutter += _box_faces(c, _rot(rng), half, int(rng.integers(0, 43)))
+            # furniture: three floor-standing axis-aligned boxes (no bottom face)
+            for _ in range(3):
+                w, d, h = rng.uniform(0.5, 1.6), rng.uniform(0.4, 0.9), rng.uniform(0.4, 2.0)
+                bx, bz = rng.uniform(x0 + 0.1, x1 - w - 0.1), rng.uniform(z0 + 0.1, z1 - d - 0.1)
+                cls = int(rng.integers(0, 43))
+                clutter += [Patch((bx, h, bz), (0, 0, d), (w, 0, 0), cls), Patch((bx, 0, bz), (0, h, 0), (w, 0, 0), cls),
+                            Patch((bx, 0, bz + d), (w, 0, 0), (0, h, 0), cls), Patch((bx, 0, bz), (0, 0, d), (0, h, 0), cls),
+                            Patch((bx + w, 0, bz), (0, h, 0), (0, 0, d), cls)]
+            # a venetian blind in front of the windows of the two corner rooms on the z = 0 side
+            if j == 0 and i in (0, nx - 1):
+                tilt = np.deg2rad(35.0)
+                Rs = np.array([[1, 0, 0], [0, np.cos(tilt), -np.sin(tilt)], [0, np.sin(tilt), np.cos(tilt)]], np.float64)
+                for k in range(40):
+                    c = np.array([xc, 0.92 + k * (1.26 / 40), z0 + 0.08])
+                    clutter += _box_faces(c, Rs, np.array([0.85, 0.015, 0.001]), 42)
+    return P + clutter, emissive
+
+
 def _allocate_grids(P, T):
-    """choose (gu, gv) per patch, quads ~ area, 2*sum(gu*gv) <= T (remainder fixed by edge splits)."""
+    """choose (gu, gv) per patch, quads ~ area, 2*sum(gu*gv) <= T (remainder fixed by edge splits).  Patches with a `fixed` grid keep it; the
+    others share what is left of T."""
+    fixed = [p for p in P if p.fixed is not None]
+    if fixed:
+        for p in fixed:
+            p.gu, p.gv = p.fixed
+        T = T - sum(2 * p.gu * p.gv for p in fixed)
+        P = [p for p in P if p.fixed is None]
+        if T < 2 * len(P):
+            raise ValueError("not enough triangles for the fixed shell plus one quad per remaining patch")
     if T <= 2 * len(P):
         for p in P:
             p.gu = p.gv = 1
@@ -211,15 +340,22 @@ def _scan_heights(p, rng, gu, gv):
 def make_scene(T, seed=666, tex_res=1024, n_boxes=40, amp=3e-3, style="room"):
     """returns dict: verts [V,3] f32, tris [T,3] i32, tri_uvs [3T,2] f32, hdr [tex_res,tex_res,3] f32,
     patches (list of Patch), plus per-chart GT material colours.  style = "room" (axis-aligned room + boxes)
-    or "scan" (_scan_clutter: rotated clutter, thin slats, openings, noisy surfaces; T >= 20000)."""
+    or "scan" (_scan_clutter: rotated clutter, thin slats, openings, noisy surfaces; T >= 20000) or "house" (_house: 3 x 3 rooms joined by doors,
+    large untessellated shell triangles next to dense clutter, windows; T >= 10000)."""
     rng = np.random.default_rng(seed)
     if T < 12 or T % 2:
         raise ValueError("T must be even and >= 12")
+    emissive = None
     if style == "scan":
         if T < 4000:
             raise ValueError("scan style needs T >= 4000")
         P = _scan_clutter(rng)
         amp = 1.2e-2
+    elif style == "house":
+        if T < 10000:
+            raise ValueError("house style needs T >= 10000")
+        P, emissive = _house(rng)
+        amp = 6e-3
     else:
         P = _room_and_boxes(rng, 0 if T < 12 + 40 * 10 else n_boxes)
     _allocate_grids(P, T)
@@ -228,12 +364,12 @@ def make_scene(T, seed=666, tex_res=1024, n_boxes=40, amp=3e-3, style="room"):
     vbase = 0
     tcount = 0
     for p in P:
-        p.amp = amp if (p.gu > 1 and p.gv > 1) else 0.0
+        p.amp = amp if (p.gu > 1 and p.gv > 1 and not p.flat) else 0.0
         p.phase = rng.uniform(0, 1, 3)
         gu, gv = p.gu, p.gv
         a = np.linspace(0.0, 1.0, gu + 1)
         b = np.linspace(0.0, 1.0, gv + 1)
-        hgt = _scan_heights(p, rng, gu, gv) if style == "scan" else _patch_heights(p, p.phase, gu, gv)
+        hgt = _scan_heights(p, rng, gu, gv) if (style in ("scan", "house") and p.amp > 0.0) else _patch_heights(p, p.phase, gu, gv)
         pos = (p.o[None, None, :] + a[:, None, None] * p.eu[None, None, :] + b[None, :, None] * p.ev[None, None, :]
                + hgt[:, :, None] * p.n[None, None, :])
         verts.append(pos.reshape(-1, 3))
@@ -280,6 +416,8 @@ def make_scene(T, seed=666, tex_res=1024, n_boxes=40, amp=3e-3, style="room"):
         "verts": verts.astype(np.float32), "tris": tris.astype(np.int32),
         "tri_uvs": tuvs.reshape(-1, 2).astype(np.float32), "patches": P, "seed": seed, "T": T, "tri_class": tcls, "style": style,
     }
+    if emissive is not None:
+        sc["emissive"] = emissive
     sc["hdr"] = make_hdr_texture(sc, tex_res, seed)
     return sc
 
@@ -328,6 +466,8 @@ def make_hdr_texture(sc, res, seed=666):
              (2, 0.3, 0.45, 0.25, 0.35), (5, 0.35, 0.4, 0.3, 0.4)]
     if sc.get("style") == "scan":          # patch 1 is the ceiling in both styles; the wall lights sit on the z=Z and x=0 walls
         lamps = lamps[:4] + [(6, 0.3, 0.45, 0.25, 0.35), (7, 0.35, 0.4, 0.3, 0.4)]
+    if sc.get("emissive") is not None:     # (house: one ceiling lamp per room + a wall panel, listed by the generator)
+        lamps = sc["emissive"]
     for (pi, a0, b0, da, db) in lamps:
         p = P[pi]
         x, y, w, h = p.rect
