@@ -373,6 +373,7 @@ def mat_leg_pixel(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5, c
     from texir_code_amd import dist_util
     from texir_code_amd.sharded_step import ShardedMatStep
     S = 16
+    torch.manual_seed(666)                 # the ground-truth views are rendered with shifts from the CPU generator: the same stream on every rank
     model, views, data, loss_fn, opt = mat_setup(sc, sc0, irr_tex, res, dev, cube, S, tres)
     for p in (model.materials_a, model.materials_r):
         p.grad = None
@@ -400,6 +401,7 @@ def mat_leg_pixel(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5, c
     every = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(every, mine)
     agree = all(bool(torch.equal(every[0], e)) for e in every[1:])
+    spread = float(max((every[0] - e).abs().max().item() for e in every[1:])) if world > 1 else 0.0
     # back to back (no host synchronisation per step), as the trainer with train.log_lag > 0 queues them
     torch.cuda.synchronize()
     dist.barrier()
@@ -410,7 +412,8 @@ def mat_leg_pixel(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5, c
     b2b = torch.tensor([(time.perf_counter() - t0) * 1e3 / steps], device=dev, dtype=torch.float64)
     dist.all_reduce(b2b, op=dist.ReduceOp.MAX)
     return {"ms": round(float(tt.item()), 3), "ms_back_to_back": round(float(b2b.item()), 3), "views_per_step": 1, "mat_shard": "pixel",
-            "collective_bytes_per_step": int(comm_bytes), "collectives_per_step": 2, "ranks_agree_on_every_loss": agree,
+            "collective_bytes_per_step": int(comm_bytes), "collectives_per_step": 2, "ranks_agree_on_every_loss": agree, "max_loss_spread_over_ranks": spread,
+            "first_losses_rank0": [float(x) for x in every[0][:4].tolist()],
             "stage": 2, "steps": steps, "warmup": warmup, "hipgraph": "graphs" in next(iter(ss.views.values())),
             "config": "stage-2 step: albedo %d^2x3 + roughness %d^2x1, %d px x %d spp split over %d ranks (pixel slices), texture side replicated"
                       % (tres, tres, 6 * cube * cube, S, world)}
@@ -729,7 +732,8 @@ def main():
             out["material_step_view_mode"] = mat_view
         if r["ranks"] is not None:
             out["ranks"] = r["ranks"]
-            out["assembled_ok"] = r["ranks"]["assembled_ok"]
+            if "assembled_ok" in r["ranks"]:
+                out["assembled_ok"] = r["ranks"]["assembled_ok"]
         rays_this_rank = int(r["ids"].numel()) * r["spp"]
         alg = cpu = None
         if not args.no_cpu:

@@ -190,6 +190,20 @@ __device__ __forceinline__ float edge2_exact(float bx, float by, float cx, float
 // ------------------------------------------------------------------------------------------------
 struct Hit { float t, u, v; int slot; };
 
+// TEXIR_CHAIN_PROBE (measurement build only, tools/chain_probe.sh; 0 = shipped): the wave reads the shader clock (s_memtime) around every wave-level step of
+// trace_core -- per-lane (vector) node step, wave-uniform (scalar-cache) node step, leaf step -- and the kernel around the trace, the hit shader and the whole
+// pass; cycles and step counts per kind go to stats[8...] (kernels.hip irt_probe_flush).  Summed over the resident waves these cycles ARE the kernel's duration
+// (a wave is always in exactly one of the measured regions or in the scheduler between them), which is what bench.py's `roofline.limits.chain` is built from.
+#ifndef TEXIR_CHAIN_PROBE
+#define TEXIR_CHAIN_PROBE 0
+#endif
+#if TEXIR_CHAIN_PROBE
+__device__ __forceinline__ uint32_t probe_clock() { return (uint32_t)__builtin_amdgcn_s_memtime(); }
+// wave-uniform accumulate (keeps the counter in an SGPR)
+__device__ __forceinline__ void probe_add(uint32_t& acc, uint32_t x) { acc = (uint32_t)__builtin_amdgcn_readfirstlane((int)(acc + x)); }
+#endif
+constexpr int kProbeSlots = 6;       // wave_iters[2 + ...]: cycles / count of vector node steps, scalar node steps, leaf steps
+
 // TEXIR_SCHED (A/B switch; 1 = default).  How the wave shares its issue slots between lanes that hold an inner node and lanes
 // that hold a leaf:
 //   0: "while-while" -- node steps until NO lane holds an inner node, then leaf steps until NO lane holds a leaf.  One lane on a
@@ -324,6 +338,10 @@ __device__ __forceinline__ Hit trace_core(const SceneDev& sc, float ox, float oy
         }
     };
 
+#if TEXIR_CHAIN_PROBE
+    bool probe_scalar_path = false;
+    uint32_t pc_nv = 0, pn_nv = 0, pc_ns = 0, pn_ns = 0, pc_lf = 0, pn_lf = 0;
+#endif
     // ---- one node step of the 4-wide tree: four box tests, sort, push the far children, descend into the nearest ----
     auto node_step4 = [&]() __attribute__((always_inline)) {
         float key[4]; int code[4];
@@ -356,6 +374,9 @@ __device__ __forceinline__ Hit trace_core(const SceneDev& sc, float ox, float oy
         // axis plane), the step reads the FLOAT planes of the node (GpuNode4F) through wave-uniform offsets that pick the near / far
         // plane arrays: no byte -> float conversion (24 per step), no sign select, no origin / cell-size set-up.
         const int n0 = __builtin_amdgcn_readfirstlane(node);
+#if TEXIR_CHAIN_PROBE
+        probe_scalar_path = signs_uniform && !__any(node != n0);
+#endif
         if (signs_uniform && !__any(node != n0)) {
             typedef float F4 __attribute__((ext_vector_type(4)));
             typedef int32_t I4 __attribute__((ext_vector_type(4)));
@@ -567,9 +588,28 @@ __device__ __forceinline__ Hit trace_core(const SceneDev& sc, float ox, float oy
         const bool at_node = (uint32_t)node < (uint32_t)kSentinel;        // an inner node (>= 0 and not the sentinel)
         const unsigned long long m_node = __ballot(at_node), m_leaf = __ballot(node < 0);
         if (!(m_node | m_leaf)) break;
+#if TEXIR_CHAIN_PROBE
+        const uint32_t c0 = probe_clock();
+        if (sched_w * __popcll(m_node) >= __popcll(m_leaf)) {
+            if (at_node) node_step();
+            const uint32_t dt = probe_clock() - c0;
+            if (__ballot(at_node && probe_scalar_path)) { probe_add(pc_ns, dt); probe_add(pn_ns, 1u); }
+            else { probe_add(pc_nv, dt); probe_add(pn_nv, 1u); }
+        } else {
+            if (node < 0) leaf_step();
+            probe_add(pc_lf, probe_clock() - c0); probe_add(pn_lf, 1u);
+        }
+#else
         if (sched_w * __popcll(m_node) >= __popcll(m_leaf)) { if (at_node) node_step(); }
         else if (node < 0) leaf_step();
+#endif
     }
+#if TEXIR_CHAIN_PROBE
+    if (wave_iters) {
+        probe_add(wave_iters[2], pc_nv); probe_add(wave_iters[3], pn_nv); probe_add(wave_iters[4], pc_ns); probe_add(wave_iters[5], pn_ns);
+        probe_add(wave_iters[6], pc_lf); probe_add(wave_iters[7], pn_lf);
+    }
+#endif
 #else
     while (node != kSentinel) {
         while (node >= 0 && node != kSentinel) node_step();

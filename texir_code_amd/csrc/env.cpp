@@ -35,6 +35,7 @@ static Env parse()
     const int mc = geti("TEXIR_IRT_MIN_PART_CELLS", 8);
     v.irt_min_part_cells = mc >= 1 ? mc : 8;
     v.irt_log2parts_cap = getenv("TEXIR_IRT_LOG2PARTS") ? std::max(0, geti("TEXIR_IRT_LOG2PARTS", 0)) : -1;
+    v.irt_grid_cap = std::max(0, geti("TEXIR_IRT_GRID_CAP", 0));
     const int gc = geti("TEXIR_SPEC_GRID_CAP", 1 << 16);
     v.spec_grid_cap = gc >= 1 ? gc : (1 << 16);
     const int lpp = geti("TEXIR_SPEC_LPP", 0);
@@ -55,7 +56,7 @@ int env_switch(const char* name, int* value)
         {"TEXIR_ADAM_SCALAR", g_env.adam_scalar}, {"TEXIR_ADAM_GRID_Y", g_env.adam_grid_y}, {"TEXIR_MAX_LEAF", g_env.max_leaf},
         {"TEXIR_BOX_SLACK_LOG2", g_env.box_slack_log2}, {"TEXIR_IRT_TEXELS_PER_WAVE", g_env.irt_texels_per_wave}, {"TEXIR_IRT_REFILL", g_env.irt_refill},
         {"TEXIR_IRT_MIN_PART_CELLS", g_env.irt_min_part_cells}, {"TEXIR_IRT_LOG2PARTS", g_env.irt_log2parts_cap},
-        {"TEXIR_SPEC_GRID_CAP", g_env.spec_grid_cap}, {"TEXIR_SPEC_LPP", g_env.spec_lpp}};
+        {"TEXIR_IRT_GRID_CAP", g_env.irt_grid_cap}, {"TEXIR_SPEC_GRID_CAP", g_env.spec_grid_cap}, {"TEXIR_SPEC_LPP", g_env.spec_lpp}};
     for (const auto& t : tab)
         if (name && !strcmp(name, t.n)) { *value = t.v; return 0; }
     return -1;

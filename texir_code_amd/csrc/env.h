@@ -19,6 +19,7 @@ struct Env {
     int irt_refill;            // TEXIR_IRT_REFILL           0 = lock-step passes (default) | 1..63: refill idle lanes once this many have gathered (irt_stream_kernel)
     int irt_min_part_cells;    // TEXIR_IRT_MIN_PART_CELLS   8 (default)
     int irt_log2parts_cap;     // TEXIR_IRT_LOG2PARTS        -1 = no cap
+    int irt_grid_cap;          // TEXIR_IRT_GRID_CAP         0 = every co-resident workgroup (default) | blocks of the persistent IrT grid (256 = one wave per SIMD: occupancy sweeps, tools/chain_probe.py)
     int spec_grid_cap;         // TEXIR_SPEC_GRID_CAP        65536 (default)
     int spec_lpp;              // TEXIR_SPEC_LPP             0 = automatic | forced lanes per pixel (power of two)
 };

@@ -42,6 +42,18 @@ __device__ __forceinline__ void irt_stats_flush(unsigned long long* stats, int l
     }
 }
 
+#if TEXIR_CHAIN_PROBE
+// stats[8 + q] of a probe build (device_common.h TEXIR_CHAIN_PROBE), added once per chunk by lane 0; q =
+//   0 cycles / 1 count of per-lane (vector) node steps, 2 / 3 wave-uniform (scalar-cache) node steps, 4 / 5 leaf steps   [trace_core]
+//   6 cycles inside trace_closest, 7 passes;  8 cycles in the hit shader, 9 passes with a hit;  10 cycles of whole passes (sampling + trace + shade)
+//   11 cycles of whole chunks (hand-out, texel fetch, passes, reduction, store), 12 chunks
+constexpr int kProbeStats = 13;
+__device__ __forceinline__ void irt_probe_flush(unsigned long long* stats, int lane, const uint32_t* v)
+{
+    if (lane == 0 && stats) for (int q = 0; q < kProbeStats; q++) if (v[q]) atomicAdd(&stats[8 + q], (unsigned long long)v[q]);
+}
+#endif
+
 // Occupancy.  Round 1 (4-byte stack entries): 5 waves / 24 entries 13.85, 6 / 24 14.79, 7 / 16 15.11, 8 / 16 15.06 Grays/s (c4).  Round 2, after the
 // scalar node path took the L1 off the critical path (8-byte entries): 6 waves / 12 entries 15.01, 7 / 11 15.82, 8 / 10 15.87 (c2: 16.30, 17.11, 17.40;
 // c4_scan: 4.98, 5.31, 5.54): 8 waves per SIMD = 64 VGPRs (the compiler parks the per-texel frame and the ray's shear rows in scratch across the
@@ -162,7 +174,7 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
     const int lane = threadIdx.x & 63;
     const int grp = lane >> LOG2M, sub = lane & (M - 1);
     const int n_cells = N >> LOG2M;
-    uint32_t cn = 0, ct = 0, c_rays = 0, c_hits = 0, wi[2] = {0, 0};
+    uint32_t cn = 0, ct = 0, c_rays = 0, c_hits = 0, wi[2 + kProbeSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool cosw = (mode & kEstimatorCosine) != 0;
     mode &= 3;
     // A chunk = GRP texels x (all passes / 2^log2parts).  With parts > 1 the raw partial sums go to partial[part][k][3] and
@@ -196,6 +208,11 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
             continue;
         }
         dry = 0;
+#if TEXIR_CHAIN_PROBE
+        uint32_t pv[kProbeStats] = {0};
+        const uint32_t chunk_c0 = probe_clock();
+        for (int q = 2; q < 2 + kProbeSlots; q++) wi[q] = 0;
+#endif
         const int part = (owner << log2ppo) | (int)(chunk & ((1ull << log2ppo) - 1ull));
         const int64_t k0 = (int64_t)(chunk >> log2ppo) * GRP;
         const int64_t k = k0 + grp;
@@ -208,6 +225,9 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
         float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
         for (int Lc = part * part_cells; Lc < (part + 1) * part_cells; Lc++) {
             const int J = (TEXIR_PART_WEDGE && log2N >= 0) ? (((Lc & ((1 << bth) - 1)) << bphi) | (Lc >> bth)) : Lc;
+#if TEXIR_CHAIN_PROBE
+            const uint32_t pass_c0 = probe_clock();
+#endif
             if (live) {
                 // (N not a power of two: only the one-sample-per-pass form is launched, in natural sample order)
                 const uint32_t i = log2N < 0 ? (uint32_t)J : sample_index_m(cell_to_pass_m((uint32_t)J, sh0, sh1, log2N, LOG2M), (uint32_t)sub, log2N, LOG2M);
@@ -216,7 +236,14 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
                 float d[3];
                 sample_dir<TEXIR_IRT_FAST_SINCOS != 0>(mode, s0, s1, 0.f, f, d);
                 const float ndl = cosw ? 1.f : fminf(fmaxf(nx * d[0] + ny * d[1] + nz * d[2], 0.f), 1.f);       // :170, RAW normal (before the trace: one live register instead of three)
+#if TEXIR_CHAIN_PROBE
+                const uint32_t tr_c0 = probe_clock();
+                Hit h = trace_closest<STATS, kGroupLstk, WIDTH, kCull>(sc, px, py, pz, d[0], d[1], d[2], cn, ct, wi);
+                const uint32_t tr_c1 = probe_clock();
+                probe_add(pv[6], tr_c1 - tr_c0); probe_add(pv[7], 1u);
+#else
                 Hit h = trace_closest<STATS, kGroupLstk, WIDTH, kCull>(sc, px, py, pz, d[0], d[1], d[2], cn, ct, STATS ? wi : nullptr);
+#endif
                 if (STATS) c_rays++;
                 if (h.slot >= 0 && h.t > 1e-4f) {          // tracer_o3d_irt.py:248
                     float L[3];
@@ -224,7 +251,17 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
                     acc0 += L[0] * ndl; acc1 += L[1] * ndl; acc2 += L[2] * ndl;
                     if (STATS) c_hits++;
                 }
+#if TEXIR_CHAIN_PROBE
+                // (the shader's loads are consumed by the three multiply-adds above: acc0 is data-dependent on them, the clock read below is ordered behind a
+                // use of it so that it cannot be hoisted over the wait)
+                const uint32_t sh_c1 = probe_clock() + (uint32_t)(__builtin_amdgcn_readfirstlane(__float_as_int(acc0)) & 0);
+                probe_add(pv[8], sh_c1 - tr_c1);
+                if (__any(h.slot >= 0 && h.t > 1e-4f)) probe_add(pv[9], 1u);
+#endif
             }
+#if TEXIR_CHAIN_PROBE
+            probe_add(pv[10], probe_clock() - pass_c0);
+#endif
         }
         // reduce over the M lanes of each texel
         for (int o = M >> 1; o > 0; o >>= 1) { acc0 += __shfl_xor(acc0, o, 64); acc1 += __shfl_xor(acc1, o, 64); acc2 += __shfl_xor(acc2, o, 64); }
@@ -239,6 +276,13 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
                 irr[3 * t + 2] = ((acc2 * two) * pi) / (float)N;
             }
         }
+#if TEXIR_CHAIN_PROBE
+        if constexpr (!STATS) {
+            for (int q = 0; q < kProbeSlots; q++) pv[q] = wi[2 + q];
+            pv[11] = probe_clock() - chunk_c0; pv[12] = 1u;
+            irt_probe_flush(stats, lane, pv);
+        }
+#endif
     }
     if (STATS) irt_stats_flush(stats, lane, c_rays, cn, ct, c_hits, wi[0], wi[1]);
 }
@@ -715,6 +759,7 @@ static void irt_launch(K kernel, int64_t waves_wanted, const SceneDev& sc, const
     const int64_t want = (waves_wanted + (kBlock / 64) - 1) / (kBlock / 64);
     int grid = resident_grid(kernel, kBlock);
     if (want < grid) grid = (int)want;
+    if (const int cap = env().irt_grid_cap; cap > 0 && grid > cap) grid = cap;            // occupancy sweeps only (any grid gives the same result: the waves pull chunks)
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, st, sc, pos, nrm, shift, ids, n_ids, N, l2, mode, irr, stats, work, partial, log2parts);
 }
 
@@ -737,7 +782,12 @@ hipError_t launch_irt(const SceneDev& sc, const float* pos, const float* nrm, co
     const bool pow2 = (N & (N - 1)) == 0;
     const int l2 = ilog2_exact(N);
     const IrtPlan plan = irt_plan(sc, n_ids, N);
-#define TEXIR_IRT(WAVES, L2, NAME, ...) { if (stats) irt_launch(NAME<true, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, work, partial, log2parts, st); \
+#if TEXIR_CHAIN_PROBE
+    const bool probe_group = stats && sc.nodes4 && plan.per_wave == 64 && !(env().irt_refill && pow2 && plan.log2parts > 0);
+#else
+    constexpr bool probe_group = false;
+#endif
+#define TEXIR_IRT(WAVES, L2, NAME, ...) { if (stats && !probe_group) irt_launch(NAME<true, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, work, partial, log2parts, st); \
                                         else irt_launch(NAME<false, __VA_ARGS__>, WAVES, sc, pos, nrm, shift, ids, n_ids, N, L2, mode, irr, stats, work, partial, log2parts, st); }
     const int per_wave = plan.per_wave;
     float* partial = nullptr;

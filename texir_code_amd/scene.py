@@ -130,7 +130,7 @@ class Scene:
         if texel_ids is not None:
             ids = texel_ids.to(device=self.device, dtype=torch.int32).contiguous()
             n_ids = ids.numel()
-        st = torch.zeros(8, device=self.device, dtype=torch.int64) if stats else None
+        st = torch.zeros(32, device=self.device, dtype=torch.int64) if stats else None         # [0:6] counters; [8:21] cycle probe of a TEXIR_CHAIN_PROBE build
         if Nt == 0 or (texel_ids is not None and n_ids == 0):
             # nothing to do.  (An EMPTY id list must not reach the library: its null data pointer would read as "no list = all texels" --
             # the case of a rank whose shard of a small texel list is empty, dist_util.shard_block_cyclic)
