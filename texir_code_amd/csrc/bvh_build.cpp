@@ -340,6 +340,13 @@ void build_bvh(const float* verts, int V, const int32_t* tris, int T, const floa
                 if (same(vtx(p, i), vtx(q, (j + 1) % 3)) && same(vtx(p, (i + 1) % 3), vtx(q, j))) {
                     // degenerate partners (a repeated vertex) stay single: their "shared edge" is not one
                     if (same(vtx(p, i), vtx(p, (i + 1) % 3)) || same(vtx(p, (i + 2) % 3), vtx(q, (j + 2) % 3))) return false;
+#if TEXIR_UV_QUAD
+                    // one uv per record corner: a uv seam along the shared edge keeps the two triangles single
+                    if (tri_uvs) {
+                        auto cuv = [&](int t_, int k) { return tri_uvs + 6 * (size_t)t_ + 2 * (size_t)k; };
+                        if (std::memcmp(cuv(p, i), cuv(q, (j + 1) % 3), 8) || std::memcmp(cuv(p, (i + 1) % 3), cuv(q, j), 8)) return false;
+                    }
+#endif
                     r0 = (i + 2) % 3; r1 = (j + 2) % 3; return true;
                 }
 #endif
@@ -405,7 +412,7 @@ void build_bvh(const float* verts, int V, const int32_t* tris, int T, const floa
     relayout4(out.nodes4, out.nodes4f, env().bvh_layout);
     // slot data in STORED corner order: stored corner k = the caller's corner (rot + k) % 3
     out.tris.assign(n_slots + 1, GpuTri{});
-    out.uvs.assign(n_slots + 1, GpuTriUV{});
+    out.uvs.assign((TEXIR_UV_QUAD ? n_rec : n_slots) + 1, GpuTriUV{});
     for (auto& g : out.tris) g.prim = 0xFFFFFFFFu;          // holes (the odd slot of a single) and the dummy: degenerate, never hit
     auto put_slot = [&](size_t slot, int p, int rot) {
         GpuTri& g = out.tris[slot];
@@ -419,9 +426,20 @@ void build_bvh(const float* verts, int V, const int32_t* tris, int T, const floa
         g.prim = (uint32_t)p;
         const uint32_t r = (uint32_t)rot;
         std::memcpy(&g.pad1, &r, 4); g.pad2 = 0.f;
+#if TEXIR_UV_QUAD
+        // record form: the even slot writes its three stored corners (q0, q1, q2), the odd slot its first stored corner (q3; its other two are q2, q1)
+        GpuTriUV& u = out.uvs[slot >> 1];
+        const int n_put = (slot & 1) ? 1 : 3;
+        for (int k = 0; k < n_put; k++) {
+            const float* uv = tri_uvs + 6 * (size_t)p + 2 * (size_t)((rot + k) % 3);
+            const int at = (slot & 1) ? 3 : k;
+            u.uv[2 * at] = uv[0]; u.uv[2 * at + 1] = uv[1];
+        }
+#else
         GpuTriUV& u = out.uvs[slot];
         for (int k = 0; k < 3; k++) { const float* uv = tri_uvs + 6 * (size_t)p + 2 * (size_t)((rot + k) % 3); u.uv[2 * k] = uv[0]; u.uv[2 * k + 1] = uv[1]; }
         u.uv[6] = u.uv[7] = 0.f;
+#endif
     };
 #if TEXIR_QUAD
     out.quads.assign(n_rec + 1, GpuQuad{});

@@ -52,7 +52,15 @@ constexpr int kTriQuads = 3;          // float4s per triangle record
 struct alignas(16) GpuQuad { float q[12]; };          // q0.xyz q1.xyz q2.xyz q3.xyz
 static_assert(sizeof(GpuQuad) == 48, "quad record must be 48 bytes");
 
-// 32-byte leaf-ordered corner uvs: (uv0, uv1), (uv2, 0, 0)
+// Corner uvs, fetched only for the closest hit.
+//   TEXIR_UV_QUAD = 1 (default with quad leaves): ONE 32-byte record per quad RECORD -- the uvs of its four vertices (q0, q1, q2, q3); triangle 0 (even slot)
+//     reads (q0, q1, q2), triangle 1 (odd slot) reads (q3, q2, q1), the stored corner order of its slot.  Two triangles are only paired when their corner uvs
+//     agree on the shared edge (no uv seam along it), so the four pairs are all there is.  Half the bytes of the per-slot form: a 128-byte line holds the
+//     uvs of 8 neighbouring triangles instead of 4 (the hit shader's uv fetch was 1 of its 2 lines per ray; round 5).
+//   TEXIR_UV_QUAD = 0: 32 bytes per leaf-order SLOT: (uv0, uv1), (uv2, 0, 0).
+#ifndef TEXIR_UV_QUAD
+#define TEXIR_UV_QUAD TEXIR_QUAD
+#endif
 struct alignas(16) GpuTriUV {
     float uv[8];
 };

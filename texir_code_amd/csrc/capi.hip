@@ -24,7 +24,7 @@ struct texir_scene {
     void* d_nodes = nullptr; void* d_tris = nullptr; void* d_quads = nullptr; void* d_uvs = nullptr; float* d_tex = nullptr;
     float* d_tex_tiled = nullptr;        // retiled copy read by the hit shader (texture layouts 1, 2); d_tex stays the row-major master
     size_t tiled_bytes = 0;
-    int64_t n_nodes = 0, n_nodes4 = 0, n_tris = 0, n_slots = 0 /* leaf-order slots behind d_tris / d_uvs / d_cnrm: = n_tris, or 2 per quad record (bvh_build.h) */, n_quads = 0, max_depth = 0;
+    int64_t n_nodes = 0, n_nodes4 = 0, n_tris = 0, n_slots = 0 /* leaf-order slots behind d_tris / d_uvs / d_cnrm: = n_tris, or 2 per quad record (bvh_build.h) */, n_quads = 0, n_uv_recs = 0 /* 32-byte uv records behind d_uvs: one per quad record (TEXIR_UV_QUAD) or per slot */, max_depth = 0;
     int width = 2;
     size_t tex_bytes = 0;
     std::vector<uint32_t> slot_prim;     // leaf slot -> primitive id (host copy, for per-corner attribute uploads; 0xFFFFFFFF: an empty slot)
@@ -92,7 +92,7 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
     try { build_bvh(verts, V, tris, T, tri_uvs, h); } catch (const std::bad_alloc&) { return fail(TEXIR_ERR_NOMEM, "BVH build: out of host memory"); }
     texir_scene* s = new (std::nothrow) texir_scene;
     if (!s) return fail(TEXIR_ERR_NOMEM, "out of host memory");
-    s->n_slots = h.n_slots; s->n_quads = (int64_t)h.quads.size();
+    s->n_slots = h.n_slots; s->n_quads = (int64_t)h.quads.size(); s->n_uv_recs = (int64_t)h.uvs.size();
     s->slot_prim.resize((size_t)h.n_slots); s->slot_rot.resize((size_t)h.n_slots);
     for (int64_t i = 0; i < h.n_slots; i++) { s->slot_prim[i] = h.tris[i].prim; uint32_t r; std::memcpy(&r, &h.tris[i].pad1, 4); s->slot_rot[i] = (uint8_t)(r % 3u); }
     s->device = device; s->n_nodes = (int64_t)h.nodes.size(); s->n_tris = T; s->max_depth = h.max_depth;
@@ -177,7 +177,7 @@ int texir_scene_info(const texir_scene* s, int64_t out[8])
     if (!s || !out) return fail(TEXIR_ERR_INVALID, "texir_scene_info: null argument");
     out[0] = s->width == 4 ? s->n_nodes4 : s->n_nodes; out[1] = s->n_tris; out[2] = s->max_depth;
     out[3] = s->width == 4 ? s->n_nodes4 * (int64_t)(sizeof(GpuNode4) + (s->d_nodes4f ? sizeof(GpuNode4F) : 0)) : s->n_nodes * (int64_t)sizeof(GpuNode);
-    out[4] = s->n_slots * (int64_t)sizeof(GpuTri) + s->n_quads * (int64_t)sizeof(GpuQuad); out[5] = s->d_uvs ? s->n_slots * (int64_t)sizeof(GpuTriUV) : 0; out[6] = (int64_t)(s->d_tex_tiled ? s->tiled_bytes : s->tex_bytes); out[7] = s->device;
+    out[4] = s->n_slots * (int64_t)sizeof(GpuTri) + s->n_quads * (int64_t)sizeof(GpuQuad); out[5] = s->d_uvs ? s->n_uv_recs * (int64_t)sizeof(GpuTriUV) : 0; out[6] = (int64_t)(s->d_tex_tiled ? s->tiled_bytes : s->tex_bytes); out[7] = s->device;
     return TEXIR_OK;
 }
 
@@ -191,7 +191,7 @@ int texir_scene_prefetch(const texir_scene* s, int32_t what, int32_t blocks, voi
     // (what the traversal reads of the triangles: the quad records where the library has them, else the leaf-ordered triangles)
     if ((what & 4) && s->d_quads && s->width == 4) HIP_TRY(launch_prefetch(s->d_quads, (size_t)s->n_quads * sizeof(GpuQuad), blocks, sink, (hipStream_t)stream));
     else if ((what & 4) && s->d_tris) HIP_TRY(launch_prefetch(s->d_tris, (size_t)s->n_slots * sizeof(GpuTri), blocks, sink, (hipStream_t)stream));
-    if ((what & 8) && s->d_uvs) HIP_TRY(launch_prefetch(s->d_uvs, (size_t)s->n_slots * sizeof(GpuTriUV), blocks, sink, (hipStream_t)stream));
+    if ((what & 8) && s->d_uvs) HIP_TRY(launch_prefetch(s->d_uvs, (size_t)s->n_uv_recs * sizeof(GpuTriUV), blocks, sink, (hipStream_t)stream));
     return TEXIR_OK;
 }
 

@@ -110,7 +110,16 @@ __device__ __forceinline__ void sample_dir(int mode, float s0, float s1, float r
 // corner uvs of the triangle in leaf slot `slot`: a = (uv0, uv1), b = (uv2, -, -)
 __device__ __forceinline__ void tri_uvs(const SceneDev& sc, int slot, float4& a, float4& b)
 {
+#if TEXIR_UV_QUAD
+    // one 32-byte record per quad record: (q0, q1), (q2, q3); the even slot is triangle (q0, q1, q2), the odd one (q3, q2, q1)  (bvh_build.h)
+    const size_t rec = (size_t)(slot >> 1);
+    const float4 A = sc.uvs[2 * rec], B = sc.uvs[2 * rec + 1];
+    const bool odd = (slot & 1) != 0;
+    a = odd ? make_float4(B.z, B.w, B.x, B.y) : A;
+    b = odd ? make_float4(A.z, A.w, 0.f, 0.f) : B;
+#else
     a = sc.uvs[2 * (size_t)slot]; b = sc.uvs[2 * (size_t)slot + 1];
+#endif
 }
 // primitive id (row of the caller's index array) of the triangle in leaf slot `slot`
 __device__ __forceinline__ uint32_t tri_prim(const SceneDev& sc, int slot) { return __float_as_uint(sc.tris[3 * (size_t)slot].w); }
