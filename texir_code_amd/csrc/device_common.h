@@ -206,12 +206,21 @@ struct Hit { float t, u, v; int slot; };
 #ifndef TEXIR_CHAIN_PROBE
 #define TEXIR_CHAIN_PROBE 0
 #endif
+// A clock read is not free: s_memtime goes through the scalar memory path and its result is waited for (a first probe build that read it around EVERY step
+// ran 3.9x slower than the shipped kernel and measured mostly itself).  The build therefore COUNTS every step (one scalar add) but TIMES only every
+// kProbeEvery-th wave-level step of a wave, and times an empty region right after each timed step (`null`): mean(step) - mean(null) is the step's duration
+// under the load of seven undisturbed neighbour waves.
 #if TEXIR_CHAIN_PROBE
 __device__ __forceinline__ uint32_t probe_clock() { return (uint32_t)__builtin_amdgcn_s_memtime(); }
 // wave-uniform accumulate (keeps the counter in an SGPR)
 __device__ __forceinline__ void probe_add(uint32_t& acc, uint32_t x) { acc = (uint32_t)__builtin_amdgcn_readfirstlane((int)(acc + x)); }
+#ifndef TEXIR_PROBE_EVERY
+#define TEXIR_PROBE_EVERY 32
 #endif
-constexpr int kProbeSlots = 6;       // wave_iters[2 + ...]: cycles / count of vector node steps, scalar node steps, leaf steps
+constexpr uint32_t kProbeEvery = TEXIR_PROBE_EVERY;
+#endif
+// wave_iters[2 + ...]: steps, timed steps, cycles of timed steps -- of per-lane node steps, wave-uniform node steps, leaf steps; then timed empty regions, their cycles
+constexpr int kProbeSlots = 11;
 
 // TEXIR_SCHED (A/B switch; 1 = default).  How the wave shares its issue slots between lanes that hold an inner node and lanes
 // that hold a leaf:
@@ -349,7 +358,7 @@ __device__ __forceinline__ Hit trace_core(const SceneDev& sc, float ox, float oy
 
 #if TEXIR_CHAIN_PROBE
     bool probe_scalar_path = false;
-    uint32_t pc_nv = 0, pn_nv = 0, pc_ns = 0, pn_ns = 0, pc_lf = 0, pn_lf = 0;
+    uint32_t pn_nv = 0, pt_nv = 0, pc_nv = 0, pn_ns = 0, pt_ns = 0, pc_ns = 0, pn_lf = 0, pt_lf = 0, pc_lf = 0, pt_null = 0, pc_null = 0, probe_tick = 0;
 #endif
     // ---- one node step of the 4-wide tree: four box tests, sort, push the far children, descend into the nearest ----
     auto node_step4 = [&]() __attribute__((always_inline)) {
@@ -598,16 +607,24 @@ __device__ __forceinline__ Hit trace_core(const SceneDev& sc, float ox, float oy
         const unsigned long long m_node = __ballot(at_node), m_leaf = __ballot(node < 0);
         if (!(m_node | m_leaf)) break;
 #if TEXIR_CHAIN_PROBE
-        const uint32_t c0 = probe_clock();
+        probe_add(probe_tick, 1u);
+        const bool timed = (probe_tick & (kProbeEvery - 1u)) == 0u;              // wave-uniform
+        uint32_t c0 = 0;
+        if (timed) c0 = probe_clock();
         if (sched_w * __popcll(m_node) >= __popcll(m_leaf)) {
             if (at_node) node_step();
-            const uint32_t dt = probe_clock() - c0;
-            if (__ballot(at_node && probe_scalar_path)) { probe_add(pc_ns, dt); probe_add(pn_ns, 1u); }
-            else { probe_add(pc_nv, dt); probe_add(pn_nv, 1u); }
+            const bool scalar = __ballot(at_node && probe_scalar_path) != 0ull;
+            if (scalar) probe_add(pn_ns, 1u); else probe_add(pn_nv, 1u);
+            if (timed) {
+                const uint32_t dt = probe_clock() - c0;
+                if (scalar) { probe_add(pc_ns, dt); probe_add(pt_ns, 1u); } else { probe_add(pc_nv, dt); probe_add(pt_nv, 1u); }
+            }
         } else {
             if (node < 0) leaf_step();
-            probe_add(pc_lf, probe_clock() - c0); probe_add(pn_lf, 1u);
+            probe_add(pn_lf, 1u);
+            if (timed) { probe_add(pc_lf, probe_clock() - c0); probe_add(pt_lf, 1u); }
         }
+        if (timed) { const uint32_t n0 = probe_clock(); probe_add(pc_null, probe_clock() - n0); probe_add(pt_null, 1u); }
 #else
         if (sched_w * __popcll(m_node) >= __popcll(m_leaf)) { if (at_node) node_step(); }
         else if (node < 0) leaf_step();
@@ -615,8 +632,8 @@ __device__ __forceinline__ Hit trace_core(const SceneDev& sc, float ox, float oy
     }
 #if TEXIR_CHAIN_PROBE
     if (wave_iters) {
-        probe_add(wave_iters[2], pc_nv); probe_add(wave_iters[3], pn_nv); probe_add(wave_iters[4], pc_ns); probe_add(wave_iters[5], pn_ns);
-        probe_add(wave_iters[6], pc_lf); probe_add(wave_iters[7], pn_lf);
+        const uint32_t v[kProbeSlots] = {pn_nv, pt_nv, pc_nv, pn_ns, pt_ns, pc_ns, pn_lf, pt_lf, pc_lf, pt_null, pc_null};
+        for (int q = 0; q < kProbeSlots; q++) probe_add(wave_iters[2 + q], v[q]);
     }
 #endif
 #else

@@ -44,10 +44,10 @@ __device__ __forceinline__ void irt_stats_flush(unsigned long long* stats, int l
 
 #if TEXIR_CHAIN_PROBE
 // stats[8 + q] of a probe build (device_common.h TEXIR_CHAIN_PROBE), added once per chunk by lane 0; q =
-//   0 cycles / 1 count of per-lane (vector) node steps, 2 / 3 wave-uniform (scalar-cache) node steps, 4 / 5 leaf steps   [trace_core]
-//   6 cycles inside trace_closest, 7 passes;  8 cycles in the hit shader, 9 passes with a hit;  10 cycles of whole passes (sampling + trace + shade)
-//   11 cycles of whole chunks (hand-out, texel fetch, passes, reduction, store), 12 chunks
-constexpr int kProbeStats = 13;
+//   0-2 steps / timed steps / cycles of the timed steps of per-lane (vector) node steps, 3-5 of wave-uniform (scalar-cache) node steps, 6-8 of leaf steps,
+//   9-10 timed empty regions / their cycles   [trace_core];   11 passes, 12 timed passes, 13 cycles inside trace_closest, 14 cycles in the hit shader,
+//   15 cycles of whole passes (sampling + trace + shade) -- of the timed passes (every 8th);  16 cycles of whole chunks, 17 chunks
+constexpr int kProbeStats = 18;
 __device__ __forceinline__ void irt_probe_flush(unsigned long long* stats, int lane, const uint32_t* v)
 {
     if (lane == 0 && stats) for (int q = 0; q < kProbeStats; q++) if (v[q]) atomicAdd(&stats[8 + q], (unsigned long long)v[q]);
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
     const int lane = threadIdx.x & 63;
     const int grp = lane >> LOG2M, sub = lane & (M - 1);
     const int n_cells = N >> LOG2M;
-    uint32_t cn = 0, ct = 0, c_rays = 0, c_hits = 0, wi[2 + kProbeSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t cn = 0, ct = 0, c_rays = 0, c_hits = 0, wi[2 + kProbeSlots] = {0};
     const bool cosw = (mode & kEstimatorCosine) != 0;
     mode &= 3;
     // A chunk = GRP texels x (all passes / 2^log2parts).  With parts > 1 the raw partial sums go to partial[part][k][3] and
@@ -226,7 +226,10 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
         for (int Lc = part * part_cells; Lc < (part + 1) * part_cells; Lc++) {
             const int J = (TEXIR_PART_WEDGE && log2N >= 0) ? (((Lc & ((1 << bth) - 1)) << bphi) | (Lc >> bth)) : Lc;
 #if TEXIR_CHAIN_PROBE
-            const uint32_t pass_c0 = probe_clock();
+            const bool pass_timed = (Lc & 7) == 0;
+            uint32_t pass_c0 = 0;
+            if (pass_timed) pass_c0 = probe_clock();
+            probe_add(pv[11], 1u);
 #endif
             if (live) {
                 // (N not a power of two: only the one-sample-per-pass form is launched, in natural sample order)
@@ -237,10 +240,10 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
                 sample_dir<TEXIR_IRT_FAST_SINCOS != 0>(mode, s0, s1, 0.f, f, d);
                 const float ndl = cosw ? 1.f : fminf(fmaxf(nx * d[0] + ny * d[1] + nz * d[2], 0.f), 1.f);       // :170, RAW normal (before the trace: one live register instead of three)
 #if TEXIR_CHAIN_PROBE
-                const uint32_t tr_c0 = probe_clock();
+                uint32_t tr_c0 = 0, tr_c1 = 0;
+                if (pass_timed) tr_c0 = probe_clock();
                 Hit h = trace_closest<STATS, kGroupLstk, WIDTH, kCull>(sc, px, py, pz, d[0], d[1], d[2], cn, ct, wi);
-                const uint32_t tr_c1 = probe_clock();
-                probe_add(pv[6], tr_c1 - tr_c0); probe_add(pv[7], 1u);
+                if (pass_timed) { tr_c1 = probe_clock(); probe_add(pv[13], tr_c1 - tr_c0); probe_add(pv[12], 1u); }
 #else
                 Hit h = trace_closest<STATS, kGroupLstk, WIDTH, kCull>(sc, px, py, pz, d[0], d[1], d[2], cn, ct, STATS ? wi : nullptr);
 #endif
@@ -252,15 +255,16 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
                     if (STATS) c_hits++;
                 }
 #if TEXIR_CHAIN_PROBE
-                // (the shader's loads are consumed by the three multiply-adds above: acc0 is data-dependent on them, the clock read below is ordered behind a
-                // use of it so that it cannot be hoisted over the wait)
-                const uint32_t sh_c1 = probe_clock() + (uint32_t)(__builtin_amdgcn_readfirstlane(__float_as_int(acc0)) & 0);
-                probe_add(pv[8], sh_c1 - tr_c1);
-                if (__any(h.slot >= 0 && h.t > 1e-4f)) probe_add(pv[9], 1u);
+                // (the shader's loads are consumed by the three multiply-adds above: the clock read below is ordered behind a use of acc0 so that it cannot be
+                // hoisted over the wait)
+                if (pass_timed) {
+                    const uint32_t sh_c1 = probe_clock() + (uint32_t)(__builtin_amdgcn_readfirstlane(__float_as_int(acc0)) & 0);
+                    probe_add(pv[14], sh_c1 - tr_c1);
+                }
 #endif
             }
 #if TEXIR_CHAIN_PROBE
-            probe_add(pv[10], probe_clock() - pass_c0);
+            if (pass_timed) probe_add(pv[15], probe_clock() - pass_c0);
 #endif
         }
         // reduce over the M lanes of each texel
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(kBlock, kGroupWaves) void irt_group_kernel(SceneDev
 #if TEXIR_CHAIN_PROBE
         if constexpr (!STATS) {
             for (int q = 0; q < kProbeSlots; q++) pv[q] = wi[2 + q];
-            pv[11] = probe_clock() - chunk_c0; pv[12] = 1u;
+            pv[16] = probe_clock() - chunk_c0; pv[17] = 1u;
             irt_probe_flush(stats, lane, pv);
         }
 #endif

@@ -81,7 +81,11 @@ class GraphedMatStep:
         self.model._static_shift = self.shift_bufs[key][0] if self.zero_copy else self.static_shift
         import gc
         from .scene import defer_destroy
-        gc.collect()                                    # finalisers (hipFree of dead scenes/tensors) must not run inside the capture
+        # finalisers (hipFree of dead scenes / tensors) must not run inside a capture: the collector is switched off for its duration; a full collection
+        # beforehand is only worth its 20-50 ms once per step object (a stage captures one graph per view: 16-500 of them back to back)
+        if not getattr(self, "_collected_once", False):
+            gc.collect()
+            self._collected_once = True
         gc_was = gc.isenabled()
         gc.disable()
         try:

@@ -11,6 +11,7 @@ from datetime import datetime
 import torch
 
 from ..conf import ConfigFactory
+from ..runlog import phases
 
 
 class RunnerBase:
@@ -56,13 +57,21 @@ class RunnerBase:
         for epoch in range(first_epoch, last_epoch + 1):
             if epoch_begin is not None:
                 epoch_begin(epoch)
-            for data_index, batch in enumerate(loader):
+            it = iter(loader)
+            data_index = -1
+            while True:
+                with phases.phase("in_stages:dataloader", sync=False):
+                    batch = next(it, None)
+                if batch is None:
+                    break
+                data_index += 1
                 if takes is not None and not takes(data_index):
                     continue
                 self.model.train()
                 if before_step is not None:
                     before_step(epoch, data_index)
-                out = step(batch)
+                with phases.phase("in_stages:step_host", sync=False):
+                    out = step(batch)
                 self.cur_iter += 1
                 if after_step is not None and after_step(epoch, data_index, out):
                     return True

@@ -44,6 +44,22 @@ def build_masks(segs, stage_m1_rgb, room_img=None, positions=None, room_meta=Non
     return source_seg_mask, floor_max_mask, room_mask
 
 
+def collate_one_view(batch):
+    """what torch's default_collate returns for a batch of ONE item -- tensors with a leading dimension of 1, strings in a list, numbers as tensors -- without
+    copying the tensors"""
+    if len(batch) != 1:
+        return torch.utils.data.default_collate(batch)
+    out = {}
+    for k, v in batch[0].items():
+        if torch.is_tensor(v):
+            out[k] = v.unsqueeze(0)
+        elif isinstance(v, (str, bytes)):
+            out[k] = [v]
+        else:
+            out[k] = torch.utils.data.default_collate([v])
+    return out
+
+
 class MatTrainRunner(RunnerBase):
     def __init__(self, **kwargs):
         # --is_continue: the reference's resume path is dead code (SURVEY.md B.11); the flags are accepted and ignored
@@ -57,7 +73,9 @@ class MatTrainRunner(RunnerBase):
             self.train_dataset = get_class(self.conf.get_string("train.dataset_class"))(
                 self.conf.get_string("train.path_mesh_open3d"), self.conf.get_list("train.pano_img_res"), self.conf.get_float("train.hdr_exposure"))
         print("Finish loading data ...")
-        self.train_dataloader = torch.utils.data.DataLoader(self.train_dataset, batch_size=1, shuffle=True)
+        # batch_size = 1, shuffle = True as in the reference (train_material.py:101-104: the sampler's draws are part of the CPU random stream); the batch
+        # is the item itself with a leading dimension of one -- views instead of default_collate's stacked copies (1.3 MB per step at c = 128)
+        self.train_dataloader = torch.utils.data.DataLoader(self.train_dataset, batch_size=1, shuffle=True, collate_fn=collate_one_view)
         with phases.phase("model_init"):
             self.model = get_class(self.conf.get_string("train.model_class"))(
                 conf=self.conf, ids=self.train_dataset.ids, extrinsics=self.train_dataset.extrinsics_list, optim_cam=self.conf.get_bool("train.optim_cam"))
@@ -141,8 +159,9 @@ class MatTrainRunner(RunnerBase):
                 return None
             mvp, cam, gt, gmask = self._view_inputs(gt_item, vid0)
             try:
-                self._gs.capture(vid0, mvp, cam, gt, gmask, self.seg_mask[str(vid0)], self.floor_max_mask[str(vid0)],
-                                 self.room_seg_mask[str(vid0)] if stage == 2 else None, stage)
+                with phases.phase("in_stages:graph_capture"):
+                    self._gs.capture(vid0, mvp, cam, gt, gmask, self.seg_mask[str(vid0)], self.floor_max_mask[str(vid0)],
+                                     self.room_seg_mask[str(vid0)] if stage == 2 else None, stage)
             except Exception as e:          # capture is an optimisation, not a requirement
                 print("hipGraph capture unavailable (%s); continuing with eager steps" % (str(e).splitlines()[0][:160],), file=sys.stderr)
                 self.use_graph = False
@@ -260,11 +279,13 @@ class MatTrainRunner(RunnerBase):
         def report(epoch, data_index, loss_v, seg_v, dt, it):
             self.log.append((stage, epoch, data_index, float(loss_v), float(seg_v)))     # the reference prints .item() every step too
             # scalars under the reference's names at the step's own (pre-increment) iteration index (train_material.py:465-468, 532-536, 600-604)
-            lt = self.conf.get_string("render_loss.loss_type")
-            self.writer.add_scalar("img_loss_%s_stage%d" % (lt, stage), loss_v, it)
-            self.writer.add_scalar("seg_loss_%s_stage%d" % (lt, stage), seg_v, it)
-            if stage > 0:
-                self.writer.add_scalar("tv_loss_%s_stage%d" % (lt, stage), 0.0, it)       # (always 0 in the reference: models/loss.py:105,115)
+            w = getattr(self, "writer", None)                 # (a runner assembled without setup_experiment -- tests -- has no run directory and no log)
+            if w is not None:
+                lt = self.conf.get_string("render_loss.loss_type")
+                w.add_scalar("img_loss_%s_stage%d" % (lt, stage), loss_v, it)
+                w.add_scalar("seg_loss_%s_stage%d" % (lt, stage), seg_v, it)
+                if stage > 0:
+                    w.add_scalar("tv_loss_%s_stage%d" % (lt, stage), 0.0, it)       # (always 0 in the reference: models/loss.py:105,115)
             print("{0} [{1}] ({2}/{3}): img_loss_stage{7} ({5}) = {4}, seg_loss = {6}, batch cost time : {8:.4f}s".format(
                 self.expname, epoch, data_index, self.n_batches, loss_v, self.conf.get_string("render_loss.loss_type"), seg_v, stage, dt))
 
@@ -289,7 +310,9 @@ class MatTrainRunner(RunnerBase):
                 pending.append((epoch, data_index, host, ev, time.time() - t0[0], self.cur_iter - 1))
                 drain(getattr(self, "log_lag", 0))
             else:
-                report(epoch, data_index, loss.item(), seg_item, time.time() - t0[0], self.cur_iter - 1)
+                with phases.phase("in_stages:loss_item_wait", sync=False):
+                    loss_v = loss.item()
+                report(epoch, data_index, loss_v, seg_item, time.time() - t0[0], self.cur_iter - 1)
             return max_steps is not None and self.cur_iter >= max_steps
 
         try:
@@ -334,7 +357,8 @@ class MatTrainRunner(RunnerBase):
             if getattr(self, "_plots", None) is not None:
                 self._plots.close()
                 self._plots = None
-        self.writer.flush()
+        if getattr(self, "writer", None) is not None:
+            self.writer.flush()
 
 
 class MatTrainSynRunner(MatTrainRunner):

@@ -68,7 +68,7 @@ static uint32_t sample_index(uint32_t cell, int log2N)
 
 struct Ray { float o[3], d[3], id[3], ood[3]; float t; int slot; int node; int pleaf = 0; std::vector<int> stk; std::vector<float> stk_t; };
 
-struct Counters { double rays = 0, nodes = 0, tris = 0, wnode = 0, wtri = 0, culled = 0, hits = 0, wcull = 0, maxsp = 0, wuni = 0, wuni0 = 0, wdeep[4] = {0, 0, 0, 0}, lines = 0, wmaxn = 0, rounds = 0, wmaxt = 0, refills = 0, refill_lanes = 0, spread = 0, specpops = 0, un_nodes = 0, un_leaves = 0, dh[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dl[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };
+struct Counters { double rays = 0, nodes = 0, tris = 0, wnode = 0, wtri = 0, culled = 0, hits = 0, wcull = 0, maxsp = 0, wuni = 0, wuni0 = 0, wdeep[4] = {0, 0, 0, 0}, lines = 0, wmaxn = 0, rounds = 0, wmaxt = 0, refills = 0, refill_lanes = 0, spread = 0, specpops = 0, un_nodes = 0, un_leaves = 0, dh[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, parked = 0, cpass = 0, cwnode = 0, cwtri = 0, cnodes = 0, ctris = 0, ah[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; };
 
 static const int kSent = 0x7FFFFFFF;
 
@@ -77,8 +77,8 @@ int main(int argc, char** argv)
     if (argc < 2) { fprintf(stderr, "usage: bvh_sim <dir> [groups=64] [passes=64] [variant flags: cull cull8 nosort]\n"); return 1; }
     std::string dir = argv[1];
     int n_groups = argc > 2 ? atoi(argv[2]) : 64, n_pass = argc > 3 ? atoi(argv[3]) : 64;
-    bool cull = false, cull8 = false, nosort = false, psort3 = false; int policy = 0; double alpha = 1.0, alpha2 = 1.0, tricost = 1.5; int refillK = 0; int spec = 0; int switch_after = 0;
-    for (int i = 4; i < argc; i++) { if (!strcmp(argv[i], "cull")) cull = true; if (!strcmp(argv[i], "cull8")) cull = cull8 = true; if (!strcmp(argv[i], "nosort")) nosort = true; if (!strcmp(argv[i], "psort3")) psort3 = true; if (!strncmp(argv[i], "after:", 6)) switch_after = atoi(argv[i] + 6); if (!strcmp(argv[i], "spec")) spec = 1; if (!strcmp(argv[i], "spec2")) spec = 2; if (!strncmp(argv[i], "refill:", 7)) refillK = atoi(argv[i] + 7); if (!strncmp(argv[i], "arr", 3)) { policy = 2; if (argv[i][3] == ':') { alpha = alpha2 = atof(argv[i] + 4); const char* c2 = strchr(argv[i] + 4, ','); if (c2) alpha2 = atof(c2 + 1); } } if (!strncmp(argv[i], "maj", 3)) { policy = 1; if (argv[i][3] == ':') { alpha = alpha2 = atof(argv[i] + 4); const char* c2 = strchr(argv[i] + 4, ','); if (c2) alpha2 = atof(c2 + 1); } } if (!strncmp(argv[i], "tricost:", 8)) tricost = atof(argv[i] + 8); }
+    bool cull = false, cull8 = false, nosort = false, psort3 = false; int policy = 0; double alpha = 1.0, alpha2 = 1.0, tricost = 1.5; int refillK = 0; int spec = 0; int switch_after = 0; int parkK = 0, parkM = 0;
+    for (int i = 4; i < argc; i++) { if (!strcmp(argv[i], "cull")) cull = true; if (!strcmp(argv[i], "cull8")) cull = cull8 = true; if (!strcmp(argv[i], "nosort")) nosort = true; if (!strcmp(argv[i], "psort3")) psort3 = true; if (!strncmp(argv[i], "after:", 6)) switch_after = atoi(argv[i] + 6); if (!strcmp(argv[i], "spec")) spec = 1; if (!strcmp(argv[i], "spec2")) spec = 2; if (!strncmp(argv[i], "refill:", 7)) refillK = atoi(argv[i] + 7); if (!strncmp(argv[i], "arr", 3)) { policy = 2; if (argv[i][3] == ':') { alpha = alpha2 = atof(argv[i] + 4); const char* c2 = strchr(argv[i] + 4, ','); if (c2) alpha2 = atof(c2 + 1); } } if (!strncmp(argv[i], "maj", 3)) { policy = 1; if (argv[i][3] == ':') { alpha = alpha2 = atof(argv[i] + 4); const char* c2 = strchr(argv[i] + 4, ','); if (c2) alpha2 = atof(c2 + 1); } } if (!strncmp(argv[i], "tricost:", 8)) tricost = atof(argv[i] + 8); if (!strncmp(argv[i], "park:", 5)) { parkK = atoi(argv[i] + 5); const char* c2 = strchr(argv[i] + 5, ','); parkM = c2 ? atoi(c2 + 1) : 0; } }
     auto verts = load<float>(dir + "/verts.f32"); auto tris = load<int32_t>(dir + "/tris.i32"); auto uvs = load<float>(dir + "/tri_uvs.f32");
     auto pos = load<float>(dir + "/pos.f32"); auto nrm = load<float>(dir + "/nrm.f32"); auto shift = load<float>(dir + "/shift.f32");
     auto ids = load<int32_t>(dir + "/ids.i32"); auto meta = load<int32_t>(dir + "/meta.i32");
@@ -211,8 +211,19 @@ int main(int argc, char** argv)
             // refill mode: the lanes of a wave walk n_pass CONSECUTIVE cells each at its own pace; finished lanes take their next cell when at least
             // refillK lanes are idle (or nothing else is left to do)
             const uint32_t Jbase = (uint32_t)((gi * 97) % 32) * (uint32_t)(N / 32);
-            for (int pj = 0; pj < (refillK ? 1 : n_pass); pj++) {
+            std::vector<Ray> queue; bool in_compact = false;
+            for (int pj = 0; pj < (refillK ? 1 : n_pass) || !queue.empty(); pj++) {
                 const uint32_t J = refillK ? Jbase : (uint32_t)((double)pj / n_pass * N);
+                in_compact = false;
+                const double w0n = c.wnode, w0t = c.wtri, n0 = c.nodes, t0 = c.tris;
+                if (parkK && (queue.size() >= 64 || pj >= n_pass)) {
+                    // a compact pass over (up to) 64 parked rays
+                    in_compact = true; pj--;
+                    const size_t take = std::min<size_t>(64, queue.size());
+                    for (size_t l = 0; l < 64; l++) { if (l < take) R[l] = queue[queue.size() - take + l]; else { R[l].node = kSent; R[l].pleaf = 0; R[l].stk.clear(); R[l].stk_t.clear(); R[l].slot = -1; } }
+                    queue.resize(queue.size() - take);
+                    c.cpass++; c.rays -= 64;          // (not new rays)
+                } else
                 for (int l = 0; l < 64; l++) { init_ray(l, J); lane_pass[l] = 0; }
                 if (refillK) { c.refills++; c.refill_lanes += 64; }
                 c.rays += 64;
@@ -301,7 +312,7 @@ int main(int argc, char** argv)
                 };
                 // scheduling policy: 0 = the kernel's while-while (node phase until no lane holds an inner node, then leaf phase until no lane holds a leaf);
                 // 1 = per step, the phase with more waiting lanes (node lanes weighted by `alpha`)
-                int phase = 0, prev_nl = 0, sched_iter = -1;
+                int phase = 0, prev_nl = 0, sched_iter = -1, few_steps = 0;
                 for (;;) {
                     sched_iter++;
                     int nn = 0, nl = 0;
@@ -317,6 +328,19 @@ int main(int argc, char** argv)
                         }
                     }
                     if (!nn && !nl) break;
+                    {   // histogram of wave-level steps by lanes under way (1, 2, 3-4, 5-8, 9-16, 17-32, 33-48, 49-63, 64)
+                        const int act = nn + nl; const int bk = act <= 1 ? 0 : act == 2 ? 1 : act <= 4 ? 2 : act <= 8 ? 3 : act <= 16 ? 4 : act <= 32 ? 5 : act <= 48 ? 6 : act < 64 ? 7 : 8;
+                        c.ah[bk] += 1;
+                    }
+                    if (parkK && !in_compact) {
+                        // straggler parking: at most parkK lanes under way for more than parkM consecutive wave-level steps -> their rays (with the closest hit found
+                        // so far) go to the wave's queue and the pass ends; the queue is traced 64 rays at a time, restarted from the root with t_max = that hit
+                        if (nn + nl <= parkK) few_steps++; else few_steps = 0;
+                        if (few_steps > parkM) {
+                            for (auto& r : R) if (r.node != kSent) { Ray q = r; q.node = 0; q.stk.clear(); q.stk_t.clear(); q.pleaf = 0; queue.push_back(q); r.node = kSent; c.parked++; }
+                            break;
+                        }
+                    }
                     int want;
                     if (policy == 0) want = phase == 0 ? (nn ? 0 : 1) : (nl ? 1 : 0);
                     else if (policy == 1) want = !nn ? 1 : (!nl_any ? 0 : ((double)nn * (switch_after > 0 ? (sched_iter < switch_after ? alpha : alpha2) : (phase == 0 ? alpha : alpha2)) >= (double)nl ? 0 : 1));
@@ -334,6 +358,7 @@ int main(int argc, char** argv)
                     phase = want;
                     if (phase == 0) node_step(); else leaf_step();
                 }
+                if (in_compact) { c.cwnode += c.wnode - w0n; c.cwtri += c.wtri - w0t; c.cnodes += c.nodes - n0; c.ctris += c.tris - t0; }
                 for (auto& r : R) if (r.slot >= 0) c.hits++;
                 { int mn = 0, mt = 0; for (int l = 0; l < 64; l++) { mn = std::max(mn, lane_nodes[l]); mt = std::max(mt, lane_tris[l]); } c.wmaxn += mn; c.wmaxt += mt; }
                 { std::sort(pass_nodes.begin(), pass_nodes.end()); c.un_nodes += (double)(std::unique(pass_nodes.begin(), pass_nodes.end()) - pass_nodes.begin());
@@ -341,7 +366,7 @@ int main(int argc, char** argv)
             }
         }
 #pragma omp critical
-        { tot.rays += c.rays; tot.nodes += c.nodes; tot.tris += c.tris; tot.wnode += c.wnode; tot.wtri += c.wtri; tot.culled += c.culled; tot.hits += c.hits; tot.wuni += c.wuni; tot.wuni0 += c.wuni0; tot.lines += c.lines; tot.wmaxn += c.wmaxn; tot.wmaxt += c.wmaxt; tot.rounds += c.rounds; for (int q = 0; q < 8; q++) { tot.dh[q] += c.dh[q]; tot.dl[q] += c.dl[q]; } tot.refills += c.refills; tot.refill_lanes += c.refill_lanes; tot.spread += c.spread; tot.un_nodes += c.un_nodes; tot.un_leaves += c.un_leaves; for (int q = 0; q < 4; q++) tot.wdeep[q] += c.wdeep[q]; if (c.maxsp > tot.maxsp) tot.maxsp = c.maxsp; }
+        { tot.rays += c.rays; tot.nodes += c.nodes; tot.tris += c.tris; tot.wnode += c.wnode; tot.wtri += c.wtri; tot.culled += c.culled; tot.hits += c.hits; tot.wuni += c.wuni; tot.wuni0 += c.wuni0; tot.lines += c.lines; tot.wmaxn += c.wmaxn; tot.wmaxt += c.wmaxt; tot.rounds += c.rounds; for (int q = 0; q < 8; q++) { tot.dh[q] += c.dh[q]; tot.dl[q] += c.dl[q]; } tot.refills += c.refills; tot.refill_lanes += c.refill_lanes; tot.spread += c.spread; tot.un_nodes += c.un_nodes; tot.un_leaves += c.un_leaves; tot.parked += c.parked; tot.cpass += c.cpass; tot.cwnode += c.cwnode; tot.cwtri += c.cwtri; tot.cnodes += c.cnodes; tot.ctris += c.ctris; for (int q = 0; q < 9; q++) tot.ah[q] += c.ah[q]; for (int q = 0; q < 4; q++) tot.wdeep[q] += c.wdeep[q]; if (c.maxsp > tot.maxsp) tot.maxsp = c.maxsp; }
     }
     double wr = tot.rays / 64.0;
     printf("per ray: %.2f node visits, %.2f tri tests, %.2f culled pops, hit %.4f, max stack %.0f\n", tot.nodes / tot.rays, tot.tris / tot.rays, tot.culled / tot.rays, tot.hits / tot.rays, tot.maxsp);
@@ -352,6 +377,11 @@ int main(int argc, char** argv)
     printf("union over the 64 rays of a pass (= the visits of ONE packet traversal of the wave): %.1f inner nodes, %.1f leaves\n", tot.un_nodes / wr, tot.un_leaves / wr);
     printf("distinct nodes per wave-level node step (share of steps : mean lanes taking part):"); for (int q = 0; q < 8; q++) printf(" %d%s %.3f:%.1f", q + 1, q == 7 ? "+" : "", tot.dh[q] / tot.wnode, tot.dh[q] > 0 ? tot.dl[q] / tot.dh[q] : 0.0); printf("\n");
     if (tot.refills > 0) printf("refill events per 64 rays %.3f (lanes per event %.1f, pass spread at refill %.1f); cost incl. %.1f per refill event: %.2f per pass\n", tot.refills / wr, tot.refill_lanes / tot.refills, tot.spread / tot.refills, 2.6, tot.wnode / wr + tricost * tot.wtri / wr + 2.6 * tot.refills / wr);
+    { const char* nm[9] = {"1", "2", "3-4", "5-8", "9-16", "17-32", "33-48", "49-63", "64"}; double all = 0; for (int q = 0; q < 9; q++) all += tot.ah[q];
+      printf("wave-level steps by lanes under way:"); for (int q = 0; q < 9; q++) printf(" %s %.3f", nm[q], tot.ah[q] / all); printf("\n"); }
+    if (parkK) printf("parking (<= %d lanes for > %d steps): %.3f of the rays parked; compact passes per main pass %.3f: %.2f node steps (util %.3f) + %.2f tri steps (util %.3f) each; of all wave-level steps %.3f node / %.3f tri run in compact passes\n",
+                      parkK, parkM, tot.parked / tot.rays, tot.cpass / wr, tot.cwnode / std::max(1.0, tot.cpass), tot.cnodes / (64.0 * std::max(1.0, tot.cwnode)), tot.cwtri / std::max(1.0, tot.cpass), tot.ctris / (64.0 * std::max(1.0, tot.cwtri)),
+                      tot.cwnode / tot.wnode, tot.cwtri / tot.wtri);
     printf("cost model (node step 1, triangle test %.2f): %.2f per pass\n", tricost, tot.wnode / wr + tricost * tot.wtri / wr);
     return 0;
 }

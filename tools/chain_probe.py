@@ -23,8 +23,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROBE_LIB = os.path.join(ROOT, "build_ab", "libtexir_probe.so")
-NAMES = ["node_vector_cycles", "node_vector_steps", "node_scalar_cycles", "node_scalar_steps", "leaf_cycles", "leaf_steps", "trace_cycles", "passes",
-         "shade_cycles", "passes_with_hit", "pass_cycles", "chunk_cycles", "chunks"]
+NAMES = ["node_vector_steps", "node_vector_timed", "node_vector_cycles", "node_scalar_steps", "node_scalar_timed", "node_scalar_cycles",
+         "leaf_steps", "leaf_timed", "leaf_cycles", "null_timed", "null_cycles", "passes", "passes_timed", "trace_cycles", "shade_cycles", "pass_cycles",
+         "chunk_cycles", "chunks"]
 
 
 def child(workload, spp, probe):
@@ -87,19 +88,26 @@ def run_child(workload, spp, probe, cap):
 
 
 def per_step(p):
-    """cycles per wave-level step of each kind and the split of a pass, from one probe dict"""
+    """cycles per wave-level step of each kind (mean of the timed steps minus the mean empty region) and the split of a pass, from one probe dict"""
     d = lambda a, b: (a / b) if b else None
-    steps = p["node_vector_steps"] + p["node_scalar_steps"] + p["leaf_steps"]
-    in_steps = p["node_vector_cycles"] + p["node_scalar_cycles"] + p["leaf_cycles"]
-    return {"node_vector": d(p["node_vector_cycles"], p["node_vector_steps"]), "node_scalar": d(p["node_scalar_cycles"], p["node_scalar_steps"]),
-            "leaf": d(p["leaf_cycles"], p["leaf_steps"]), "shade_per_pass": d(p["shade_cycles"], p["passes"]),
-            "steps_per_pass": {"node_vector": d(p["node_vector_steps"], p["passes"]), "node_scalar": d(p["node_scalar_steps"], p["passes"]), "leaf": d(p["leaf_steps"], p["passes"])},
-            "pass_cycles": d(p["pass_cycles"], p["passes"]),
-            "share_of_chunk_cycles": {"node_vector": d(p["node_vector_cycles"], p["chunk_cycles"]), "node_scalar": d(p["node_scalar_cycles"], p["chunk_cycles"]),
-                                      "leaf": d(p["leaf_cycles"], p["chunk_cycles"]), "scheduler_between_steps": d(p["trace_cycles"] - in_steps, p["chunk_cycles"]),
-                                      "shade": d(p["shade_cycles"], p["chunk_cycles"]), "sampling_and_pass_overhead": d(p["pass_cycles"] - p["trace_cycles"] - p["shade_cycles"], p["chunk_cycles"]),
-                                      "chunk_overhead": d(p["chunk_cycles"] - p["pass_cycles"], p["chunk_cycles"])},
-            "wave_level_steps": steps}
+    null = d(p["null_cycles"], p["null_timed"]) or 0.0
+    c = {k: (None if not p[k + "_timed"] else max(0.0, p[k + "_cycles"] / p[k + "_timed"] - null)) for k in ("node_vector", "node_scalar", "leaf")}
+    spp = {k: d(p[k + "_steps"], p["passes"]) for k in ("node_vector", "node_scalar", "leaf")}
+    trace = d(p["trace_cycles"], p["passes_timed"])
+    shade = d(p["shade_cycles"], p["passes_timed"])
+    pas = d(p["pass_cycles"], p["passes_timed"])
+    if trace is not None:
+        trace, shade, pas = trace - null, shade - null, pas - null
+    in_steps = sum((c[k] or 0.0) * (spp[k] or 0.0) for k in c)
+    chunk_per_pass = d(p["chunk_cycles"], p["passes"])
+    share = None
+    if pas:
+        share = {"node_vector": (c["node_vector"] or 0) * (spp["node_vector"] or 0) / pas, "node_scalar": (c["node_scalar"] or 0) * (spp["node_scalar"] or 0) / pas,
+                 "leaf": (c["leaf"] or 0) * (spp["leaf"] or 0) / pas, "scheduler_between_steps": (trace - in_steps) / pas, "shade": shade / pas,
+                 "sampling_and_pass_overhead": (pas - trace - shade) / pas}
+    return {"node_vector": c["node_vector"], "node_scalar": c["node_scalar"], "leaf": c["leaf"], "null_region": null, "shade_per_pass": shade, "trace_per_pass": trace,
+            "steps_per_pass": spp, "pass_cycles": pas, "chunk_cycles_per_pass": chunk_per_pass, "share_of_pass_cycles": share,
+            "wave_level_steps": p["node_vector_steps"] + p["node_scalar_steps"] + p["leaf_steps"]}
 
 
 def main():
@@ -135,7 +143,7 @@ def main():
         ps = per_step(pr["probe"])
         sweep.append({"waves_per_simd": waves_per_simd, "grid_blocks": cap or BLOCKS_FULL, "shipped_kernel_ms": round(sh["kernel_ms"], 3), "probe_kernel_ms": round(pr["kernel_ms"], 3),
                       "grays_per_s": round(sh["rays"] / sh["kernel_ms"] / 1e6, 3), "cycles_per_step": {k: (None if ps[k] is None else round(ps[k], 1)) for k in ("node_vector", "node_scalar", "leaf", "shade_per_pass")},
-                      "pass_cycles": round(ps["pass_cycles"], 1), "steps_per_pass": ps["steps_per_pass"]})
+                      "pass_cycles": round(ps["pass_cycles"], 1), "null_region": round(ps["null_region"], 1), "steps_per_pass": ps["steps_per_pass"]})
     out["occupancy_sweep"] = {"spp": a.sweep_spp, "points": sweep}
     # chain bound: every wave-level step at its UNLOADED latency (1 wave per SIMD), all resident waves overlapping perfectly
     c1 = sweep[0]["cycles_per_step"]
