@@ -189,7 +189,7 @@ class FusedAdam(torch.optim.Optimizer):
             l1 = torch.where(bits1, l1, torch.zeros((), device=p.device))
         g2 = getattr(p, "_texir_grad_l2", None)
         if g2 is not None:
-            l1 += 0.25 * up(g2.view(H // 4, W // 4, C))
+            l1 += 0.25 * up(g2.view(H // 4, W // 4, C))          # (level 2 is written densely by the fold kernels: only level 1 is read through the mask)
         return g + 0.25 * up(l1)
 
     def set_clamp(self, param, lo=-math.inf, hi=math.inf):

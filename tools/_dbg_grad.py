@@ -1,0 +1,78 @@
+import os, sys, subprocess, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    import torch
+    poison = os.environ.get("DBG_POISON") == "1"
+    if poison:
+        _empty = torch.empty
+        def empty(*a, **k):
+            t = _empty(*a, **k)
+            if t.is_floating_point() and t.numel():
+                t.fill_(float("nan"))
+            return t
+        torch.empty = empty
+        _el = torch.empty_like
+        def empty_like(x, *a, **k):
+            t = _el(x, *a, **k)
+            if t.is_floating_point() and t.numel():
+                t.fill_(float("nan"))
+            return t
+        torch.empty_like = empty_like
+    import test_gpu_mat_step_oracle as T
+    import conftest
+    from texir_code_amd.loss import RenderLoss
+    golden = lambda name: np.load(os.path.join(ROOT, "tests", "golden", name), allow_pickle=False)
+    ra, rr, c = 64, 128, 32
+    m, oracle, views = T._world(golden, c, ra, rr)
+    loss_fn = RenderLoss("L1", 1, lazy_item=True)
+    gen = torch.Generator().manual_seed(3)
+    out = {}
+    for stage in (0, 1, 2):
+        opt = T._fresh_optimizer(m, stage)
+        oracle.make_optimizer(stage, T.LR)
+        for key, v in views.items():
+            shift = torch.rand(6 * c * c, 2, generator=gen)
+            d = T._cu(v)
+            m._static_shift = shift.cuda()
+            preds = m(v["mvp"], key, d["cam"], stage)
+            m._static_shift = None
+            loss = loss_fn(d["gt"], preds, d["gmask"], d["fm"], d["seg"], stage=stage, room_seg_mask=d["room"] if stage == 2 else None)[0]
+            opt.zero_grad()
+            loss.backward()
+            if m.materials_r.requires_grad:
+                p = m.materials_r
+                out["gr_%d_%s" % (stage, key)] = opt.dense_grad(p).cpu().numpy()
+                out["g0_%d_%s" % (stage, key)] = (torch.zeros_like(p) if p.grad is None else p.grad.detach()).cpu().numpy()
+                g1 = getattr(p, "_texir_grad_l1", None)
+                if g1 is not None:
+                    out["g1_%d_%s" % (stage, key)] = g1.detach().cpu().numpy()
+                    out["hasmask_%d_%s" % (stage, key)] = np.array([getattr(g1, "_texir_mask", None) is not None, getattr(p, "_texir_grad_l2", None) is not None,
+                                                                   bool(getattr(p, "_texir_l0_sparse", False)), getattr(p, "_texir_l0_mask", None) is not None])
+                    g2 = getattr(p, "_texir_grad_l2", None)
+                    if g2 is not None:
+                        out["g2_%d_%s" % (stage, key)] = g2.detach().cpu().numpy()
+                lo, oa, orr = oracle.grads(key, v["mvp"].numpy(), v["cam"], stage, shift.numpy(), v["gt"], v["gmask"], v["fm"], v["seg"], v["room"])
+                out["or_%d_%s" % (stage, key)] = orr.numpy()
+                out["rw_%d_%s" % (stage, key)] = preds["roughness"].detach().cpu().numpy()
+            opt.zero_grad()
+    np.savez(sys.argv[2], **out)
+    sys.exit(0)
+res = {}
+for name, lib, poison in (("quad", None, "0"), ("quad_poison", None, "1"), ("slot", os.path.join(ROOT, "build_ab", "libtexir_uvslot.so"), "0"), ("slot_poison", os.path.join(ROOT, "build_ab", "libtexir_uvslot.so"), "1")):
+    env = dict(os.environ); env["DBG_POISON"] = poison
+    if lib: env["TEXIR_HIP_LIB"] = lib
+    r = subprocess.run([sys.executable, __file__, "child", "/tmp/dbgg_%s.npz" % name], env=env, capture_output=True, text=True)
+    if r.returncode: print(name, "FAILED", r.stderr[-800:]); continue
+    res[name] = np.load("/tmp/dbgg_%s.npz" % name)
+rl2 = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
+for name, z in res.items():
+    for k in sorted(z.files):
+        if k.startswith("gr_"):
+            o = z["or_" + k[3:]]
+            print(name, k, "rel_l2 vs oracle %.3e" % rl2(z[k], o), "nan", int(np.isnan(z[k]).sum()), "flags", z["hasmask_" + k[3:]] if ("hasmask_" + k[3:]) in z.files else None)
+if "quad" in res and "slot" in res:
+    a, b = res["quad"], res["slot"]
+    for k in sorted(a.files):
+        if a[k].dtype.kind == "f":
+            d = np.abs(a[k] - b[k]); print("quad vs slot", k, a[k].shape, "max diff %.3e" % np.nanmax(d), "n>1e-6:", int((d > 1e-6).sum()), "argmax", np.unravel_index(np.nanargmax(d), d.shape))
