@@ -433,6 +433,19 @@ def load_pmc(workload, kernel):
     return tj, None
 
 
+def load_chain(workload, kernel):
+    """the chain probe of this workload (tools/chain_probe.py), refused when taken with other kernel sources"""
+    path = os.path.join(ROOT, "profiles", "chain_%s.json" % workload)
+    if not os.path.exists(path):
+        return None, "no profiles/chain_%s.json" % workload
+    tj = json.load(open(path))
+    if tj.get("kernel_src_sha") != kernel_src_sha():
+        return None, "profiles/chain_%s.json was taken with other kernel sources" % workload
+    if kernel not in tj.get("kernel", ""):
+        return None, "profiles/chain_%s.json describes %s" % (workload, tj.get("kernel"))
+    return tj, None
+
+
 def roofline(workload, kernel, kern_ms, rays_this_rank, world, alg):
     """the two bounds of the module docstring; `alg` = (bytes/ray, nodes/ray, tris/ray, p_hit) of SURVEY 8(d) or None"""
     t = kern_ms * 1e-3
@@ -481,6 +494,28 @@ def roofline(workload, kernel, kern_ms, rays_this_rank, world, alg):
                     "scalar_path": None if pmc.get("smem_insts") is None else {"smem_insts_per_launch": float(pmc["smem_insts"]) * scale,
                                                                                "scalar_cache_hit_rate": pmc.get("scalar_cache_hit_rate")},
                     "profile": "profiles/pmc_%s.json (%s)" % (workload, pmc.get("source", ""))})
+    chain, why_c = load_chain(workload, kernel)
+    if chain is not None and out.get("limits") is not None:
+        # the dependent-chain bound (tools/chain_probe.py -> profiles/chain_<workload>.json): every wave-level step of the launch at the latency it has with ONE wave
+        # per SIMD, all resident waves overlapping perfectly; and what the rate does when waves are taken away
+        pts = chain["occupancy_sweep"]["points"]
+        t_chain = float(chain["chain_bound"]["seconds"]) * (rays_this_rank / float(chain["rays_per_launch"]))
+        out["limits"]["chain"] = {"frac": round(t_chain / t, 4), "achieved": round(t_chain, 5), "peak": round(t, 5), "unit": "s (chain time over kernel time)",
+                                  "cycles_per_step_at_1_wave": pts[0]["cycles_per_step"], "cycles_per_step_at_8_waves": pts[-1]["cycles_per_step"],
+                                  "steps_per_pass": chain["full_occupancy"]["per_step"]["steps_per_pass"], "probe_overhead": chain["full_occupancy"]["probe_overhead"],
+                                  "note": "sum over step kinds of (wave-level steps of the launch) x (cycles per step measured with ONE wave per SIMD) / 8192 resident waves / 2.4 GHz, over the "
+                                          "live kernel time: the share of the launch that the dependent fetch -> test -> sort -> push chain explains if nothing were shared; the rest is "
+                                          "waves queueing for their SIMD's issue slots and L1"}
+        out["occupancy"] = {"waves_per_simd": [p["waves_per_simd"] for p in pts], "grays_per_s": [p["grays_per_s"] for p in pts], "spp": chain["occupancy_sweep"]["spp"],
+                            "rate_8_over_1": chain["reading"]["rate_8_waves_over_1_wave"],
+                            "note": "shipped kernel, persistent grid capped (TEXIR_IRT_GRID_CAP): 8x the waves buy %.2fx the rate -- the SIMD-shared resources (issue slots, L1) saturate; "
+                                    "a pure latency chain would scale 8x" % chain["reading"]["rate_8_waves_over_1_wave"]}
+        fr = {k: v["frac"] for k, v in out["limits"].items() if v is not None and v.get("frac") is not None}
+        out["binding"] = max(fr, key=fr.get)
+        out["profile_chain"] = "profiles/chain_%s.json" % workload
+    elif out.get("limits") is not None:
+        out["limits"]["chain"] = None
+        out["chain_note"] = why_c
     if alg is not None:
         bpr, nbar, tbar, phit = alg
         out["algorithmic"] = {"bytes_per_ray": round(bpr, 1), "nodes_per_ray": round(nbar, 2), "tris_per_ray": round(tbar, 2), "p_hit": round(phit, 4),

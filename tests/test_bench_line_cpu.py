@@ -27,6 +27,16 @@ def test_roofline_fields_are_self_consistent(monkeypatch):
             assert abs(v["frac"] - v["achieved"] / v["peak"]) < 2e-3, k
     assert r["binding"] == max(fr, key=fr.get)
     assert "SELF-CALIBRATED" in r["limits"]["l1"]["note"]
+    # with a chain probe of these sources the line carries the dependent-chain bound and the occupancy sweep too
+    chain = {"kernel_src_sha": bench.kernel_src_sha(), "kernel": "void texir::irt_group_kernel<false, 4, 6>", "rays_per_launch": 1000000,
+             "chain_bound": {"seconds": 6.0e-5}, "reading": {"rate_8_waves_over_1_wave": 4.2},
+             "full_occupancy": {"probe_overhead": 0.3, "per_step": {"steps_per_pass": {"node_vector": 12, "node_scalar": 6, "leaf": 3}}},
+             "occupancy_sweep": {"spp": 256, "points": [{"waves_per_simd": w, "grays_per_s": g, "cycles_per_step": {"node_vector": 1800.0 * w ** 0.5}} for w, g in ((1, 3.3), (2, 6.0), (4, 10.0), (8, 14.0))]}}
+    monkeypatch.setattr(bench, "load_chain", lambda w, k: (chain, None))
+    r2 = bench.roofline("c4", "irt_group_kernel<false, 4, 6>", 0.1, 1000000, 1, None)
+    assert abs(r2["limits"]["chain"]["frac"] - 0.6) < 1e-3 and r2["occupancy"]["grays_per_s"][-1] == 14.0
+    fr2 = {k: v["frac"] for k, v in r2["limits"].items() if v}
+    assert r2["binding"] == max(fr2, key=fr2.get)
     assert r["algorithmic"]["bytes_per_ray"] == 1952.0
     json.dumps(r)
     # a profile of other kernel sources is refused, loudly, and the line then carries no measured bound
@@ -39,12 +49,19 @@ def test_committed_profiles_match_the_committed_kernel_sources():
     """profiles/pmc_<workload>.json are only read when they were taken with THESE sources: the committed pair must agree"""
     import bench
     sha = bench.kernel_src_sha()
-    for w in ("c4", "c2", "c4_scan", "c1"):
+    for w in ("c4", "c2", "c4_scan", "house", "c1"):
         p = os.path.join(ROOT, "profiles", "pmc_%s.json" % w)
         assert os.path.exists(p), p
         d = json.load(open(p))
         assert d["kernel_src_sha"] == sha, (w, d["kernel_src_sha"], sha)
         assert d["fabric_bytes_per_launch"] > 0 and d["rays_per_launch"] > 0
+    # the chain probes (tools/chain_probe.py) of the headline and of its hostile sibling: same rule
+    for w in ("c4", "c4_scan"):
+        p = os.path.join(ROOT, "profiles", "chain_%s.json" % w)
+        assert os.path.exists(p), p
+        d = json.load(open(p))
+        assert d["kernel_src_sha"] == sha, (w, d["kernel_src_sha"], sha)
+        assert 0.0 < d["chain_bound"]["frac_of_shipped_kernel_time"] <= 1.0 and len(d["occupancy_sweep"]["points"]) == 4
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from mat_step_pmc import mat_src_sha
     assert json.load(open(os.path.join(ROOT, "profiles", "pmc_mat_step.json")))["mat_src_sha"] == mat_src_sha()
