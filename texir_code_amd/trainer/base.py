@@ -51,21 +51,25 @@ class RunnerBase:
         torch.save({"epoch": epoch, "model_state_dict": self.model.state_dict()},
                    os.path.join(self.checkpoints_path, self.model_params_subdir, "latest.pth"))
 
-    def fit(self, loader, first_epoch, last_epoch, step, epoch_begin=None, takes=None, before_step=None, after_step=None, epoch_end=None):
+    def fit(self, loader, first_epoch, last_epoch, step, epoch_begin=None, takes=None, before_step=None, after_step=None, epoch_end=None, between_steps=None):
         """for epoch in first_epoch..last_epoch: epoch_begin(epoch); for every batch this rank `takes`: before_step, step, after_step;
-        epoch_end(epoch).  A hook that returns True from after_step ends the run (the runners' step budgets).  Returns True if ended early."""
+        epoch_end(epoch).  A hook that returns True from after_step ends the run (the runners' step budgets).  Returns True if ended early.
+        between_steps(next_batch, epoch, next_index) runs after a step has been LAUNCHED and before after_step (which is where the reference's loops
+        synchronise with `.item()`), with the next batch of the SAME epoch -- the place to prepare the next step's host-side inputs while the GPU
+        works (the batch order of an epoch is fixed when its iterator is made, so looking one batch ahead draws nothing)."""
         for epoch in range(first_epoch, last_epoch + 1):
             if epoch_begin is not None:
                 epoch_begin(epoch)
             it = iter(loader)
             data_index = -1
-            while True:
-                with phases.phase("in_stages:dataloader", sync=False):
-                    batch = next(it, None)
-                if batch is None:
-                    break
+            with phases.phase("in_stages:dataloader", sync=False):
+                nxt = next(it, None)
+            while nxt is not None:
+                batch = nxt
                 data_index += 1
                 if takes is not None and not takes(data_index):
+                    with phases.phase("in_stages:dataloader", sync=False):
+                        nxt = next(it, None)
                     continue
                 self.model.train()
                 if before_step is not None:
@@ -73,6 +77,11 @@ class RunnerBase:
                 with phases.phase("in_stages:step_host", sync=False):
                     out = step(batch)
                 self.cur_iter += 1
+                with phases.phase("in_stages:dataloader", sync=False):
+                    nxt = next(it, None)
+                if nxt is not None and between_steps is not None and (takes is None or takes(data_index + 1)):
+                    with phases.phase("in_stages:next_step_prep", sync=False):
+                        between_steps(nxt, epoch, data_index + 1)
                 if after_step is not None and after_step(epoch, data_index, out):
                     return True
             if epoch_end is not None:

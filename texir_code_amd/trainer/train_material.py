@@ -168,9 +168,29 @@ class MatTrainRunner(RunnerBase):
                 self.model._static_shift = None
                 return None
         world = dist_util.world_info()[1]
-        self._gs.step(vid0, stage, reduce_grads=dist_util.reduce_texture_grads if (world > 1 and not replicated) else None)
+        staged = getattr(self, "_shift_staged_for", None) == (id(self._gs), vid0, stage)       # (_prepare_next_step drew and placed this step's shifts already)
+        self._shift_staged_for = None
+        self._gs.step(vid0, stage, reduce_grads=dist_util.reduce_texture_grads if (world > 1 and not replicated) else None, staged=staged)
         out = self._gs.outs[(vid0, stage)]
         return out[0], out[1]
+
+    def _prepare_next_step(self, next_item, stage):
+        """between two steps of one epoch (RunnerBase.fit between_steps): the NEXT step's GGX shifts are drawn from the CPU generator and written where
+        that view's recorded kernels read them, while the step just launched runs on the GPU -- before this step's `.item()` instead of after it.
+        The generator's stream is consumed in the same order as in the reference's loop (nothing else draws between two steps of an epoch: the
+        sampler drew its permutation when the epoch's iterator was made, the validation forwards run at epoch starts), so the trajectory is unchanged;
+        what changes is that the 0.6 ms draw no longer sits between two 0.6 ms steps.  Only for a view whose (view, stage) graph exists."""
+        gs = getattr(self, "_gs", None)
+        if stage == 0 or gs is None or not getattr(self, "use_graph", False) or gs.opt is not self.mat_optimizer:
+            return
+        if dist_util.world_info()[1] > 1 and getattr(self, "mat_shard", "pixel") == "pixel":
+            return                                      # (the pixel-sharded step draws inside ShardedMatStep.step)
+        vid = next_item["id"]
+        vid0 = vid[0] if isinstance(vid, (list, tuple)) else vid
+        if (vid0, stage) not in gs.graphs:
+            return
+        gs.stage_shift(vid0, gs.draw_shift())
+        self._shift_staged_for = (id(gs), vid0, stage)
 
     def _new_optimizer(self):
         """fresh Adam + StepLR over ALL model parameters (train_material.py:122-128, 472-476, 539-543); the post-step
@@ -316,8 +336,14 @@ class MatTrainRunner(RunnerBase):
             return max_steps is not None and self.cur_iter >= max_steps
 
         try:
+            def between_steps(next_item, epoch, next_index):
+                # (never for a step that will not happen: a step budget that ends the run after the current step must leave the generator where the reference's loop leaves it)
+                if max_steps is None or self.cur_iter < max_steps:
+                    self._prepare_next_step(next_item, stage)
+
             self.fit(self.train_dataloader, self.start_epoch, self.nepochs, lambda gt_item: self.train_step(gt_item, stage), epoch_begin=epoch_begin,
-                     takes=takes, before_step=before_step, after_step=after_step, epoch_end=lambda epoch: (drain(0), self.mat_scheduler.step()))
+                     takes=takes, before_step=before_step, after_step=after_step, epoch_end=lambda epoch: (drain(0), self.mat_scheduler.step()),
+                     between_steps=between_steps)
         finally:
             drain(0)
 

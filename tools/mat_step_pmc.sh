@@ -10,7 +10,7 @@ export TEXIR_SYNTH_CACHE=${TEXIR_SYNTH_CACHE:-/tmp/texir_synth}
 for pass in "rd TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "wr WRITE_SIZE" "tcc TCC_HIT_sum TCC_MISS_sum"; do
   set -- $pass; name=$1; shift
   rm -rf /tmp/matpmc_$name
-  timeout 600 rocprofv3 --pmc "$@" --output-format csv -d /tmp/matpmc_$name -- python $R/bench.py --no-cpu --steps 1 --warmup 0 --extra none > /tmp/matpmc_$name.log 2>&1
+  timeout 600 rocprofv3 --pmc "$@" --output-format csv -d /tmp/matpmc_$name -- python $R/bench.py --no-cpu --steps 1 --warmup 0 --extra none --no-project --no-e2e > /tmp/matpmc_$name.log 2>&1
   f=$(find /tmp/matpmc_$name -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && cp "$f" $out/mat_$name.csv
 done

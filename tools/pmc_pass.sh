@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/$out
 run() { name=$1; shift
-  env "${EXTRA[@]}" timeout 300 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_$name -- python $R/bench.py --workload $wl --steps 1 --warmup 0 --no-cpu --no-mat --extra none > /tmp/pmc_$name.log 2>&1
+  env "${EXTRA[@]}" timeout 300 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_$name -- python $R/bench.py --workload $wl --steps 1 --warmup 0 --no-cpu --no-mat --extra none --no-project > /tmp/pmc_$name.log 2>&1
   f=$(find /tmp/pmc_$name -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && python - "$f" "$R/gpurun_out/$out/pmc_$name.csv" <<'PY'
 import csv,sys

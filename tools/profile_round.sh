@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 export TEXIR_SYNTH_CACHE=${TEXIR_SYNTH_CACHE:-/tmp/texir_synth}
 run() { wl=$1; name=$2; shift 2
   rm -rf /tmp/pmc_$name
-  timeout 400 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_$name -- python $R/bench.py --workload $wl --steps 1 --warmup 0 --no-cpu --no-mat --extra none > /tmp/pmc_$name.log 2>&1
+  timeout 400 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_$name -- python $R/bench.py --workload $wl --steps 1 --warmup 0 --no-cpu --no-mat --extra none --no-project > /tmp/pmc_$name.log 2>&1
   f=$(find /tmp/pmc_$name -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && python - "$f" "$out/$wl/pmc_$name.csv" <<'PY'
 import csv,sys,collections
@@ -39,7 +39,7 @@ done
 # kernel-trace stats of the default bench run (the headline), with the PMC json in place so that the line carries the measured bounds
 mkdir -p $R/profiles; cp $out/pmc_*.json $R/profiles/ 2>/dev/null
 rm -rf /tmp/kt
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --steps 2 --warmup 1 --extra none > $out/bench_default_under_rocprof.json 2> $out/bench_default.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --steps 2 --warmup 1 --extra none --no-project --no-e2e > $out/bench_default_under_rocprof.json 2> $out/bench_default.err
 f=$(find /tmp/kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $out/c4_kernel_stats.csv
 f=$(find /tmp/kt -name '*kernel_trace.csv' | head -1); [ -n "$f" ] && (head -1 "$f"; grep "irt_" "$f") > $out/c4_irt_kernel_trace_rows.csv
 tail -1 $out/bench_default_under_rocprof.json

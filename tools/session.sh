@@ -39,6 +39,8 @@ PY
     chain:*)  wl=${step#chain:}; timeout 2400 python tools/chain_probe.py --workload $wl --out $out/chain_$wl.json > $out/chain_$wl.log 2>&1; echo "rc $?"; tail -25 $out/chain_$wl.log ;;
     profile:*) wls=${step#profile:}; bash tools/profile_round.sh $tag ${wls//,/ } > $out/profile.log 2>&1; tail -3 $out/profile.log ;;
     matpmc)   bash tools/mat_step_pmc.sh $tag > $out/matpmc.log 2>&1; tail -3 $out/matpmc.log ;;
+    mattrace) bash tools/trace_mat_step.sh $tag > $out/mattrace.log 2>&1; tail -20 $out/mattrace.log ;;
+    weights:*) wl=${step#weights:}; for w in 1 2 3; do echo "$wl TEXIR_SCHED_WEIGHT=$w $(irt_line $wl TEXIR_SCHED_WEIGHT=$w)" | tee -a $out/ab_weights.txt; done; echo "$wl tuned $(irt_line $wl)" | tee -a $out/ab_weights.txt ;;
     e2e:*)    wl=${step#e2e:}; timeout 1500 python tools/stage_time.py --workload $wl > $out/e2e_$wl.json 2> $out/e2e_$wl.err; echo "rc $?"; tail -c 1500 $out/e2e_$wl.json ;;
     *) echo "unknown step $step" ;;
   esac

@@ -132,6 +132,10 @@ def run(workload="c4", root=None, mat_epochs=40, keep=False, style="room", do_ma
                 D.render_gt_views(root, C.parse_file(conf_mat), sc, mres, mres)
             out["gt_views_prep_s"] = round(time.perf_counter() - t0, 2)
             out["mat"] = time_mat(conf_mat, os.path.join(root, "exps"), mat_epochs, log_lag)
+            if not log_lag:
+                # the same stage with the optional conf key train.log_lag = 8: loss values are logged 8 steps late from pinned copies, no host synchronisation per step
+                open(conf_mat, "w").write(txt.replace("batch_size = 1", "batch_size = 1\n    log_lag = 8"))
+                out["mat_log_lag8"] = time_mat(conf_mat, os.path.join(root, "exps_lag8"), mat_epochs, 8)
     finally:
         if made and not keep:
             shutil.rmtree(root, ignore_errors=True)

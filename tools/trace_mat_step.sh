@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ktm
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ktm -- python $R/bench.py --no-cpu --steps 1 --warmup 0 > /tmp/ktm.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ktm -- python $R/bench.py --no-cpu --steps 1 --warmup 0 --extra none --no-project --no-e2e > /tmp/ktm.log 2>&1
 f=$(find /tmp/ktm -name '*kernel_trace.csv' | head -1)
 python - "$f" <<'PY'
 import csv,sys
