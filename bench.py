@@ -500,7 +500,7 @@ def roofline(workload, kernel, kern_ms, rays_this_rank, world, alg):
         # per SIMD, all resident waves overlapping perfectly; and what the rate does when waves are taken away
         pts = chain["occupancy_sweep"]["points"]
         t_chain = float(chain["chain_bound"]["seconds"]) * (rays_this_rank / float(chain["rays_per_launch"]))
-        out["limits"]["chain"] = {"frac": round(t_chain / t, 4), "achieved": round(t_chain, 5), "peak": round(t, 5), "unit": "s (chain time over kernel time)",
+        out["limits"]["chain"] = {"frac": round(t_chain / t, 4), "achieved": round(t_chain, 7), "peak": round(t, 7), "unit": "s (chain time over kernel time)",
                                   "cycles_per_step_at_1_wave": pts[0]["cycles_per_step"], "cycles_per_step_at_8_waves": pts[-1]["cycles_per_step"],
                                   "steps_per_pass": chain["full_occupancy"]["per_step"]["steps_per_pass"], "probe_overhead": chain["full_occupancy"]["probe_overhead"],
                                   "note": "sum over step kinds of (wave-level steps of the launch) x (cycles per step measured with ONE wave per SIMD) / 8192 resident waves / 2.4 GHz, over the "

@@ -15,6 +15,7 @@ def test_roofline_fields_are_self_consistent(monkeypatch):
            "fabric_bytes_per_launch": 3.0e8, "SQ_INSTS_VALU": 5.0e7, "tcp_cache_accesses": 3.0e7, "tcp_clocks": 4.0e7, "kernel_ms_under_pmc": [0.1, 0.1],
            "l2_hit_rate": 0.5, "valu_lane_utilisation": 0.7, "source": "unit test"}
     monkeypatch.setattr(bench, "load_pmc", lambda w, k: (pmc, None))
+    monkeypatch.setattr(bench, "load_chain", lambda w, k: (None, "no chain probe in this test yet"))
     r = bench.roofline("c4", "irt_group_kernel<false, 4, 6>", 0.1, 1000000, 1, (1952.0, 54.6, 3.65, 1.0))
     # top level = the memory side, always: frac = achieved / peak, achieved = traffic / time
     assert r["bound"] == "hbm" and r["unit"] == "GB/s"

@@ -66,6 +66,8 @@ class GraphedMatStep:
     def capture(self, key, mvp, cam, gt, gmask, seg, fm, room, stage):
         """inputs must be device tensors (they are kept alive with the graph, self.inputs: the recorded kernels read them by address); one graph per
         (view key, stage)"""
+        from .plot_writer import quiesce
+        quiesce()                                       # no worker thread may touch the HIP runtime while a stream is being captured
         P = gt.shape[0] * gt.shape[1] * gt.shape[2]
         if self.static_shift is None:
             self.static_shift = torch.zeros((P, 2), device=gt.device)

@@ -18,8 +18,26 @@ import torch
 from . import io_formats as IO
 
 
+_LIVE = None          # weak set of the writers with a worker thread
+
+
+def quiesce():
+    """wait until no writer has anything in flight.  Called before a hipGraph capture (graph_step / sharded_step): while a stream is being captured in the
+    default (global) mode, a hipEventSynchronize from ANY thread -- the worker waiting for its device -> host copy -- is an error that also invalidates the
+    capture (seen in round 5: the stage-1 captures right behind the epoch-0 plot fell back to eager steps).  Captures happen in the first epoch of a stage
+    only, so the wait (one encode + write, ~0.1 s at 4096^2) is paid at most once per stage."""
+    if _LIVE:
+        for w in list(_LIVE):
+            w.flush()
+
+
 class AsyncPlotWriter:
     def __init__(self, max_pending=4):
+        global _LIVE
+        if _LIVE is None:
+            import weakref
+            _LIVE = weakref.WeakSet()
+        _LIVE.add(self)
         self._q = queue.Queue()
         self._pool = {}                 # (shape, dtype) -> [pinned tensors]
         self._lock = threading.Lock()

@@ -154,6 +154,8 @@ class ShardedMatStep:
     # ---- set-up -----------------------------------------------------------------------------------------------------------------------------
     def capture(self, key, mvp, cam, gt, gmask, seg, fm, room, stage):
         """inputs must be device tensors that stay alive; one state (and, with use_graph, three graphs) per (view key, stage)"""
+        from .plot_writer import quiesce
+        quiesce()                                       # no worker thread may touch the HIP runtime while a stream is being captured
         if stage == 0:
             raise ValueError("stage 0 has no specular term: run it as the replicated GraphedMatStep (no communication needed)")
         dev = gt.device
