@@ -398,3 +398,35 @@ def test_pixel_sharded_material_training_matches_single_rank(tmp_path, tex_res):
     assert np.array_equal(z["a"], ref.model.materials_a.detach().cpu().numpy())
     assert np.array_equal(z["r"], ref.model.materials_r.detach().cpu().numpy())
     assert int(z["sharded_graphs"]) > 0                    # the stage-1 / stage-2 steps really ran as recorded phases
+
+
+def test_index_texture_written_from_the_products_panoramas_feeds_the_reference_flow(tmp_path):
+    """datasets.write_index_texture_from_panoramas (asset preparation of bench.py --e2e's second IrrT timing): every valid texel gets the (row, column,
+    panorama) code of the panorama pixel that sees it; TracerO3d's reference flow (generate_positions -> Cube2Pano -> calcute_position_normal_texture,
+    models/tracer_o3d_irt.py:99-142) must then gather, for the texels some panorama sees, a position within a panorama pixel of the texel's own"""
+    from texir_code_amd import conf as C, datasets as D
+    from texir_code_amd.models import TracerO3d
+    root = str(tmp_path / "ds")
+    D.write_synthetic_dataset(root, T=2000, texel_res=64, tex_res=64, n_side=2)
+    conf_irt = str(tmp_path / "irt.conf")
+    D.write_conf(conf_irt, root, cube_res=16, spp=(64, 16), model="irt")
+    seen = D.write_index_texture_from_panoramas(root, conf_irt)
+    assert seen > 0.8, seen
+    mesh_dir = os.path.join(root, "vrproc", "hdr_texture")
+    z = np.load(os.path.join(mesh_dir, "texel_gbuffer.npz"))
+    valid = np.abs(z["normal"]).sum(-1) > 0
+    open(conf_irt, "w").write(open(conf_irt).read().replace("irt_res = native", "irt_res = native\n    texel_gbuffer = pano"))
+    cf = C.parse_file(conf_irt)
+    ds = D.SynCubeDataset(cf.get_string("train.path_mesh_open3d"), cf.get_list("train.pano_img_res"), cf.get_float("train.hdr_exposure"))
+    m = TracerO3d(cf, ds.ids, ds.extrinsics_list)
+    idx = m.index_texture
+    assert idx.dtype == np.uint16 and (idx[valid].astype(np.int64).sum(-1) > 0).all() and (idx[~valid] == 0).all()
+    assert idx[valid][:, 2].max() < len(ds.ids) and idx[valid][:, :2].max() <= 50000
+    m.generate_positions()
+    m.calcute_position_normal_texture()
+    got = m.position_texture.cpu().numpy()
+    err = np.linalg.norm(got - z["position"], axis=-1)[valid]
+    assert (err < 0.06).mean() > 0.8, float((err < 0.06).mean())                 # (a 1024 x 512 panorama pixel is ~2.5 cm at 4 m)
+    assert np.all(got[~valid] == 0)
+    irr = m()                                                                    # the whole forward through the gathered G-buffer
+    assert irr.shape == (64, 64, 3) and torch.isfinite(irr).all() and float(irr[torch.from_numpy(valid).cuda()].mean()) > 0

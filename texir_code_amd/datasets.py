@@ -260,6 +260,76 @@ def write_synthetic_dataset(root, T=20000, texel_res=256, tex_res=256, n_side=2,
     return sc
 
 
+def write_index_texture_from_panoramas(root, conf_irt, chunk=1 << 21):
+    """Replace the placeholder codes of `0.png` by real ones (needs the GPU; asset preparation, not a stage): what the reference's asset pipeline stores per texel
+    is WHERE one of the scene's panoramas sees it -- (row code, column code, panorama id), models/tracer_o3d_irt.py:119-135 -- and TracerO3d gathers the texel's
+    position and normal from that panorama's G-buffer.  Here the panoramas are the product's own (TracerO3d.generate_positions), every valid texel of the exact
+    texel G-buffer is projected into all of them (equirectangular: theta = atan2(x, z), phi = asin(y), utils/Cube2Pano.py:57-70) and assigned to the panorama whose
+    stored position at that pixel lies nearest to the texel (i.e. sees it un-occluded, if any does).  Returns the share of texels whose gathered position is
+    within 5 cm of their true one."""
+    from .conf import ConfigFactory
+    from .models import TracerO3d
+    mesh_dir = os.path.join(root, "vrproc", "hdr_texture")
+    conf = ConfigFactory.parse_file(conf_irt)
+    ds = SynCubeDataset(conf.get_string("train.path_mesh_open3d"), conf.get_list("train.pano_img_res"), conf.get_float("train.hdr_exposure"))
+    model = TracerO3d(conf, ds.ids, ds.extrinsics_list)
+    model.generate_positions()
+    panos = torch.stack([p_[..., 0:3] for p_ in model.position_normal_list], 0)            # [K, h, w, 3]
+    K, h, w, _ = panos.shape
+    cams = torch.stack([c_.to(panos.device).reshape(3) for c_ in ds.cam_position_list], 0)
+    z = np.load(os.path.join(mesh_dir, "texel_gbuffer.npz"))
+    pos = torch.from_numpy(z["position"]).to(panos.device)
+    H, W, _ = pos.shape
+    valid = torch.from_numpy((np.abs(z["normal"]).sum(-1) > 0)).to(panos.device).reshape(-1)
+    pos = pos.reshape(-1, 3)
+    codes = torch.zeros((H * W, 3), dtype=torch.int32, device=panos.device)
+    near = torch.zeros(H * W, dtype=torch.bool, device=panos.device)
+    idx_all = torch.nonzero(valid)[:, 0]
+
+    def pixel_of(d, sg):
+        theta, phi = torch.atan2(sg[0] * d[:, 0], sg[2] * d[:, 2]), torch.asin((sg[1] * d[:, 1]).clamp(-1, 1))
+        col = ((theta + np.pi) / (2 * np.pi) * (w - 1)).round().long().clamp(0, w - 1)
+        row = ((0.5 * np.pi - phi) / np.pi * (h - 1)).round().long().clamp(0, h - 1)
+        return row, col
+
+    # the panorama's axis conventions are whatever the cube faces + Cube2Pano produce: measured, not assumed -- the sign triple under which the panoramas show
+    # the texels where they are
+    sub = idx_all[:: max(1, idx_all.numel() // 100000)]
+    score = {}
+    for sg in [(a_, b_, c_) for a_ in (1.0, -1.0) for b_ in (1.0, -1.0) for c_ in (1.0, -1.0)]:
+        p_ = pos[sub]
+        best = torch.full((sub.numel(),), float("inf"), device=panos.device)
+        for k in range(K):
+            d = p_ - cams[k]
+            row, col = pixel_of(d / d.norm(dim=-1, keepdim=True).clamp(min=1e-12), sg)
+            best = torch.minimum(best, (panos[k, row, col] - p_).norm(dim=-1))
+        score[sg] = float((best < 0.05).float().mean().item())
+    sg = max(score, key=score.get)
+    if score[sg] < 0.5:
+        raise RuntimeError("no axis convention maps the texels into the panoramas (best %s: %.3f)" % (sg, score[sg]))
+    for a in range(0, idx_all.numel(), chunk):
+        ids = idx_all[a:a + chunk]
+        p_ = pos[ids]
+        best = torch.full((ids.numel(),), float("inf"), device=panos.device)
+        best_code = torch.zeros((ids.numel(), 3), dtype=torch.int32, device=panos.device)
+        for k in range(K):
+            d = p_ - cams[k]
+            row, col = pixel_of(d / d.norm(dim=-1, keepdim=True).clamp(min=1e-12), sg)
+            err = (panos[k, row, col] - p_).norm(dim=-1)
+            better = err < best
+            best = torch.where(better, err, best)
+            # the reference decodes int(code / 50000 * size): store the code of the pixel's centre, never (0, 0, 0) -- that is a seam
+            rc = ((row.float() + 0.5) / h * 50000).round().clamp(1, 50000).int()
+            cc = ((col.float() + 0.5) / w * 50000).round().clamp(1, 50000).int()
+            kk = torch.full_like(rc, k)
+            best_code = torch.where(better[:, None], torch.stack([rc, cc, kk], -1), best_code)
+        codes[ids] = best_code
+        near[ids] = best < 0.05
+    idx = codes.reshape(H, W, 3).cpu().numpy().astype(np.uint16)
+    IO.write_png(os.path.join(mesh_dir, "0.png"), np.ascontiguousarray(idx[..., ::-1]))        # the file stores RGB = (panorama id, column code, row code)
+    return float(near[idx_all].float().mean().item())
+
+
 def write_conf(path, root, cube_res=32, spp=(64, 16), albedo_res=256, rough_res=256, epochs=1, model="mat"):
     txt = """train{
     expname = synthetic

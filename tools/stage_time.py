@@ -102,7 +102,7 @@ def time_mat(conf_mat, exps, epochs, log_lag):
     return out
 
 
-def run(workload="c4", root=None, mat_epochs=40, keep=False, style="room", do_mat=True, log_lag=0):
+def run(workload="c4", root=None, mat_epochs=40, keep=False, style="room", do_mat=True, log_lag=0, pano_flow=True):
     import torch
     from texir_code_amd import conf as C, datasets as D
     made = root is None
@@ -120,8 +120,20 @@ def run(workload="c4", root=None, mat_epochs=40, keep=False, style="room", do_ma
         _lib.lib()
         out["irrt"] = time_irrt(conf_irt)
         out["irrt"]["output"] = os.path.getsize(os.path.join(mesh_dir, "0_irr_texture.hdr"))
+        out["irrt"]["texel_gbuffer"] = "file (the synthetic generator's exact texel_gbuffer.npz)"
+        shutil.copy(os.path.join(mesh_dir, "0_irr_texture.hdr"), os.path.join(mesh_dir, "irt.hdr"))         # (Mat's irradiance input: the exact-G-buffer texture)
+        if pano_flow:
+            # the reference's own flow (tracer_o3d_irt.py:99-142): per-panorama cube G-buffers -> Cube2Pano -> gather through the index texture's codes
+            t0 = time.perf_counter()
+            with _quiet():
+                seen = D.write_index_texture_from_panoramas(root, conf_irt)
+            out["index_texture_prep_s"] = round(time.perf_counter() - t0, 2)
+            conf_pano = os.path.join(root, "irt_pano.conf")
+            open(conf_pano, "w").write(open(conf_irt).read().replace("irt_res = native", "irt_res = native\n    texel_gbuffer = pano"))
+            out["irrt_pano_gather"] = time_irrt(conf_pano)
+            out["irrt_pano_gather"]["texel_gbuffer"] = ("generate_positions (%d panoramas x cube 256 ray-cast G-buffers -> Cube2Pano 1024 x 512) + index-texture gather; "
+                                                        "%.3f of the valid texels land within 5 cm of their true position" % (side * side, seen))
         if do_mat:
-            shutil.copy(os.path.join(mesh_dir, "0_irr_texture.hdr"), os.path.join(mesh_dir, "irt.hdr"))
             D.write_conf(conf_mat, root, cube_res=cube, spp=(spp, S), albedo_res=mres, rough_res=mres, epochs=mat_epochs, model="mat")
             txt = open(conf_mat).read().replace("plot_freq = 1000", "plot_freq = 10")
             if log_lag:
