@@ -415,7 +415,9 @@ def test_index_texture_written_from_the_products_panoramas_feeds_the_reference_f
     mesh_dir = os.path.join(root, "vrproc", "hdr_texture")
     z = np.load(os.path.join(mesh_dir, "texel_gbuffer.npz"))
     valid = np.abs(z["normal"]).sum(-1) > 0
-    open(conf_irt, "w").write(open(conf_irt).read().replace("irt_res = native", "irt_res = native\n    texel_gbuffer = pano"))
+    txt = open(conf_irt).read().replace("irt_res = native", "irt_res = native\n    texel_gbuffer = pano")
+    with open(conf_irt, "w") as f:
+        f.write(txt)
     cf = C.parse_file(conf_irt)
     ds = D.SynCubeDataset(cf.get_string("train.path_mesh_open3d"), cf.get_list("train.pano_img_res"), cf.get_float("train.hdr_exposure"))
     m = TracerO3d(cf, ds.ids, ds.extrinsics_list)
