@@ -28,7 +28,7 @@ def quiesce():
     only, so the wait (one encode + write, ~0.1 s at 4096^2) is paid at most once per stage."""
     if _LIVE:
         for w in list(_LIVE):
-            w.flush()
+            w._q.join()            # (wait only: a failed write is reported by the writer's own flush() / close(), not disguised as a failed capture)
 
 
 class AsyncPlotWriter:
