@@ -108,3 +108,38 @@ def test_cpu_baseline_reports_the_cpus_it_may_really_use():
     if h["cgroup_cpus"] is not None:
         assert h["usable"] <= int(h["cgroup_cpus"]) + 1
     assert [bench.irt_plan_parts(n) for n in (2048, 1024, 256, 64, 16, 8, 100)] == [32, 32, 32, 8, 2, 1, 1]
+
+
+def test_between_steps_hook_sees_the_next_batch_of_the_same_epoch_only():
+    """RunnerBase.fit (round 5): between_steps(next_batch, epoch, next_index) runs after a step was launched and before after_step, only when the epoch has a next batch
+    this rank takes -- never across an epoch boundary (that is where the reference's loops draw other random numbers) and never after the last step"""
+    from texir_code_amd.trainer.base import RunnerBase
+
+    class M:
+        def train(self):
+            pass
+
+    log = []
+    r = RunnerBase()
+    r.model, r.cur_iter = M(), 0
+    r.fit([10, 11, 12, 13], 0, 1, lambda b: b, takes=lambda i: i != 2,
+          after_step=lambda e, i, out: log.append("after %d.%d" % (e, i)), between_steps=lambda nb, e, ni: log.append("prep %d.%d=%d" % (e, ni, nb)),
+          epoch_end=lambda e: log.append("end %d" % e))
+    # batch 2 is another rank's: no preparation for it; batch 3 is prepared only when it is the NEXT one (after the skipped batch nothing was launched)
+    assert log == ["prep 0.1=11", "after 0.0", "after 0.1", "after 0.3", "end 0", "prep 1.1=11", "after 1.0", "after 1.1", "after 1.3", "end 1"]
+
+
+def test_collate_one_view_equals_default_collate_without_copies():
+    import torch
+    from texir_code_amd.trainer.train_material import collate_one_view
+    item = {"color": torch.rand(6, 4, 4, 3), "mask": torch.rand(6, 4, 4, 1), "cam_to_world": torch.rand(6, 4, 4), "id": "view003", "cam_position": torch.rand(3), "n": 5}
+    a, b = collate_one_view([item]), torch.utils.data.default_collate([item])
+    assert set(a) == set(b)
+    for k in a:
+        if torch.is_tensor(b[k]):
+            assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
+        else:
+            assert a[k] == b[k], k
+    assert a["color"].data_ptr() == item["color"].data_ptr()                  # a view of the dataset's tensor, not a stacked copy
+    two = collate_one_view([item, item])
+    assert two["color"].shape == (2, 6, 4, 4, 3)                              # (larger batches fall back to the stock collate)
