@@ -2,7 +2,7 @@
 (trainer/exp_runner.py:54-80, trainer/generate_ir_texture.py:75-82, trainer/train_material.py:408-605) -- at BASELINE.json's sizes,
 from files on disk to files on disk, with the per-phase breakdown (load, BVH, G-buffer, kernel, download, write ...).
 
-    python tools/stage_time.py [--workload c4] [--root DIR] [--mat-epochs 40] [--json]         (also: python bench.py --e2e)
+    python tools/stage_time.py [--workload c4] [--root DIR] [--mat-epochs 40] [--no-mat] [--log-lag N] [--keep]         (also: python bench.py --e2e)
 
 The asset set is written first (not timed): a 1 M-triangle out1.obj, a 4096^2 16-bit index PNG, a 4096^2 Radiance hdr_texture.hdr, the exact
 texel G-buffer, 16 cameras, and -- for Mat -- the 16 ground-truth cube views rendered by the product's own forward.  What is timed is what a
