@@ -246,7 +246,7 @@ def write_synthetic_dataset(root, T=20000, texel_res=256, tex_res=256, n_side=2,
         r0, r1 = max(0, int(np.floor((y - synth.GUTTER / 2) * texel_res))), min(texel_res, int(np.ceil((y + h + synth.GUTTER / 2) * texel_res)))
         seg[r0:r1, c0:c1] = p.cls
     IO.write_png(os.path.join(d, "0_seg_gray.png"), np.ascontiguousarray(seg[::-1]))
-    cams = cameras.grid_cameras(n_side)
+    cams = cameras.grid_cameras(n_side, room=synth.HOUSE) if style == "house" else cameras.grid_cameras(n_side)      # (house: the grid spans all 3 x 3 rooms)
     with open(os.path.join(root, "info", "aligned.txt"), "w") as f:
         f.write("\n".join("view%03d" % i for i in range(len(cams))) + "\n")
     with open(os.path.join(root, "info", "final_extrinsics.txt"), "w") as f:
@@ -305,7 +305,7 @@ def write_index_texture_from_panoramas(root, conf_irt, chunk=1 << 21):
             best = torch.minimum(best, (panos[k, row, col] - p_).norm(dim=-1))
         score[sg] = float((best < 0.05).float().mean().item())
     sg = max(score, key=score.get)
-    if score[sg] < 0.5:
+    if score[sg] < 0.2:
         raise RuntimeError("no axis convention maps the texels into the panoramas (best %s: %.3f)" % (sg, score[sg]))
     for a in range(0, idx_all.numel(), chunk):
         ids = idx_all[a:a + chunk]
