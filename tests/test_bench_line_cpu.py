@@ -143,3 +143,55 @@ def test_collate_one_view_equals_default_collate_without_copies():
     assert a["color"].data_ptr() == item["color"].data_ptr()                  # a view of the dataset's tensor, not a stacked copy
     two = collate_one_view([item, item])
     assert two["color"].shape == (2, 6, 4, 4, 3)                              # (larger batches fall back to the stock collate)
+
+
+def _contract_keys():
+    return {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+            "roofline", "cpu_baseline", "full"}
+
+
+def test_compact_line_fits_the_drivers_capture_and_keeps_the_contract_keys():
+    """BENCH_r05.json had parsed = null because the printed line had grown to 20 KB.  The printed line is built by bench.compact_line from the full record;
+    canned inputs = the full records of round 5 (N = 1 driver command; 2 gloo ranks on one GPU)"""
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05", "bench_driver_command.json")))
+    assert len(json.dumps(full)) > 15000
+    line = bench.compact_line(full, "gpurun_out/bench_full.json")
+    assert "\n" not in line and len(line) < 4096 and len(line) <= bench.LINE_CAP
+    o = json.loads(line)
+    assert _contract_keys() <= set(o), _contract_keys() - set(o)
+    assert set(o["config"]) == {"workload", "parallelism"} and o["config"]["workload"].startswith("c4:")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "data", "scaling", "higher_is_better"):
+        assert o[k] == full[k], k
+    r = o["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "binding", "binding_frac", "algorithmic_frac", "profile"} <= set(r)
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["traffic"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1.0
+    # SURVEY 8(d)'s algorithmic bytes over the live kernel time: recomputable from the line, and > 1 on this path (cache-served; it bounds nothing)
+    rays = full["roofline"]["rays_per_launch"]
+    assert abs(r["algorithmic_frac"] - r["algorithmic_bytes_per_ray"] * rays / (r["kernel_ms"] * 1e-3) / 8e12) < 5e-3 and r["algorithmic_frac"] > 1.0
+    assert r["binding_frac"] == full["roofline"]["limits"][r["binding"]]["frac"] and r["profile"] == "profiles/pmc_c4.json"
+    assert set(o["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"} and o["cpu_baseline"]["kind"] == "port"
+    assert {"ms", "ms_back_to_back", "frac"} <= set(o["material_step"]) and o["material_step"]["ms"] == full["material_step"]["ms"]
+    assert set(o["extra_mrays_s"]) == {"c4_scan", "house"} and o["projected_speedup"]["8"] == full["ranks"]["projected"]["8"]["projected_speedup"]
+    ph = full["e2e"]["mat"]["phases_s"]
+    assert abs(o["e2e_s"]["mat_stage_ms_per_step"] - 1e3 * (ph["stage0"] + ph["stage1"] + ph["stage2"]) / full["e2e"]["mat"]["steps"]) < 1e-3
+    assert o["full"] == "gpurun_out/bench_full.json"
+    # N > 1 record: same cap, the per-rank block in place of the projection
+    full2 = json.loads([l for l in open(os.path.join(ROOT, "profiles", "r05", "bench_2rank_gloo_one_gpu.json")) if l.startswith("{")][-1])
+    full2.setdefault("ranks", {}).update({"rccl_ranks": None, "backend": "gloo", "collective_bytes_per_step": 12345})
+    line2 = bench.compact_line(full2, "x.json")
+    o2 = json.loads(line2)
+    assert len(line2) <= bench.LINE_CAP and (_contract_keys() - {"cpu_baseline"}) <= set(o2)
+    assert o2["n_gpus"] == 2 and len(o2["ranks"]["kernel_ms"]) == 2 and o2["ranks"]["assembled_ok"] is True and o2["ranks"]["backend"] == "gloo"
+    # an unexpected long string cannot push the line past the cap: optional blocks go first
+    full3 = json.loads(json.dumps(full))
+    full3["config"]["workload"] = "w" * 2500
+    assert len(bench.compact_line(full3, "x.json")) <= bench.LINE_CAP
+
+
+def test_write_full_record_goes_to_the_named_file(tmp_path, monkeypatch):
+    import bench
+    p = tmp_path / "sub" / "full.json"
+    monkeypatch.setenv("TEXIR_BENCH_FULL", str(p))
+    assert bench.write_full({"a": 1}) == str(p) and json.load(open(p)) == {"a": 1}

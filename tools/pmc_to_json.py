@@ -21,8 +21,15 @@ res = {"workload": wl, "kernel": kernel, "kernel_src_sha": bench.kernel_src_sha(
        "counters": dict(c), "kernel_ms_under_pmc": dur}
 rd = c.get("TCC_EA0_RDREQ_sum", 0.0)
 if rd:
-    # every read request of this kernel is a 128-byte line (TCC_EA0_RDREQ_128B == RDREQ, profiles/r01/calib); WRITE_SIZE is in KB
-    res["fabric_bytes_per_launch"] = rd * 128.0 + c.get("WRITE_SIZE", 0.0) * 1024.0
+    # read requests priced at their own size where the split counters were collected (98.4 % are 128-byte lines on c4; round 5 priced the 64-byte
+    # ones at 128 B too: +0.8 %); without the split every request is taken as a 128-byte line.  WRITE_SIZE is in KB
+    r128, r64, r32 = c.get("TCC_EA0_RDREQ_128B_sum"), c.get("TCC_EA0_RDREQ_64B_sum", 0.0), c.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+    if r128:
+        rd_bytes = r128 * 128.0 + r64 * 64.0 + r32 * 32.0 + max(0.0, rd - r128 - r64 - r32) * 128.0
+    else:
+        rd_bytes = rd * 128.0
+    res["fabric_read_bytes_per_launch"] = rd_bytes
+    res["fabric_bytes_per_launch"] = rd_bytes + c.get("WRITE_SIZE", 0.0) * 1024.0
 if c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0) > 0:
     res["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
 if c.get("SQ_INSTS_VALU", 0):
