@@ -77,7 +77,7 @@ def make_workload(name, cache=None):
     from texir_code_amd import synth
     T, res, tex_res, spp, style = WORKLOADS[name]
     cache = cache or os.environ.get("TEXIR_SYNTH_CACHE")
-    path = os.path.join(cache, "%s.npz" % name) if cache else None
+    path = os.path.join(cache, "%s%s.npz" % (name, "_f32tex" if os.environ.get("TEXIR_BENCH_FLOAT_TEX", "0") == "1" else "")) if cache else None
     if path and os.path.exists(path):
         z = np.load(path)
         sc0 = {k: z[k] for k in ("verts", "tris", "tri_uvs", "hdr", "tri_class")}
@@ -87,6 +87,10 @@ def make_workload(name, cache=None):
             sc0["patches"] = [types.SimpleNamespace(rect=tuple(float(x) for x in r)) for r in z["patch_rects"]]
         return sc0, z["pos"], z["nrm"], z["valid"], z["shift"], res, spp
     sc0 = synth.make_scene(T, seed=666, tex_res=tex_res, style=style)
+    if os.environ.get("TEXIR_BENCH_FLOAT_TEX", "0") != "1":
+        # the texture as the reference's pipeline holds it: an RGBE file (hdr_texture.hdr) times 2^hdr_exposure (tracer_o3d_irt.py:77-81; configs/*.conf: 5);
+        # TEXIR_BENCH_FLOAT_TEX=1 keeps the generator's float-valued texels (rounds 1-5), which the hit shader then reads as float32 tiles
+        sc0["hdr"] = synth.rgbe_born(sc0["hdr"], 5.0)
     pos, nrm, valid = synth.make_texel_gbuffer(sc0, res)
     shift = synth.make_shifts(res * res)
     if path:
@@ -827,8 +831,10 @@ def main():
         return {"sc": sc, "sc0": sc0, "pos": pos, "nrm": nrm, "valid": valid, "shift": shift, "res": res, "spp": spp, "irr": irr, "ids": ids,
                 "dt": dt, "kern_ms": kern_ms, "ranks": ranks, "n_valid": n_valid, "build_s": build_s, "kernel": sc.irt_kernel_name(int(ids.numel()), spp),
                 "value": n_valid * spp * steps / dt / 1e6,
-                "desc": "%s: IrT %d spp, %dx%d texels (%d valid), %d-tri synthetic %s mesh, %dx%d RGB32F radiance texture"
-                        % (name, spp, res, res, n_valid, T, {"room": "indoor", "scan": "scan-like (rotated clutter, slats, openings)", "house": "3x3-room house (doors, untessellated shell + dense clutter, windows)"}[style], tex_res, tex_res)}
+                "desc": "%s: IrT %d spp, %dx%d texels (%d valid), %d-tri synthetic %s mesh, %dx%d radiance texture (%s)"
+                        % (name, spp, res, res, n_valid, T, {"room": "indoor", "scan": "scan-like (rotated clutter, slats, openings)", "house": "3x3-room house (doors, untessellated shell + dense clutter, windows)"}[style], tex_res, tex_res,
+                           {3: "RGBE x 2^5, read as 4-byte shared-exponent texels: 5x5-texel lines", 4: "RGBE x 2^5, read as 4-byte shared-exponent texels: 8x4-texel lines"}.get(
+                               sc.texture_layout(), "RGB32F tiles, layout %d" % sc.texture_layout()))}
 
     r = run_irt(args.workload, args.steps, args.warmup)
     mat = mat_view = None

@@ -64,6 +64,17 @@ TEXIR_API int texir_scene_destroy(texir_scene* scene);
 /* Replaces the temporary `self.texture = torch.where(intensity>=0.5, ...)` swap of stage -1
  * (models/mat_nvdiffrast.py:141-150).  tex [Ht,Wt,3] f32; is_device selects pointer kind. */
 TEXIR_API int texir_scene_set_texture(texir_scene* scene, const float* tex, int32_t Ht, int32_t Wt, int32_t is_device, void* stream);
+/* The hit shader's copy of the radiance texture (`self.texture`, models/tracer_o3d_irt.py:77-81: an RGBE file times 2^hdr_exposure).  When EVERY
+ * texel is three 8-bit integers times one power of two -- always true of such a texture -- it is kept as 4-byte shared-exponent texels that decode
+ * to the identical float32 values (layout 3: 5x5-texel lines at stride 4; 4: 8x4 at stride 7x3); any other texture keeps float32 tiles (2; 1 / 0 are the
+ * older A/B layouts).  Decided at texir_scene_create and again at every texir_scene_set_texture (which then synchronises `stream` once to read the
+ * pack kernel's verdict; on a capturing stream the float32 layout is taken).  Results are bit-identical in every layout. */
+TEXIR_API int texir_scene_texture_layout(const texir_scene* scene, int32_t* layout);
+/* Host statement of the 4-byte texel: word = m_r | m_g << 8 | m_b << 16 | E << 24, value_c = m_c * 2^(E - 127).  rgb /+host+/ [n,3] f32 ->
+ * words /+host+/ [n], exact /+host+/ [n] (nullable; 1 where the triple has this form: non-negative, finite, normal, one shared power of two with
+ * 8-bit integers -- e.g. any cv2-decoded RGBE pixel times 2^k; 0 -> the word is 0 and the device keeps float32 texels).  unpack is the decode. */
+TEXIR_API int texir_texel_pack(const float* rgb, int64_t n, uint32_t* words, uint8_t* exact);
+TEXIR_API int texir_texel_unpack(const uint32_t* words, int64_t n, float* rgb);
 
 /* out[0]=inner nodes of the traversal tree (4-wide quantised by default), [1]=triangles, [2]=max depth, [3]=node bytes,
  * [4]=triangle bytes (leaf-order slots + the quad records the 4-wide leaves name), [5]=uv bytes, [6]=texture bytes, [7]=device */

@@ -276,3 +276,50 @@ def test_scalar_log_and_phase_timer(tmp_path):
     with t.phase("c"):
         pass
     assert t.report() == {}
+
+
+def test_four_byte_texels_hold_every_rgbe_born_value_exactly():
+    """texture layouts 3 / 4 (include/texir_hip.h texir_texel_pack): a texel of an RGBE file times 2^hdr_exposure (tracer_o3d_irt.py:77-81) is three 8-bit
+    integers times one power of two; the 4-byte word decodes to the IDENTICAL float32 triple.  Anything else is flagged and keeps float32 texels."""
+    from texir_code_amd import _lib
+    from texir_code_amd.io_formats import rgbe_decode_py
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    rgbe = rng.integers(0, 256, (200000, 4), dtype=np.uint8)
+    rgbe[:, 3] = rng.integers(40, 220, 200000)          # exponents whose values times 2^+-5 stay normal floats
+    rgbe[:1000, :3] = 0                                 # black texels
+    rgbe[1000:2000, 3] = 0                              # e = 0: cv2 decodes them to 0
+    rgbe[2000:2100] = [255, 255, 255, 219]
+    rgbe[2100:2200] = [1, 0, 0, 40]
+    for exposure in (5.0, 3.0, 0.0, -2.0):
+        rgb = np.ascontiguousarray(rgbe_decode_py(rgbe) * np.float32(2.0 ** exposure), np.float32)
+        words, ok, back = np.zeros(len(rgb), np.uint32), np.zeros(len(rgb), np.uint8), np.zeros_like(rgb)
+        _lib.check(L.texir_texel_pack(_lib.ptr(rgb), len(rgb), _lib.ptr(words), _lib.ptr(ok)))
+        assert ok.all()
+        _lib.check(L.texir_texel_unpack(_lib.ptr(words), len(rgb), _lib.ptr(back)))
+        assert np.array_equal(back.view(np.uint32), rgb.view(np.uint32))
+        assert (words[:2000] == 0).all()
+    # what does not have the form: a ninth mantissa bit, two exponents too far apart, negative, -0.0, subnormal, inf, nan, a non-power-of-two exposure
+    bad = np.array([[257.0, 1.0, 1.0], [1.0, 2.0 ** -9, 0.0], [-1.0, 0.0, 0.0], [-0.0, 1.0, 1.0], [1e-45, 0.0, 0.0], [np.inf, 0.0, 0.0], [np.nan, 0.0, 0.0],
+                    [0.3, 0.3, 0.3], [2.0 ** 128 * 0 + 3.0e38, 1.0, 0.0]], np.float32)
+    ok = np.ones(len(bad), np.uint8)
+    words = np.full(len(bad), 7, np.uint32)
+    _lib.check(L.texir_texel_pack(_lib.ptr(bad), len(bad), _lib.ptr(words), _lib.ptr(ok)))
+    assert not ok.any() and (words == 0).all()
+    frac = np.ascontiguousarray(rgbe_decode_py(rgbe[3000:4000]) * np.float32(2.0 ** 2.5), np.float32)
+    ok = np.ones(len(frac), np.uint8)
+    _lib.check(L.texir_texel_pack(_lib.ptr(frac), len(frac), _lib.ptr(np.zeros(len(frac), np.uint32)), _lib.ptr(ok)))
+    assert ok.mean() < 0.05
+    # values that are exact but not RGBE-born: (255, 1, 0) * 2^-20, a lone 2^100
+    good = np.array([[255 * 2.0 ** -20, 2.0 ** -20, 0.0], [2.0 ** 100, 0.0, 0.0], [0.0, 0.0, 0.0], [96.0, 0.0, 160.0]], np.float32)
+    words, ok, back = np.zeros(4, np.uint32), np.zeros(4, np.uint8), np.zeros_like(good)
+    _lib.check(L.texir_texel_pack(_lib.ptr(good), 4, _lib.ptr(words), _lib.ptr(ok)))
+    _lib.check(L.texir_texel_unpack(_lib.ptr(words), 4, _lib.ptr(back)))
+    assert ok.all() and np.array_equal(back, good)
+    # the synthetic scenes' texture, passed through the reference's file format, has the form everywhere
+    from texir_code_amd import synth
+    sc0 = synth.make_scene(2000, tex_res=128)
+    born = np.ascontiguousarray(synth.rgbe_born(sc0["hdr"]).reshape(-1, 3))
+    ok = np.zeros(len(born), np.uint8)
+    _lib.check(L.texir_texel_pack(_lib.ptr(born), len(born), _lib.ptr(np.zeros(len(born), np.uint32)), _lib.ptr(ok)))
+    assert ok.all() and np.abs(born.reshape(sc0["hdr"].shape) - sc0["hdr"]).max() <= sc0["hdr"].max() / 128

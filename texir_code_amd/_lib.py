@@ -41,6 +41,9 @@ def lib():
             "texir_scene_create": [vp, i32, vp, i32, vp, vp, i32, i32, i32, C.POINTER(vp)],
             "texir_scene_destroy": [vp],
             "texir_scene_set_texture": [vp, vp, i32, i32, i32, vp],
+            "texir_scene_texture_layout": [vp, vp],
+            "texir_texel_pack": [vp, i64, vp, vp],
+            "texir_texel_unpack": [vp, i64, vp],
             "texir_scene_info": [vp, vp],
             "texir_scene_scheduler": [vp, vp],
             "texir_scene_tune": [vp, vp, vp, vp, vp, i64, i32, i32, vp],

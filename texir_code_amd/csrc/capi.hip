@@ -24,6 +24,11 @@ struct texir_scene {
     void* d_nodes = nullptr; void* d_tris = nullptr; void* d_quads = nullptr; void* d_uvs = nullptr; float* d_tex = nullptr;
     float* d_tex_tiled = nullptr;        // retiled copy read by the hit shader (texture layouts 1, 2); d_tex stays the row-major master
     size_t tiled_bytes = 0;
+    int tiled_layout = 0;                // layout d_tex_tiled was sized for
+    uint32_t* d_tex_packed = nullptr;    // 4-byte shared-exponent texels (layouts 3, 4), in force only while the texture packs EXACTLY (install_texture)
+    size_t packed_bytes = 0;
+    int packed_layout = 0;
+    unsigned int* d_tex_flag = nullptr;  // device word: texels of the last pack that were not representable
     int64_t n_nodes = 0, n_nodes4 = 0, n_tris = 0, n_slots = 0 /* leaf-order slots behind d_tris / d_uvs / d_cnrm: = n_tris, or 2 per quad record (bvh_build.h) */, n_quads = 0, n_uv_recs = 0 /* 32-byte uv records behind d_uvs: one per quad record (TEXIR_UV_QUAD) or per slot */, max_depth = 0;
     int width = 2;
     size_t tex_bytes = 0;
@@ -72,6 +77,48 @@ static int fail(int code, const char* fmt, ...)
         hipError_t e_ = (expr);                                                                          \
         if (e_ != hipSuccess) return fail(TEXIR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+
+// Chooses and fills the hit shader's copy of the radiance texture; d_tex (row-major float32 master) has been written on `st` already.
+// TEXIR_TEX_LAYOUT 4 (default) / 3: 4-byte shared-exponent texels when EVERY texel is three 8-bit integers times one power of two -- what an RGBE file
+// times 2^hdr_exposure always is (tracer_o3d_irt.py:77-81) -- decoding to the identical floats; any other texture (a float-valued synthetic one,
+// 2.5 x an RGBE one, negative values) keeps the float32 tiles of layout 2.  The decision needs the pack kernel's verdict, i.e. one stream
+// synchronisation: on a capturing stream the float32 layout is taken without asking.  0 / 1 / 2 force the float32 layouts (A/B runs).
+static int install_texture(texir_scene* s, hipStream_t st)
+{
+    const int want = env().tex_layout, Ht = s->dev.Ht, Wt = s->dev.Wt;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    if ((want == 3 || want == 4) && !capturing && Ht < (1 << 16) && Wt < (1 << 16)) {
+        int tx, ty;
+        const size_t bytes = tex_pack_bytes(Ht, Wt, want, &tx, &ty);
+        if (s->d_tex_packed && (s->packed_layout != want || s->packed_bytes != bytes)) { HIP_TRY(hipFree(s->d_tex_packed)); s->d_tex_packed = nullptr; }
+        if (!s->d_tex_packed) { HIP_TRY(hipMalloc((void**)&s->d_tex_packed, bytes)); s->packed_bytes = bytes; s->packed_layout = want; }
+        if (!s->d_tex_flag) HIP_TRY(hipMalloc((void**)&s->d_tex_flag, sizeof(unsigned int)));
+        HIP_TRY(launch_tex_pack(s->d_tex, s->d_tex_packed, Ht, Wt, want, s->d_tex_flag, st));
+        unsigned int bad = 1;
+        HIP_TRY(hipMemcpyAsync(&bad, s->d_tex_flag, sizeof(bad), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (bad == 0) {
+            s->dev.tex = reinterpret_cast<const float*>(s->d_tex_packed); s->dev.tex_layout = want; s->dev.tiles_x = tx;
+            return TEXIR_OK;
+        }
+    }
+    const int layout = want >= 3 ? 2 : want;
+    if (layout == 1 || layout == 2) {
+        int tx, ty;
+        const size_t bytes = tex_retile_bytes(Ht, Wt, layout, &tx, &ty);
+        if (s->d_tex_tiled && (s->tiled_layout != layout || s->tiled_bytes != bytes)) { HIP_TRY(hipFree(s->d_tex_tiled)); s->d_tex_tiled = nullptr; }
+        if (!s->d_tex_tiled) {
+            if (capturing) return fail(TEXIR_ERR_INVALID, "texir_scene_set_texture: the stream is being captured and the float32 tiles are not allocated yet");
+            HIP_TRY(hipMalloc((void**)&s->d_tex_tiled, bytes)); s->tiled_bytes = bytes; s->tiled_layout = layout;
+        }
+        HIP_TRY(launch_tex_retile(s->d_tex, s->d_tex_tiled, Ht, Wt, layout, st));
+        s->dev.tex = s->d_tex_tiled; s->dev.tex_layout = layout; s->dev.tiles_x = tx;
+    } else {
+        s->dev.tex = s->d_tex; s->dev.tex_layout = 0; s->dev.tiles_x = 0;
+    }
+    return TEXIR_OK;
+}
 
 extern "C" {
 
@@ -129,16 +176,9 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
     s->dev.nodes4 = (const float4*)s->d_nodes4; s->dev.nodes4f = (const float4*)s->d_nodes4f;
     s->dev.nodes = (const float4*)s->d_nodes; s->dev.tris = (const float4*)s->d_tris; s->dev.quads = (const float4*)s->d_quads; s->dev.uvs = (const float4*)s->d_uvs;
     s->dev.tex = s->d_tex; s->dev.Ht = Ht; s->dev.Wt = Wt; s->dev.tex_layout = 0; s->dev.tiles_x = 0; s->dev.sched_weight = 0;
-    // hit-shader texture layout: 2 (one 128-byte line per bilinear footprint) by default, TEXIR_TEX_LAYOUT=0|1|2 for A/B runs
-    const int layout = env().tex_layout;
-    if (layout == 1 || layout == 2) {
-        int tx, ty;
-        s->tiled_bytes = tex_retile_bytes(Ht, Wt, layout, &tx, &ty);
-        if ((e = hipMalloc((void**)&s->d_tex_tiled, s->tiled_bytes)) != hipSuccess) return bail(e, "hipMalloc tiled texture");
-        if ((e = launch_tex_retile(s->d_tex, s->d_tex_tiled, Ht, Wt, layout, 0)) != hipSuccess) return bail(e, "retile texture");
-        if ((e = hipStreamSynchronize(0)) != hipSuccess) return bail(e, "retile texture");
-        s->dev.tex = s->d_tex_tiled; s->dev.tex_layout = layout; s->dev.tiles_x = tx;
-    }
+    // hit-shader copy of the texture (install_texture): 4-byte texels when they decode to the identical floats, else float32 tiles
+    if (const int rc = install_texture(s, 0)) { texir_scene_destroy(s); return rc; }
+    if ((e = hipStreamSynchronize(0)) != hipSuccess) return bail(e, "texture layout");
     *out = s;
     return TEXIR_OK;
 }
@@ -155,6 +195,8 @@ int texir_scene_destroy(texir_scene* s)
     if (s->d_uvs) (void)hipFree(s->d_uvs);
     if (s->d_tex) (void)hipFree(s->d_tex);
     if (s->d_tex_tiled) (void)hipFree(s->d_tex_tiled);
+    if (s->d_tex_packed) (void)hipFree(s->d_tex_packed);
+    if (s->d_tex_flag) (void)hipFree(s->d_tex_flag);
     if (s->d_cnrm) (void)hipFree(s->d_cnrm);
     if (s->d_scratch) (void)hipFree(s->d_scratch);
     for (float* p : s->retired_scratch) (void)hipFree(p);
@@ -168,8 +210,7 @@ int texir_scene_set_texture(texir_scene* s, const float* tex, int32_t Ht, int32_
     if (!s || !tex) return fail(TEXIR_ERR_INVALID, "texir_scene_set_texture: null argument");
     if (Ht != s->dev.Ht || Wt != s->dev.Wt) return fail(TEXIR_ERR_INVALID, "texir_scene_set_texture: size %dx%d != scene texture %dx%d", Ht, Wt, s->dev.Ht, s->dev.Wt);
     HIP_TRY(hipMemcpyAsync(s->d_tex, tex, s->tex_bytes, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, (hipStream_t)stream));
-    if (s->d_tex_tiled) HIP_TRY(launch_tex_retile(s->d_tex, s->d_tex_tiled, Ht, Wt, s->dev.tex_layout, (hipStream_t)stream));
-    return TEXIR_OK;
+    return install_texture(s, (hipStream_t)stream);
 }
 
 int texir_scene_info(const texir_scene* s, int64_t out[8])
@@ -177,7 +218,38 @@ int texir_scene_info(const texir_scene* s, int64_t out[8])
     if (!s || !out) return fail(TEXIR_ERR_INVALID, "texir_scene_info: null argument");
     out[0] = s->width == 4 ? s->n_nodes4 : s->n_nodes; out[1] = s->n_tris; out[2] = s->max_depth;
     out[3] = s->width == 4 ? s->n_nodes4 * (int64_t)(sizeof(GpuNode4) + (s->d_nodes4f ? sizeof(GpuNode4F) : 0)) : s->n_nodes * (int64_t)sizeof(GpuNode);
-    out[4] = s->n_slots * (int64_t)sizeof(GpuTri) + s->n_quads * (int64_t)sizeof(GpuQuad); out[5] = s->d_uvs ? s->n_uv_recs * (int64_t)sizeof(GpuTriUV) : 0; out[6] = (int64_t)(s->d_tex_tiled ? s->tiled_bytes : s->tex_bytes); out[7] = s->device;
+    out[4] = s->n_slots * (int64_t)sizeof(GpuTri) + s->n_quads * (int64_t)sizeof(GpuQuad); out[5] = s->d_uvs ? s->n_uv_recs * (int64_t)sizeof(GpuTriUV) : 0; out[6] = (int64_t)(s->dev.tex_layout >= 3 ? s->packed_bytes : s->dev.tex_layout >= 1 ? s->tiled_bytes : s->tex_bytes); out[7] = s->device;
+    return TEXIR_OK;
+}
+
+int texir_scene_texture_layout(const texir_scene* s, int32_t* layout)
+{
+    if (!s || !layout) return fail(TEXIR_ERR_INVALID, "texir_scene_texture_layout: null argument");
+    *layout = s->dev.tex_layout;
+    return TEXIR_OK;
+}
+
+int texir_texel_pack(const float* rgb, int64_t n, uint32_t* words, uint8_t* exact)
+{
+    if ((!rgb || !words) && n > 0) return fail(TEXIR_ERR_INVALID, "texir_texel_pack: null argument");
+    for (int64_t i = 0; i < n; i++) {
+        uint32_t b[3], w = 0u;
+        std::memcpy(b, rgb + 3 * i, 12);
+        const bool ok = pack_texel(b[0], b[1], b[2], w);
+        words[i] = ok ? w : 0u;
+        if (exact) exact[i] = ok ? 1 : 0;
+    }
+    return TEXIR_OK;
+}
+
+int texir_texel_unpack(const uint32_t* words, int64_t n, float* rgb)
+{
+    if ((!rgb || !words) && n > 0) return fail(TEXIR_ERR_INVALID, "texir_texel_unpack: null argument");
+    for (int64_t i = 0; i < n; i++) {
+        const uint32_t q = words[i], sb = (q >> 1) & 0x7F800000u;
+        float scale; std::memcpy(&scale, &sb, 4);
+        for (int c = 0; c < 3; c++) rgb[3 * i + c] = (float)((q >> (8 * c)) & 0xFFu) * scale;
+    }
     return TEXIR_OK;
 }
 

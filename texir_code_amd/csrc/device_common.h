@@ -21,7 +21,8 @@ struct SceneDev {
     const float4* uvs;     // GpuTriUV as 2 x float4
     const float* tex;      // [Ht,Wt,3] row-major (layout 0), or the retiled copy the hit shader reads (layouts 1, 2: see shade_hit)
     int Ht, Wt;
-    int tex_layout;        // 0 row-major; 1 = 8x8-texel tiles of 12-byte texels; 2 = overlapping 3x3 tiles at stride 2, one 128-byte line each
+    int tex_layout;        // 0 row-major; 1 = 8x8-texel tiles of 12-byte texels; 2 = overlapping 3x3 tiles at stride 2, one 128-byte line each;
+                           // 3, 4 = 4-byte shared-exponent texels (pack_texel), overlapping 5x5 tiles at stride 4 / 8x4 tiles at stride 7x3, one line each
     int tiles_x;           // tiles per tile row (layouts 1, 2)
     int sched_weight;      // phase scheduler of trace_closest: weight of the lanes at inner nodes (2; 1 for scenes whose node steps run less than ~60 % full: texir_scene_tune measures it once per scene)
 };
@@ -125,6 +126,50 @@ __device__ __forceinline__ void tri_uvs(const SceneDev& sc, int slot, float4& a,
 __device__ __forceinline__ uint32_t tri_prim(const SceneDev& sc, int slot) { return __float_as_uint(sc.tris[3 * (size_t)slot].w); }
 
 // ------------------------------------------------------------------------------------------------
+// 4-byte texels (texture layouts 3, 4).  The reference's radiance texture is an RGBE file times 2^hdr_exposure
+// (tracer_o3d_irt.py:77-81): every texel is three 8-bit integers times ONE power of two.  Such a texel is stored as
+// m_r | m_g << 8 | m_b << 16 | E << 24 with value_c = m_c * 2^(E - 127) -- E is the float exponent field of the scale itself, so the decode
+// is one shift + mask for the scale, v_cvt_f32_ubyte{0,1,2} and three multiplications by a power of two: the IDENTICAL float32 values
+// (m <= 255 times a normal power of two is exact), hence bit-identical bilinear sums.  pack_texel says whether a float triple has this form.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ bool pack_texel(uint32_t br, uint32_t bg, uint32_t bb, uint32_t& word)
+{
+    const uint32_t b[3] = {br, bg, bb};
+    int t[3]; uint32_t odd[3];
+    int k = 1 << 30;
+    for (int c = 0; c < 3; c++) {
+        if (b[c] == 0u) { t[c] = 1 << 30; odd[c] = 0u; continue; }           // +0.0
+        const uint32_t ex = b[c] >> 23;                                       // sign bit set -> ex > 254 below
+        if (ex < 1u || ex > 254u) return false;                               // negative (incl. -0.0), subnormal, inf, nan
+        uint32_t m = (b[c] & 0x7FFFFFu) | 0x800000u;
+        int tz = 0;
+        while (!(m & 1u)) { m >>= 1; tz++; }                                  // <= 23 rounds
+        odd[c] = m; t[c] = (int)ex - 150 + tz;                                // value = odd * 2^t
+        k = t[c] < k ? t[c] : k;
+    }
+    if (k == (1 << 30)) { word = 0u; return true; }                           // black texel
+    const int E = k + 127;
+    if (E < 1 || E > 254) return false;
+    uint32_t w = (uint32_t)E << 24;
+    for (int c = 0; c < 3; c++) {
+        if (odd[c] == 0u) continue;
+        const int sh = t[c] - k;
+        if (sh > 7) return false;
+        const uint32_t m = odd[c] << sh;
+        if (m > 255u) return false;
+        w |= m << (8 * c);
+    }
+    word = w;
+    return true;
+}
+
+__device__ __forceinline__ void unpack_texel(uint32_t q, float& r, float& g, float& b)
+{
+    const float scale = __uint_as_float((q >> 1) & 0x7F800000u);
+    r = (float)(q & 0xFFu) * scale; g = (float)((q >> 8) & 0xFFu) * scale; b = (float)((q >> 16) & 0xFFu) * scale;
+}
+
+// ------------------------------------------------------------------------------------------------
 // hit shader: query_irf post-intersection math (tracer_o3d_irt.py:248-267)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void shade_hit(const SceneDev& sc, int tri_slot, float bu, float bv, float* rgb)
@@ -151,6 +196,31 @@ __device__ __forceinline__ void shade_hit(const SceneDev& sc, int tri_slot, floa
     // Where the four taps live.  The values read are the same in every layout (the retiled copies hold the identical floats), so
     // the result is bit-identical; what changes is how many 128-byte lines a fetch touches: row-major 2 rows 12*Wt bytes apart
     // (2.4 lines on average), layout 2 exactly one line (any 2x2 footprint lies inside the 3x3 tile of (x0/2, y0/2)).
+    if (sc.tex_layout >= 3) {
+        // one 128-byte line of 4-byte texels holds the whole footprint: two adjacent-dword loads
+        const uint32_t* t;
+        int pitch;
+        if (sc.tex_layout == 3) {
+            t = (const uint32_t*)sc.tex + ((size_t)(y0 >> 2) * sc.tiles_x + (x0 >> 2)) * 32 + ((y0 & 3) * 5 + (x0 & 3));
+            pitch = 5;
+        } else {
+            const int tx = (int)__umulhi((uint32_t)x0, 0x24924925u), ty = (int)__umulhi((uint32_t)y0, 0x55555556u);      // x0 / 7, y0 / 3 (exact below 2^17; the host checks the size)
+            t = (const uint32_t*)sc.tex + ((size_t)ty * sc.tiles_x + tx) * 32 + ((y0 - 3 * ty) * 8 + (x0 - 7 * tx));
+            pitch = 8;
+        }
+        const uint32_t q00 = t[0], q10 = t[1], q01 = t[pitch], q11 = t[pitch + 1];
+        float a[3], b[3], c[3], d[3];
+        unpack_texel(q00, a[0], a[1], a[2]); unpack_texel(q10, b[0], b[1], b[2]);
+        unpack_texel(q01, c[0], c[1], c[2]); unpack_texel(q11, d[0], d[1], d[2]);
+        for (int ch = 0; ch < 3; ch++) {
+            float acc = a[ch] * w00;
+            acc += b[ch] * w10;
+            acc += c[ch] * w01;
+            acc += d[ch] * w11;
+            rgb[ch] = acc;
+        }
+        return;
+    }
     const float *p00, *p10, *p01, *p11;
     if (sc.tex_layout == 2) {
         const float* t = sc.tex + ((size_t)(y0 >> 1) * sc.tiles_x + (x0 >> 1)) * 32 + ((y0 & 1) * 3 + (x0 & 1)) * 3;

@@ -19,7 +19,7 @@ static Env parse()
     v.bvh_width = geti("TEXIR_BVH_WIDTH", 4);
     v.bvh_layout = std::min(3, std::max(0, geti("TEXIR_BVH_LAYOUT", 0)));
     v.uniform_float = geti("TEXIR_UNIFORM_FLOAT", 1) != 0;
-    v.tex_layout = geti("TEXIR_TEX_LAYOUT", 2);
+    v.tex_layout = geti("TEXIR_TEX_LAYOUT", 4);
     const int w = geti("TEXIR_SCHED_WEIGHT", 0);
     v.sched_weight = (w >= 1 && w <= 4) ? w : 0;
     v.mip_per_level = geti("TEXIR_MIP_PER_LEVEL", 0) != 0;

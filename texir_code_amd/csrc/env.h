@@ -8,7 +8,7 @@ struct Env {
     int bvh_width;             // TEXIR_BVH_WIDTH            4 (default) | 2 = binary tree only
     int bvh_layout;            // TEXIR_BVH_LAYOUT           0 depth-first | 1 sibling blocks | 2, 3 treelets (bvh_build.cpp relayout4)
     int uniform_float;         // TEXIR_UNIFORM_FLOAT        1 (default) | 0 = scenes without the float node copy (every node step per lane)
-    int tex_layout;            // TEXIR_TEX_LAYOUT           2 (default) | 1 | 0: radiance-texture layout read by the hit shader
+    int tex_layout;            // TEXIR_TEX_LAYOUT           4 (default) | 3: 4-byte texels when the texture packs exactly, else 2; 2 | 1 | 0 force the float32 layouts
     int sched_weight;          // TEXIR_SCHED_WEIGHT         0 (default: measured per scene by texir_scene_tune) | 1 | 2 forced
     int mip_per_level;         // TEXIR_MIP_PER_LEVEL        0 | 1 = one launch per mip level (reference form kept for the parity tests)
     int adam_scalar;           // TEXIR_ADAM_SCALAR          0 | 1 = scalar Adam kernel (reference form kept for the parity tests)

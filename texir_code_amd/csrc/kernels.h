@@ -18,6 +18,8 @@ IrtPlan irt_plan(const SceneDev& sc, int64_t n_ids, int N);      // the kernel f
 hipError_t launch_prefetch(const void* p, size_t bytes, int blocks, uint32_t* sink, hipStream_t st);
 size_t tex_retile_bytes(int Ht, int Wt, int layout, int* tiles_x, int* tiles_y);
 hipError_t launch_tex_retile(const float* src_row_major, float* dst, int Ht, int Wt, int layout, hipStream_t st);
+size_t tex_pack_bytes(int Ht, int Wt, int layout, int* tiles_x, int* tiles_y);          // layouts 3, 4 (4-byte shared-exponent texels)
+hipError_t launch_tex_pack(const float* src_row_major, uint32_t* dst, int Ht, int Wt, int layout, unsigned int* bad /*dev: texels that do not pack exactly*/, hipStream_t st);
 hipError_t launch_trace_shade(const SceneDev& sc, const float* org, const float* dir, int64_t R, float t_min, float* rad, float* t_hit,
                               uint32_t* prim, float* puv, hipStream_t st);
 hipError_t launch_gen_dir(const float* normals, const float* rough, const float* shift, int64_t b, int N, int mode, float* L, hipStream_t st);

@@ -431,6 +431,50 @@ __global__ __launch_bounds__(256) void tex_retile_kernel(const float* __restrict
     }
 }
 
+// Layouts 3, 4: 4-byte shared-exponent texels (device_common.h pack_texel) in overlapping tiles of one 128-byte line each -- 5x5 texels at stride 4
+// (25 of 32 words used) or 8x4 texels at stride 7x3 -- so that every 2x2 bilinear footprint lies inside ONE line.  `bad` counts the texels that are
+// NOT three 8-bit integers times one power of two (the caller then keeps the float32 layout 2): the packed copy is only ever used when it decodes
+// to the identical floats.
+__global__ __launch_bounds__(256) void tex_pack_kernel(const float* __restrict__ src, uint32_t* __restrict__ dst, int Ht, int Wt, int layout, int tiles_x, int tiles_y,
+                                                       unsigned int* __restrict__ bad)
+{
+    const int tw = layout == 3 ? 5 : 8, th = layout == 3 ? 5 : 4, sx = tw - 1, sy = th - 1;
+    const int64_t n = (int64_t)tiles_x * tiles_y * 32;
+    unsigned int nbad = 0;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int64_t tile = e >> 5; const int f = (int)(e & 31);
+        uint32_t w = 0u;
+        if (f < tw * th) {
+            const int ty = (int)(tile / tiles_x), tx = (int)(tile - (int64_t)ty * tiles_x);
+            const int r = f / tw, c = f - r * tw;
+            const int y = min(sy * ty + r, Ht - 1), x = min(sx * tx + c, Wt - 1);
+            const float* p = src + ((size_t)y * Wt + x) * 3;
+            if (!pack_texel(__float_as_uint(p[0]), __float_as_uint(p[1]), __float_as_uint(p[2]), w)) { nbad++; w = 0u; }
+        }
+        dst[e] = w;
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
+size_t tex_pack_bytes(int Ht, int Wt, int layout, int* tiles_x, int* tiles_y)
+{
+    if (layout == 3) { *tiles_x = (Wt - 1) / 4 + 1; *tiles_y = (Ht - 1) / 4 + 1; }
+    else if (layout == 4) { *tiles_x = (Wt - 1) / 7 + 1; *tiles_y = (Ht - 1) / 3 + 1; }
+    else { *tiles_x = *tiles_y = 0; return 0; }
+    return (size_t)*tiles_x * *tiles_y * 128;
+}
+
+hipError_t launch_tex_pack(const float* src, uint32_t* dst, int Ht, int Wt, int layout, unsigned int* bad, hipStream_t st)
+{
+    int tx, ty;
+    const size_t bytes = tex_pack_bytes(Ht, Wt, layout, &tx, &ty);
+    if (!bytes) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(bad, 0, sizeof(unsigned int), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tex_pack_kernel, dim3(grid_for_static(256, (int64_t)(bytes / 4))), dim3(256), 0, st, src, dst, Ht, Wt, layout, tx, ty, bad);
+    return hipGetLastError();
+}
+
 // Streams `n16` 16-byte words through the memory hierarchy and keeps nothing: after a kernel that has flushed the caches (the 1.8 GB stream of the
 // fused Adam), this brings the traversal data back into the memory-side Infinity Cache before the latency-bound specular trace starts.
 __global__ __launch_bounds__(256) void prefetch_kernel(const uint4* __restrict__ p, size_t n16, uint32_t* __restrict__ sink)

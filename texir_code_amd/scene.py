@@ -77,7 +77,15 @@ class Scene:
         sch = np.zeros(2, np.float64)
         _lib.check(_lib.lib().texir_scene_scheduler(self.h, _lib.ptr(sch)))
         d["sched_weight"], d["node_step_fill"] = int(sch[0]), (None if sch[1] < 0 else round(float(sch[1]), 4))
+        d["tex_layout"] = self.texture_layout()
         return d
+
+    def texture_layout(self):
+        """layout of the hit shader's texture copy in force: 3 / 4 = 4-byte shared-exponent texels (the texture packs exactly: an RGBE file times a power
+        of two), 2 / 1 / 0 = float32 (include/texir_hip.h texir_scene_texture_layout)"""
+        out = np.zeros(1, np.int32)
+        _lib.check(_lib.lib().texir_scene_texture_layout(self.h, _lib.ptr(out)))
+        return int(out[0])
 
     def reserve_irt_scratch(self, n_ids, n_samples):
         """before RECORDING irt_generate over n_ids listed texels into a hipGraph: reserve the partial-sum scratch the recorded launch will use (a recorded

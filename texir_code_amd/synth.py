@@ -477,6 +477,14 @@ def make_hdr_texture(sc, res, seed=666):
     return hdr
 
 
+def rgbe_born(hdr, exposure=5.0):
+    """the texture as the reference's pipeline would hold it: `hdr * 2^-exposure` written to hdr_texture.hdr (RGBE), read back and multiplied by
+    2^exposure (tracer_o3d_irt.py:77-81) -- every texel three 8-bit integers times one power of two"""
+    from .io_formats import rgbe_decode_py, rgbe_encode_py
+    s = np.float32(2.0 ** exposure)
+    return (rgbe_decode_py(rgbe_encode_py(np.asarray(hdr, np.float32) / s)) * s).astype(np.float32)
+
+
 def make_texel_gbuffer(sc, res):
     """pos [res,res,3] (= surface + 1e-2*n_geo, tracer_o3d_irt.py:110), nrm [res,res,3] (= n_geo),
     valid [res,res] u8.  Invalid texels are all-zero (seams, tracer_o3d_irt.py:137-139)."""
