@@ -33,7 +33,18 @@ def _bounded_host_threads():
     torch.set_num_threads(before)
 
 
-def _world(golden, c, ra, rr, seed=11):
+def _smooth_radiance(res, seed=5):
+    """a radiance texture without step edges: a low-pass random field, 0.5 x (1 +- 0.2) per channel, the same statistics over the whole atlas.
+    The radiance a specular ray returns is then continuous in its direction up to the 40 % a chart border can jump -- not the three orders of magnitude of a lamp edge
+    -- so a ray falling on the other side of an edge in the product than in the oracle moves a gradient by ~1e-5 of its norm, and NO texel needs setting aside."""
+    rng = np.random.default_rng(seed)
+    n = res // 16 + 2
+    coarse = torch.from_numpy(rng.uniform(-1.0, 1.0, (1, 3, n, n)).astype(np.float32))
+    field = torch.nn.functional.interpolate(coarse, size=(res, res), mode="bicubic", align_corners=True)[0].permute(1, 2, 0)
+    return (0.5 * (1.0 + 0.2 * field.clamp(-1.0, 1.0))).contiguous().numpy()
+
+
+def _world(golden, c, ra, rr, seed=11, smooth=False, view_keys=("v0", "v1")):
     from oracle import mat_step as MS, oracle as O
     from texir_code_amd import cameras, conf as C, gbuffer as GB
     from texir_code_amd.models import MaterialModel
@@ -41,6 +52,8 @@ def _world(golden, c, ra, rr, seed=11):
     from texir_code_amd.trainer.train_material import build_masks
     g = golden("irt_room.npz")
     verts, tris, tri_uvs, hdr = g["verts"], g["tris"], g["tri_uvs"], g["hdr"]
+    if smooth:
+        hdr = _smooth_radiance(hdr.shape[0])
     rng = np.random.default_rng(seed)
     fn = np.cross(verts[tris[:, 1]] - verts[tris[:, 0]], verts[tris[:, 2]] - verts[tris[:, 0]])
     fn /= np.maximum(np.linalg.norm(fn, axis=-1, keepdims=True), 1e-20)
@@ -62,6 +75,8 @@ def _world(golden, c, ra, rr, seed=11):
     oracle._gb = _OGB.setdefault((c, seed), {})
     views = {}
     for key, E in (("v0", cameras.grid_cameras(2)[0]), ("v1", cameras.grid_cameras(2)[3])):
+        if key not in view_keys:
+            continue
         mvp, cam = cameras.cube_mvps(E)
         gb = m._gbuffer(mvp, key)
         ogb = oracle.gbuffer(key, mvp.numpy())
@@ -80,7 +95,20 @@ def _world(golden, c, ra, rr, seed=11):
         room = room * (~drop).float()
         gmask = gmask * (~drop).float()
         views[key] = dict(mvp=mvp, cam=cam, gt=gt, gmask=gmask, seg=seg, fm=fm, room=room, differ=int((~same).sum()))
+    m._test_radiance_ratio = float(hdr.max() / np.median(hdr))           # lamp over base radiance (the edge scene: ~3600; the smooth scene: ~1.2)
     return m, oracle, views
+
+
+def _deviating(got, ref, S=16, ratio=1.0):
+    """the texels that `_rel_l2_but_few` sets aside, bounded one by one (VERDICT r5 next #3 / ADVICE r5): `count` = texels whose deviation exceeds 1e-3 of the LARGEST
+    per-texel gradient, `worst` = the largest of THOSE deviations (0 when there is none) in units of what ONE specular sample crossing a lamp edge can add to a texel's
+    gradient: the radiance jump (lamp over base = `ratio`) times one sample's weight (1 / S) times the rms per-texel gradient of the view's support"""
+    d = (np.asarray(got, np.float64) - np.asarray(ref, np.float64)).reshape(-1, got.shape[-1])
+    r = np.asarray(ref, np.float64).reshape(-1, got.shape[-1])
+    dev, mag = np.sqrt((d ** 2).sum(-1)), np.sqrt((r ** 2).sum(-1))
+    out = dev > 1e-3 * mag.max()
+    unit = ratio / S * np.sqrt((mag[mag > 0] ** 2).mean())
+    return int(out.sum()), (float(dev[out].max() / unit) if out.any() else 0.0)
 
 
 def _rel_l2_but_few(got, ref, frac=5e-4, at_least=8):
@@ -127,7 +155,7 @@ def test_material_step_gradients_match_composite_torch_oracle(golden, ra, rr):
     m, oracle, views = _world(golden, c, ra, rr)
     loss_fn = RenderLoss("L1", 1, lazy_item=True)
     gen = torch.Generator().manual_seed(3)
-    worst = {}
+    worst, devs = {}, {}
     for stage in (0, 1, 2):
         opt = _fresh_optimizer(m, stage)
         oracle.make_optimizer(stage, LR)
@@ -155,13 +183,75 @@ def test_material_step_gradients_match_composite_torch_oracle(golden, ra, rr):
                 e = _rel_l2_but_few(got, ref)
                 worst[(stage, name)] = max(worst.get((stage, name), 0.0), e)
                 assert e < 1e-3, (stage, key, name, e, rel_l2(got, ref))
-                assert rel_l2(got, ref) < 0.5, (stage, key, name)            # (and the excluded texels are a bounded part of the whole)
+                # the texels set aside are FEW and each one is at most what one edge-crossing sample can do (a localized bug -- an atlas border, a tap wrap, a seam --
+                # moves dozens of texels by their own magnitude, or a few by more than a single sample's worth)
+                count, worst_dev = _deviating(got, ref, 16, m._test_radiance_ratio)
+                devs[(stage, name)] = (max(devs.get((stage, name), (0, 0.0))[0], count), max(devs.get((stage, name), (0, 0.0))[1], worst_dev))
+                assert count <= 12 and worst_dev <= 1.0, (stage, key, name, count, worst_dev, rel_l2(got, ref))
                 assert ((got != 0) == (ref != 0)).mean() > 0.99          # same support: the texels the view's taps touch
-    print("composite material-step gradients vs torch oracle (%d^2 / %d^2 textures), worst rel-L2 per (stage, texture): %s"
-          % (ra, rr, {k: "%.1e" % e for k, e in sorted(worst.items())}))
+    print("composite material-step gradients vs torch oracle (%d^2 / %d^2 textures), worst rel-L2 per (stage, texture): %s; texels set aside (count, worst in single-sample units): %s"
+          % (ra, rr, {k: "%.1e" % e for k, e in sorted(worst.items())}, {k: "%d, %.2g" % v for k, v in sorted(devs.items())}))
     # observed on MI355X (256^2 / 512^2): albedo 1e-5, roughness 1e-4 (stage 2) / 4e-4 (stage 1: d/d roughness of the GGX weights in float32 dual numbers
     # against float32 autograd, on lighting traced by two different tracers)
     assert max(worst.values()) < 6e-4
+
+
+def _untrimmed_gradients(m, oracle, views, c, stages, bound, seed=3):
+    """d loss / d materials of one eager step per (stage, view) against the oracle's autograd: PLAIN relative L2 over every texel, nothing set aside"""
+    from texir_code_amd.loss import RenderLoss
+    loss_fn = RenderLoss("L1", 1, lazy_item=True)
+    gen = torch.Generator().manual_seed(seed)
+    worst = {}
+    for stage in stages:
+        opt = _fresh_optimizer(m, stage)
+        oracle.make_optimizer(stage, LR)
+        for key, v in views.items():
+            assert v["differ"] <= 0.005 * 6 * c * c, v["differ"]
+            shift = torch.rand(6 * c * c, 2, generator=gen)
+            d = _cu(v)
+            m._static_shift = shift.cuda()
+            try:
+                preds = m(v["mvp"], key, d["cam"], stage)
+            finally:
+                m._static_shift = None
+            loss = loss_fn(d["gt"], preds, d["gmask"], d["fm"], d["seg"], stage=stage, room_seg_mask=d["room"] if stage == 2 else None)[0]
+            opt.zero_grad()
+            loss.backward()
+            ga = opt.dense_grad(m.materials_a).cpu().numpy() if m.materials_a.requires_grad else None
+            gr = opt.dense_grad(m.materials_r).cpu().numpy() if m.materials_r.requires_grad else None
+            opt.zero_grad()
+            lo, oa, orr = oracle.grads(key, v["mvp"].numpy(), v["cam"], stage, shift.numpy(), v["gt"], v["gmask"], v["fm"], v["seg"], v["room"])
+            assert abs(float(loss.detach()) - lo) < 1e-4 * max(1.0, abs(lo)), (stage, key, float(loss.detach()), lo)
+            for name, got, ref in (("a", ga, oa.numpy()), ("r", gr, orr.numpy())):
+                if got is None:
+                    continue
+                assert np.abs(ref).max() > 0, (stage, key, name)
+                e = rel_l2(got, ref)
+                worst[(stage, name)] = max(worst.get((stage, name), 0.0), e)
+                assert e < bound, (stage, key, name, e)                     # north_star: material-step grads within 1e-3, every texel counted
+                assert ((got != 0) == (ref != 0)).mean() > 0.99
+    return worst
+
+
+@pytest.mark.parametrize("ra,rr", [(256, 512), (64, 128)])
+def test_material_step_gradients_untrimmed_on_smooth_radiance(golden, ra, rr):
+    """the same composite step on a scene whose radiance texture has no step edges -- plain rel-L2 < 1e-3 on d albedo / d roughness for stages
+    0 / 1 / 2, both views, with NO texel set aside (mat_nvdiffrast.py:131-139,234-241; loss.py:81-115)"""
+    c = 32
+    m, oracle, views = _world(golden, c, ra, rr, smooth=True)
+    assert m._test_radiance_ratio < 1.5
+    worst = _untrimmed_gradients(m, oracle, views, c, (0, 1, 2), 1e-3)
+    print("composite material-step gradients vs torch oracle, smooth radiance, UNTRIMMED (%d^2 / %d^2 textures): %s" % (ra, rr, {k: "%.1e" % e for k, e in sorted(worst.items())}))
+
+
+def test_material_step_gradients_untrimmed_at_4k_textures(golden):
+    """the composite oracle at the C3 texture size (BASELINE.json configs[2]: 4096^2 albedo / roughness; the torch oracle's mip stacks are ~270 + 90 MB): one 6 x 32^2 view,
+    stages 1 and 2, plain rel-L2 over all 16.8 M texels.  At this size a pixel's footprint spans ~2^5 texels: the taps sit on mip levels 4-6 and the level-0
+    gradient is what the deferred folds spread out of them -- the part of the backward no smaller oracle run exercises"""
+    c = 32
+    m, oracle, views = _world(golden, c, 4096, 4096, smooth=True, view_keys=("v0",))
+    worst = _untrimmed_gradients(m, oracle, views, c, (1, 2), 1e-3)
+    print("composite material-step gradients vs torch oracle at 4096^2 / 4096^2 textures, UNTRIMMED: %s" % {k: "%.1e" % e for k, e in sorted(worst.items())})
 
 
 @pytest.mark.parametrize("ra,rr", [(256, 512), (64, 128)])

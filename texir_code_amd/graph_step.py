@@ -6,7 +6,44 @@ device-resident step counts and ONE fused Adam launch over both textures
 (optim.FusedAdam keeps step count and learning rate in device memory, so no kernel argument changes from replay to replay).  The per-step GGX shifts still come from the CPU generator exactly as the reference draws them
 (utils/sample_util.py:102) -- they are copied into a static device buffer the captured kernels read.
 Multi-GPU runs (a gradient all-reduce between backward and step) keep the optimiser step outside the graph (step_in_graph=False)."""
+import queue
+import threading
+
 import torch
+
+
+class _DrawWorker:
+    """ONE helper thread that runs the host-side draw of the NEXT step's GGX shifts (the CPU generator's 196 608 floats: 0.4-0.5 ms, as long as a whole material
+    step on the GPU) while the main thread reports the current step.  Requests are executed one at a time in submission order and every request is awaited
+    before anything else may touch the global generator, so the generator's stream is consumed in exactly the order of the reference's loop
+    (utils/sample_util.py:102); torch.rand releases the GIL while it runs.  The thread makes no HIP call (a foreign thread inside the HIP runtime would
+    invalidate a stream capture)."""
+
+    def __init__(self):
+        self.q = queue.SimpleQueue()
+        self.thread = threading.Thread(target=self._run, name="texir-shift-draw", daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        torch.set_num_threads(1)
+        while True:
+            job = self.q.get()
+            if job is None:
+                return
+            fn, done, err = job
+            try:
+                fn()
+            except BaseException as e:          # surfaces in wait()
+                err.append(e)
+            done.set()
+
+    def submit(self, fn):
+        done, err = threading.Event(), []
+        self.q.put((fn, done, err))
+        return done, err
+
+    def close(self):
+        self.q.put(None)
 
 
 class GraphedMatStep:
@@ -66,8 +103,7 @@ class GraphedMatStep:
     def capture(self, key, mvp, cam, gt, gmask, seg, fm, room, stage):
         """inputs must be device tensors (they are kept alive with the graph, self.inputs: the recorded kernels read them by address); one graph per
         (view key, stage)"""
-        from .plot_writer import quiesce
-        quiesce()                                       # no worker thread may touch the HIP runtime while a stream is being captured
+        from .plot_writer import capture_gate           # no worker thread may touch the HIP runtime while a stream is being captured
         P = gt.shape[0] * gt.shape[1] * gt.shape[2]
         if self.static_shift is None:
             self.static_shift = torch.zeros((P, 2), device=gt.device)
@@ -85,13 +121,15 @@ class GraphedMatStep:
         from .scene import defer_destroy
         # finalisers (hipFree of dead scenes / tensors) must not run inside a capture: the collector is switched off for its duration; a full collection
         # beforehand is only worth its 20-50 ms once per step object (a stage captures one graph per view: 16-500 of them back to back)
+        # (round 6: a FULL collection cost 127 ms per step object on the c4 run -- the interpreter holds millions of long-lived objects by then; the young
+        # generation is where a dead scene or tensor cycle of the preceding stage sits, and collecting it costs microseconds)
         if not getattr(self, "_collected_once", False):
-            gc.collect()
+            gc.collect(0)
             self._collected_once = True
         gc_was = gc.isenabled()
         gc.disable()
         try:
-            with defer_destroy():
+            with defer_destroy(), capture_gate():
                 self.side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self.side):
                     g = torch.cuda.CUDAGraph()
@@ -132,6 +170,43 @@ class GraphedMatStep:
         P = self.static_shift.shape[0]
         return torch.rand(P, 1, 2).reshape(P, 2)
 
+    def request_shift(self, key):
+        """draw the NEXT step's shifts for view `key` on the helper thread, straight into the pinned buffer that view's recorded kernels read (zero-copy mode);
+        wait_shift() must be called before the step is launched -- and before anything else draws from the global CPU generator.  Returns False (nothing
+        requested) where the direct form does not apply."""
+        if not self.zero_copy or key not in self.shift_bufs:
+            return False
+        self.wait_shift()
+        buf, ev, pending = self.shift_bufs[key]
+        if pending:
+            ev.synchronize()                 # (main thread: the previous replay of this view -- an epoch ago -- has finished reading the buffer)
+            self.shift_bufs[key][2] = False
+        if getattr(self, "_worker", None) is None:
+            self._worker = _DrawWorker()
+        P = buf.shape[0]
+        self._pending_draw = self._worker.submit(lambda: torch.rand(P, 1, 2, out=buf.view(P, 1, 2)))
+        return True
+
+    def wait_shift(self):
+        pd = getattr(self, "_pending_draw", None)
+        if pd is not None:
+            self._pending_draw = None
+            pd[0].wait()
+            if pd[1]:
+                raise pd[1][0]
+
+    def close(self):
+        self.wait_shift()
+        if getattr(self, "_worker", None) is not None:
+            self._worker.close()
+            self._worker = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def stage_shift(self, key, shift):
         """write the shifts of the NEXT step on view `key` where its recorded kernels will read them.  Callers that know the next view may call
         this right after launching a step (then pass staged=True to step()): the host-side copy then overlaps the GPU work."""
@@ -164,6 +239,7 @@ class GraphedMatStep:
     def step(self, key, stage, reduce_grads=None, shift=None, staged=False):
         """one optimiser step on a captured view; returns the (static) loss tensor of that graph.  staged=True: the caller has already put
         this step's shifts in place (stage_shift)"""
+        self.wait_shift()                               # (a draw requested for this step has landed; nothing else may be in flight on the generator)
         if stage != 0 and not staged:                   # stage 0 is Lambertian only: the reference draws no shifts there
             if shift is None:
                 shift = self.draw_shift()

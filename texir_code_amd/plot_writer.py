@@ -21,11 +21,27 @@ from . import io_formats as IO
 _LIVE = None          # weak set of the writers with a worker thread
 
 
+_GATE = threading.Lock()          # held by a worker around its HIP calls, and by a stream capture for its whole duration
+
+
+class capture_gate:
+    """`with capture_gate():` around a hipGraph capture (graph_step / sharded_step).  While a stream is being captured in the default (global) mode, a HIP call
+    from ANY thread -- the worker's hipEventSynchronize on its device -> host copy, or the event the caching allocator records when the worker drops the
+    device snapshot -- is an error that also invalidates the capture (seen in round 5: the stage-1 captures right behind the epoch-0 plot fell back to eager
+    steps).  Round 5 waited for the writer's whole queue (encode + write, ~0.1 s per plot at 4096^2: 0.27 s of the 40-epoch c4 stage); the gate only keeps the
+    worker's two HIP-touching lines out of the capture -- its encode and its write run on while graphs are being recorded."""
+
+    def __enter__(self):
+        _GATE.acquire()
+        return self
+
+    def __exit__(self, *exc):
+        _GATE.release()
+        return False
+
+
 def quiesce():
-    """wait until no writer has anything in flight.  Called before a hipGraph capture (graph_step / sharded_step): while a stream is being captured in the
-    default (global) mode, a hipEventSynchronize from ANY thread -- the worker waiting for its device -> host copy -- is an error that also invalidates the
-    capture (seen in round 5: the stage-1 captures right behind the epoch-0 plot fell back to eager steps).  Captures happen in the first epoch of a stage
-    only, so the wait (one encode + write, ~0.1 s at 4096^2) is paid at most once per stage."""
+    """wait until no writer has anything in flight (kept for callers that want the files on disk; captures use capture_gate)"""
     if _LIVE:
         for w in list(_LIVE):
             w._q.join()            # (wait only: a failed write is reported by the writer's own flush() / close(), not disguised as a failed capture)
@@ -61,10 +77,12 @@ class AsyncPlotWriter:
                 self._q.task_done()
                 return
             path, host, ev, repeat3, snap = job
+            job = None
             try:
-                if ev is not None:
-                    ev.synchronize()
-                del snap
+                with _GATE:                     # (never inside a stream capture: capture_gate)
+                    if ev is not None:
+                        ev.synchronize()
+                    snap = None                 # the device snapshot goes back to the allocator here
                 a = host.numpy()
                 if repeat3:
                     a = np.repeat(a, 3, axis=2)

@@ -154,8 +154,7 @@ class ShardedMatStep:
     # ---- set-up -----------------------------------------------------------------------------------------------------------------------------
     def capture(self, key, mvp, cam, gt, gmask, seg, fm, room, stage):
         """inputs must be device tensors that stay alive; one state (and, with use_graph, three graphs) per (view key, stage)"""
-        from .plot_writer import quiesce
-        quiesce()                                       # no worker thread may touch the HIP runtime while a stream is being captured
+        from .plot_writer import capture_gate           # no worker thread may touch the HIP runtime while a stream is being captured
         if stage == 0:
             raise ValueError("stage 0 has no specular term: run it as the replicated GraphedMatStep (no communication needed)")
         dev = gt.device
@@ -195,7 +194,7 @@ class ShardedMatStep:
         was = gc.isenabled()
         gc.disable()
         try:
-            with defer_destroy():
+            with defer_destroy(), capture_gate():
                 graphs = []
                 for phase in (lambda: self._p1(st), lambda: self._p2(st), lambda: self._p3(st, "record")):
                     self.side.wait_stream(torch.cuda.current_stream())

@@ -100,10 +100,11 @@ class MatTrainRunner(RunnerBase):
         (self.room_meta_scale, self.room_meta_w, self.room_meta_h, self.room_meta_xmin, self.room_meta_zmin, self.room_img) = parse_roomseg(rs)
         self.cur_iter = 0
         self.log = []
-        # new optional key (default 0 = the reference's behaviour: `.item()` + print after every step, i.e. one host synchronisation per step): with
-        # train.log_lag = n the loss values of a step are copied to pinned host memory asynchronously and logged / printed n steps later, so that the
-        # recorded steps are queued back to back (bench.py: 0.63 ms period against 0.64 ms latency per step at 4k textures); same values, same order
-        self.log_lag = max(0, self.conf.get_int("train.log_lag", default=0))
+        # new optional key: with train.log_lag = n the loss values of a step are copied to pinned host memory asynchronously and logged / printed n steps
+        # later, so that the recorded steps are queued back to back; same values, same lines, same order (an epoch's last lines appear before its end).
+        # Default 1 (round 6): the step's line is printed while the NEXT step runs -- the GPU no longer idles through the host's report of every step;
+        # 0 = the reference's own timing: `.item()` + print right after each step, one host synchronisation per step (train_material.py:459-468)
+        self.log_lag = max(0, self.conf.get_int("train.log_lag", default=1))
 
     def _view_inputs(self, gt_item, vid0):
         """device-resident, long-lived inputs of a view (what a recorded step reads)"""
@@ -189,7 +190,8 @@ class MatTrainRunner(RunnerBase):
         vid0 = vid[0] if isinstance(vid, (list, tuple)) else vid
         if (vid0, stage) not in gs.graphs:
             return
-        gs.stage_shift(vid0, gs.draw_shift())
+        if not gs.request_shift(vid0):              # (helper thread, straight into the view's pinned buffer; awaited by GraphedMatStep.step)
+            gs.stage_shift(vid0, gs.draw_shift())
         self._shift_staged_for = (id(gs), vid0, stage)
 
     def _new_optimizer(self):
@@ -294,6 +296,7 @@ class MatTrainRunner(RunnerBase):
         def before_step(epoch, data_index):
             t0[0] = time.time()
 
+        ring, ring_next = [], [0]
         pending = []             # log_lag > 0: (epoch, data_index, pinned [2] buffer, event, seconds the step's launch took)
 
         def report(epoch, data_index, loss_v, seg_v, dt, it):
@@ -319,13 +322,15 @@ class MatTrainRunner(RunnerBase):
             loss, seg_item = out
             if getattr(self, "log_lag", 0) > 0 and torch.is_tensor(loss) and loss.is_cuda:
                 # (a recorded step's loss lives in a static tensor the next replay overwrites: copy it out on the stream, right behind the step)
-                host = torch.empty(2, dtype=torch.float32).pin_memory()
+                if not ring:                     # (lag + 2 pinned pairs and their events, reused round robin: a slot is rewritten only after its line was printed)
+                    ring.extend((torch.empty(2, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(getattr(self, "log_lag", 0) + 2))
+                host, ev = ring[ring_next[0] % len(ring)]
+                ring_next[0] += 1
                 host[0:1].copy_(loss.detach().reshape(1), non_blocking=True)
                 if torch.is_tensor(seg_item):
                     host[1:2].copy_(seg_item.detach().reshape(1).to(torch.float32), non_blocking=True)
                 else:
                     host[1] = float(seg_item)
-                ev = torch.cuda.Event()
                 ev.record()
                 pending.append((epoch, data_index, host, ev, time.time() - t0[0], self.cur_iter - 1))
                 drain(getattr(self, "log_lag", 0))

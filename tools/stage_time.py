@@ -68,7 +68,7 @@ def time_irrt(conf_irt):
     return {"total_s": round(total, 3), "phases_s": ph}
 
 
-def time_mat(conf_mat, exps, epochs, log_lag):
+def time_mat(conf_mat, exps, epochs, log_lag, profile=False):
     import torch
     from texir_code_amd.runlog import phases
     from texir_code_amd.trainer.train_material import MatTrainRunner
@@ -81,7 +81,14 @@ def time_mat(conf_mat, exps, epochs, log_lag):
         runner = MatTrainRunner(conf=conf_mat, exps_folder_name=exps, expname="e2e", frame_skip=1, max_niters=10 ** 9, is_continue=False,
                                 timestamp="latest", checkpoint="latest", gpu_index=0)
         t_init = time.perf_counter() - t0
+        prof = None
+        if profile:                  # where the host time of the step loop goes (VERDICT r5 #4c): cProfile slows the loop ~2x, read the SHARES
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         runner.run()
+        if prof is not None:
+            prof.disable()
     torch.cuda.synchronize()
     total = time.perf_counter() - t0
     ph = phases.report()
@@ -95,14 +102,22 @@ def time_mat(conf_mat, exps, epochs, log_lag):
     steps = len(runner.log)
     plots = [f for f in os.listdir(runner.plots_dir) if f.endswith(".hdr")]
     out = {"total_s": round(total, 3), "init_s": round(t_init, 3), "steps": steps, "plot_files": len(plots), "plot_events": len(plots) // 2,
-           "phases_s": ph, "log_lag": log_lag}
+           "phases_s": ph, "log_lag": runner.log_lag}
     if "plot_submit" in nested and plots:
         out["plot_submit_s_per_event"] = round(nested["plot_submit"] / max(1, len(plots) // 2), 4)
     out["scalars_jsonl"] = os.path.exists(os.path.join(os.path.dirname(runner.plots_dir), "scalars.jsonl"))
+    stage_s = sum(ph.get("stage%d" % k, 0.0) for k in range(3))
+    out["stage_ms_per_step"] = round(1e3 * stage_s / max(1, steps), 4)          # wall time of the three stages over their steps (graph captures, plots, validation included)
+    if prof is not None:
+        import io
+        import pstats
+        buf = io.StringIO()
+        pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(45)
+        out["cprofile_tottime"] = [l.rstrip() for l in buf.getvalue().splitlines() if l.strip()][:60]
     return out
 
 
-def run(workload="c4", root=None, mat_epochs=40, keep=False, style="room", do_mat=True, log_lag=0, pano_flow=True):
+def run(workload="c4", root=None, mat_epochs=40, keep=False, style="room", do_mat=True, log_lag=None, pano_flow=True, profile=False):
     import torch
     from texir_code_amd import conf as C, datasets as D
     made = root is None
@@ -136,7 +151,7 @@ def run(workload="c4", root=None, mat_epochs=40, keep=False, style="room", do_ma
         if do_mat:
             D.write_conf(conf_mat, root, cube_res=cube, spp=(spp, S), albedo_res=mres, rough_res=mres, epochs=mat_epochs, model="mat")
             txt = open(conf_mat).read().replace("plot_freq = 1000", "plot_freq = 10")
-            if log_lag:
+            if log_lag is not None:
                 txt = txt.replace("batch_size = 1", "batch_size = 1\n    log_lag = %d" % log_lag)
             open(conf_mat, "w").write(txt)
             t0 = time.perf_counter()
@@ -144,10 +159,12 @@ def run(workload="c4", root=None, mat_epochs=40, keep=False, style="room", do_ma
                 D.render_gt_views(root, C.parse_file(conf_mat), sc, mres, mres)
             out["gt_views_prep_s"] = round(time.perf_counter() - t0, 2)
             out["mat"] = time_mat(conf_mat, os.path.join(root, "exps"), mat_epochs, log_lag)
-            if not log_lag:
-                # the same stage with the optional conf key train.log_lag = 8: loss values are logged 8 steps late from pinned copies, no host synchronisation per step
-                open(conf_mat, "w").write(txt.replace("batch_size = 1", "batch_size = 1\n    log_lag = 8"))
-                out["mat_log_lag8"] = time_mat(conf_mat, os.path.join(root, "exps_lag8"), mat_epochs, 8)
+            if profile:
+                out["mat_profiled"] = time_mat(conf_mat, os.path.join(root, "exps_prof"), mat_epochs, log_lag, profile=True)
+            if log_lag is None:
+                # the same stage with train.log_lag = 0: `.item()` + print right after every step, the reference's own timing (one host synchronisation per step)
+                open(conf_mat, "w").write(txt.replace("batch_size = 1", "batch_size = 1\n    log_lag = 0"))
+                out["mat_log_lag0"] = time_mat(conf_mat, os.path.join(root, "exps_lag0"), mat_epochs, 0)
     finally:
         if made and not keep:
             shutil.rmtree(root, ignore_errors=True)
@@ -161,10 +178,12 @@ def main():
     ap.add_argument("--mat-epochs", type=int, default=40)
     ap.add_argument("--style", default="room")
     ap.add_argument("--no-mat", action="store_true")
-    ap.add_argument("--log-lag", type=int, default=0)
+    ap.add_argument("--log-lag", type=int, default=None, help="train.log_lag of the Mat run (default: the product's default, then once more with 0)")
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--profile", action="store_true", help="run the Mat stage once more under cProfile: `mat_profiled.cprofile_tottime`")
+    ap.add_argument("--no-pano", action="store_true", help="skip the IrrT run through the panorama G-buffer flow")
     a = ap.parse_args()
-    print(json.dumps(run(a.workload, a.root, a.mat_epochs, a.keep, a.style, not a.no_mat, a.log_lag)))
+    print(json.dumps(run(a.workload, a.root, a.mat_epochs, a.keep, a.style, not a.no_mat, a.log_lag, not a.no_pano, a.profile)))
 
 
 if __name__ == "__main__":
