@@ -206,6 +206,41 @@ def test_index_texture_path_generate_positions_and_gather(tmp_path):
     assert rel_l2(got[close], ref[close]) < 1e-5
 
 
+def test_index_texture_resize_modes(tmp_path):
+    """train.irt_resize: `reference` resizes 0.png the way the reference's call really does (cv2's default INTER_LINEAR on the uint16 codes,
+    tracer_o3d_irt.py:95), `nearest` (default) picks codes; a 0.png that already has the target size is untouched in both"""
+    from texir_code_amd import conf as C, datasets as D, io_formats as IO
+    from texir_code_amd.imgops import resize_u16_as_cv2_default
+    from texir_code_amd.models import TracerO3d
+    root = str(tmp_path / "ds")
+    D.write_synthetic_dataset(root, T=2000, texel_res=48, tex_res=32, n_side=1)
+    mesh_dir = os.path.join(root, "vrproc", "hdr_texture")
+    rng = np.random.default_rng(2)
+    idx = np.stack([rng.integers(0, 50000, (48, 48)), rng.integers(0, 50000, (48, 48)), rng.integers(0, 2, (48, 48))], -1).astype(np.uint16)
+    IO.write_png(os.path.join(mesh_dir, "0.png"), idx[..., ::-1])
+    conf_p = str(tmp_path / "irt.conf")
+    D.write_conf(conf_p, root, cube_res=16, spp=(64, 16), model="irt")
+    base = open(conf_p).read()
+    ds = D.SynCubeDataset(C.parse_string(base).get_string("train.path_mesh_open3d"), [32, 64], 0.0)
+
+    def index_texture(extra):
+        txt = base.replace("hdr_exposure = 0", "hdr_exposure = 0\n    texel_gbuffer = index\n" + extra)
+        txt = txt if "irt_res" not in base else "\n".join(l for l in txt.splitlines() if "irt_res = native" not in l)
+        return TracerO3d(C.parse_string(txt), ds.ids, ds.extrinsics_list).index_texture
+
+    near = index_texture("    irt_res = 32")
+    assert near.shape == (32, 32, 3) and np.array_equal(near, idx[np.arange(32) * 48 // 32][:, np.arange(32) * 48 // 32])
+    strict = index_texture("    irt_res = 32\n    irt_resize = reference")
+    assert np.array_equal(strict, resize_u16_as_cv2_default(idx, (32, 32))) and not np.array_equal(strict, near)
+    half = index_texture("    irt_res = 24\n    irt_resize = reference")             # exact 2 x 2 reduction: cv2's INTER_AREA fast path
+    s = idx.astype(np.uint32)
+    assert np.array_equal(half, ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint16))
+    for mode in ("nearest", "reference"):
+        assert np.array_equal(index_texture("    irt_res = 48\n    irt_resize = %s" % mode), idx)
+    with pytest.raises(ValueError, match="irt_resize"):
+        index_texture("    irt_res = 32\n    irt_resize = bicubic")
+
+
 @pytest.mark.parametrize("fuse", [False, True])
 def test_graphed_material_step_equals_eager(golden, fuse):
     """hipGraph replay of forward+loss+backward must reproduce the eager step (same shifts, same Adam) -- eight steps queued back to

@@ -73,3 +73,46 @@ def resize_linear(a, size):
     if np.issubdtype(a.dtype, np.integer):
         out = np.clip(np.rint(out), np.iinfo(a.dtype).min, np.iinfo(a.dtype).max).astype(a.dtype)
     return out
+
+
+def resize_u16_as_cv2_default(a, size):
+    """what `cv2.resize(a, (w, h), cv2.INTER_NEAREST)` actually computes for a uint16 image: the third POSITIONAL argument of cv2.resize is `dst`, so the
+    flag is ignored and the interpolation is the default INTER_LINEAR (/root/reference/models/tracer_o3d_irt.py:95 resizes the index texture's row / column /
+    panorama codes this way).  Restated from OpenCV 4.x modules/imgproc/src/resize.cpp (not executable in this image: parity with cv2 itself is unpinned,
+    the arithmetic below is pinned by a hand-computed vector, tests/test_host_cpu.py):
+      * same size: a copy;
+      * an exact 2 x 2 reduction (src = 2 x dst on both axes) is re-routed to INTER_AREA's fast path (`if (interpolation == INTER_LINEAR && is_area_fast &&
+        iscale_x == 2 && iscale_y == 2) interpolation = INTER_AREA`): (a + b + c + d + 2) >> 2 in integers (ResizeAreaFastVec<ushort>);
+      * everything else: CV_16U has no fixed-point path (the 11-bit INTER_RESIZE_COEF table is the 8-bit case only) -- float32 taps,
+        fx = float((dx + 0.5) * scale - 0.5) with scale = 1 / (dst / src) in double, sx = floor(fx), weights (1 - fx, fx) as float32; sx < 0 -> (sx, fx) = (0, 0);
+        sx >= src - 1 -> (src - 1, 0); rows are clamped (border replicate) with the weights kept; horizontal pass first into float32 rows, then the vertical
+        pass, then saturate_cast<ushort> = round half to even (cvRound) and clamp to [0, 65535]."""
+    w, h = int(size[0]), int(size[1])
+    a = np.asarray(a)
+    if a.dtype != np.uint16:
+        raise TypeError("resize_u16_as_cv2_default: uint16 input expected, got %s" % a.dtype)
+    H, W = a.shape[:2]
+    if (H, W) == (h, w):
+        return a.copy()
+    if H == 2 * h and W == 2 * w:
+        s = a.astype(np.uint32)
+        return ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint16)
+
+    def taps(n_dst, n_src, clamp_weights):
+        scale = 1.0 / (float(n_dst) / float(n_src))
+        f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        s0 = np.floor(f).astype(np.int64)
+        f = (f - s0.astype(np.float32)).astype(np.float32)
+        if clamp_weights:                       # the x axis: out-of-range taps get weight 0
+            lo, hi = s0 < 0, s0 >= n_src - 1
+            f = np.where(lo | hi, np.float32(0), f)
+            s0 = np.where(lo, 0, np.where(hi, n_src - 1, s0))
+        return np.clip(s0, 0, n_src - 1), np.clip(s0 + 1, 0, n_src - 1), (np.float32(1) - f).astype(np.float32), f
+
+    x0, x1, ax0, ax1 = taps(w, W, True)
+    y0, y1, by0, by1 = taps(h, H, False)
+    src = a.astype(np.float32)
+    tail = (1,) * (a.ndim - 2)
+    rows = src[:, x0] * ax0.reshape(1, -1, *tail) + src[:, x1] * ax1.reshape(1, -1, *tail)             # [H, w, ...] float32
+    out = rows[y0] * by0.reshape(-1, 1, *tail) + rows[y1] * by1.reshape(-1, 1, *tail)
+    return np.clip(np.rint(out), 0, 65535).astype(np.uint16)

@@ -91,18 +91,30 @@ class TracerO3d(nn.Module):
         self.cube_res = 256
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.scene, self.obj, self.texture = _load_scene(conf, self.device.index)
-        # The reference resizes 0.png to 1024 x 1024 (tracer_o3d_irt.py:95) -- train.irt_res keeps that default size; `native` (or 0) opts
-        # out.  The resize here is NEAREST, the flag the reference passes: its call puts cv2.INTER_NEAREST in the `dst` slot, so it
-        # actually interpolates the uint16 row/col/panorama codes bilinearly -- an accident that is not reproduced.
+        # The reference resizes 0.png to 1024 x 1024 (tracer_o3d_irt.py:95) -- train.irt_res keeps that default size; `native` (or 0) opts out.
+        # train.irt_resize (new optional key):
+        #   nearest (default)  the flag the reference passes -- a true nearest-neighbour pick of the (row, column, panorama) codes;
+        #   reference          what its call computes: cv2.INTER_NEAREST sits in the `dst` slot, so cv2 interpolates the uint16 codes with its default
+        #                      INTER_LINEAR -- blended codes between texels of different panoramas included; identical to `nearest` when 0.png
+        #                      already has the target size, bit-for-bit the reference's texture otherwise (imgops.resize_u16_as_cv2_default).
         with phases.phase("load_index_texture", sync=False):
             idx = IO.read_index_texture(_sibling(self.path_traced_mesh, "0.png"))
         res = conf.get("train.irt_res", 1024)
+        how = str(conf.get("train.irt_resize", "nearest")).lower()
+        if how not in ("nearest", "reference"):
+            raise ValueError("train.irt_resize must be nearest or reference, got %r" % how)
         if res not in (None, 0, "0", "native"):
             res = int(res)
             if (res, res) != idx.shape[:2]:
-                ry = (np.arange(res) * idx.shape[0] // res)
-                rx = (np.arange(res) * idx.shape[1] // res)
-                idx = idx[ry][:, rx]
+                if how == "reference":
+                    from .imgops import resize_u16_as_cv2_default
+                    if idx.dtype != np.uint16:
+                        raise ValueError("train.irt_resize = reference restates cv2's 16-bit path; 0.png is %s" % idx.dtype)
+                    idx = resize_u16_as_cv2_default(np.ascontiguousarray(idx), (res, res))
+                else:
+                    ry = (np.arange(res) * idx.shape[0] // res)
+                    rx = (np.arange(res) * idx.shape[1] // res)
+                    idx = idx[ry][:, rx]
         self.index_texture = np.ascontiguousarray(idx)
         # optional exact texel G-buffer written by the synthetic generator (bypasses the panorama gather)
         self.texel_gbuffer_path = _sibling(self.path_traced_mesh, "texel_gbuffer.npz")
