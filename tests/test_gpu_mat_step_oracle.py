@@ -34,14 +34,14 @@ def _bounded_host_threads():
 
 
 def _smooth_radiance(res, seed=5):
-    """a radiance texture without step edges: a low-pass random field, 0.5 x (1 +- 0.2) per channel, the same statistics over the whole atlas.
-    The radiance a specular ray returns is then continuous in its direction up to the 40 % a chart border can jump -- not the three orders of magnitude of a lamp edge
+    """a radiance texture without step edges: a low-pass random field, 0.5 x (1 +- 0.05) per channel, the same statistics over the whole atlas.
+    The radiance a specular ray returns is then continuous in its direction up to the 10 % a chart border can jump -- not the three orders of magnitude of a lamp edge
     -- so a ray falling on the other side of an edge in the product than in the oracle moves a gradient by ~1e-5 of its norm, and NO texel needs setting aside."""
     rng = np.random.default_rng(seed)
     n = res // 16 + 2
     coarse = torch.from_numpy(rng.uniform(-1.0, 1.0, (1, 3, n, n)).astype(np.float32))
     field = torch.nn.functional.interpolate(coarse, size=(res, res), mode="bicubic", align_corners=True)[0].permute(1, 2, 0)
-    return (0.5 * (1.0 + 0.2 * field.clamp(-1.0, 1.0))).contiguous().numpy()
+    return (0.5 * (1.0 + 0.05 * field.clamp(-1.0, 1.0))).contiguous().numpy()
 
 
 def _world(golden, c, ra, rr, seed=11, smooth=False, view_keys=("v0", "v1")):

@@ -47,16 +47,27 @@ def rgbe_decode(rgbe):
     return out
 
 
-def write_hdr(path, rgb, rle=True):
+def write_hdr(path, rgb, rle=True, scratch=None):
     """rgb [H,W,3] float32, RGB order, row 0 = top.  The file cv2.imwrite(path, rgb[..., ::-1]) writes (trainer/generate_ir_texture.py:82):
-    header "#?RADIANCE / FORMAT=32-bit_rle_rgbe / -Y H +X W", new-style RLE scanlines (cv2's default); rle=False writes flat scanlines."""
+    header "#?RADIANCE / FORMAT=32-bit_rle_rgbe / -Y H +X W", new-style RLE scanlines (cv2's default); rle=False writes flat scanlines.
+    scratch: a dict a repeated caller passes to keep the two encode buffers between calls (plot_writer: allocating and releasing 2 x 67 MB per
+    file means page faults and munmaps of that size under the interpreter lock, which the training loop on the main thread then waits for)."""
     from . import _lib
     rgb = np.ascontiguousarray(rgb, np.float32)
     H, W, _ = rgb.shape
-    body = rgbe_encode(rgb)
+    body = None if scratch is None else scratch.get(("rgbe", H, W))
+    if body is None:
+        body = np.empty((H, W, 4), np.uint8)
+        if scratch is not None:
+            scratch[("rgbe", H, W)] = body
+    _lib.check(_lib.lib().texir_rgbe_encode(_lib.ptr(rgb), rgb.size // 3, _lib.ptr(body)))
     if rle:
         cap = H * (4 + 4 * (W + W // 64 + 4)) + 16
-        buf = np.empty(cap, np.uint8)
+        buf = None if scratch is None else scratch.get(("rle", cap))
+        if buf is None:
+            buf = np.empty(cap, np.uint8)
+            if scratch is not None:
+                scratch[("rle", cap)] = buf
         n = _lib.lib().texir_hdr_encode_rle(_lib.ptr(body), W, H, _lib.ptr(buf), cap)
         if n < 0:
             raise ValueError("%s: RLE encode failed" % path)

@@ -60,6 +60,7 @@ class AsyncPlotWriter:
         self._stream = None
         self._worker = None
         self._errors = []
+        self._wide, self._scratch = {}, {}      # worker-owned buffers kept between plot events (no 67-200 MB allocate / release per file)
         self._pending = threading.Semaphore(max_pending)        # bounds pinned memory: submit() blocks when the disk is that far behind
 
     def _pinned(self, shape, dtype):
@@ -83,10 +84,18 @@ class AsyncPlotWriter:
                     if ev is not None:
                         ev.synchronize()
                     snap = None                 # the device snapshot goes back to the allocator here
-                a = host.numpy()
                 if repeat3:
-                    a = np.repeat(a, 3, axis=2)
-                IO.write_hdr(path, a)
+                    # (torch, not numpy: np.repeat writes its 200 MB at 4096^2 with the interpreter lock held -- a 27 ms stall of the training loop per plot
+                    # event in the round-6 kernel trace; the destination is kept between events for the same reason)
+                    key = (host.shape[0], host.shape[1])
+                    wide = self._wide.get(key)
+                    if wide is None:
+                        wide = self._wide[key] = torch.empty((host.shape[0], host.shape[1], 3), dtype=torch.float32)
+                    wide.copy_(host.expand(-1, -1, 3))
+                    a = wide.numpy()
+                else:
+                    a = host.numpy()
+                IO.write_hdr(path, a, scratch=self._scratch)
             except Exception as e:              # surfaced by flush()
                 self._errors.append((path, e))
             finally:

@@ -347,7 +347,7 @@ class MatTrainRunner(RunnerBase):
                     self._prepare_next_step(next_item, stage)
 
             self.fit(self.train_dataloader, self.start_epoch, self.nepochs, lambda gt_item: self.train_step(gt_item, stage), epoch_begin=epoch_begin,
-                     takes=takes, before_step=before_step, after_step=after_step, epoch_end=lambda epoch: (drain(0), self.mat_scheduler.step()),
+                     takes=takes, before_step=before_step, after_step=after_step, epoch_end=lambda epoch: (drain(getattr(self, "log_lag", 0)), self.mat_scheduler.step()),
                      between_steps=between_steps)
         finally:
             drain(0)
