@@ -60,18 +60,36 @@ def test_bench_gpus_flag_starts_ranks_or_refuses():
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
 
 
-def test_bench_two_ranks_on_one_gpu_over_gloo():
+def _line_and_full(r, full_path):
+    """the ONE printed line (what the driver parses: <= 3 KB, contract keys) and the full record it names"""
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) <= 3072, (len(lines), [len(x) for x in lines])
+    line = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "full"):
+        assert k in line, k
+    assert set(line["config"]) == {"workload", "parallelism"} and line["full"] == full_path
+    full = json.load(open(full_path))
+    assert full["value"] == line["value"] and full["n_gpus"] == line["n_gpus"]
+    return line, full
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo(tmp_path):
     """the N > 1 bench path end to end (block-cyclic shards, all_reduce assembly, max-over-ranks timing, one JSON line from rank 0) with
     two ranks sharing this GPU over gloo; the assembled texture's throughput line must carry n_gpus: 2"""
+    fp_ = str(tmp_path / "full.json")
     r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
               "bench.py", "--gpus", "2", "--workload", "tiny", "--steps", "1", "--warmup", "1", "--no-cpu",
               "--mat", "--mat-steps", "4", "--mat-res", "512", "--mat-cube", "32"],
-             env={"TEXIR_DIST_BACKEND": "gloo"})
+             env={"TEXIR_DIST_BACKEND": "gloo", "TEXIR_BENCH_FULL": fp_})
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    line, d = _line_and_full(r, fp_)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    # the printed line's per-rank block: kernel time of every rank, the assembly check, the bytes one step's collective moves, which backend ran (rccl_ranks is the
+    # world size under nccl = RCCL, None under this test's gloo)
+    lr = line["ranks"]
+    assert lr["assembled_ok"] is True and len(lr["kernel_ms"]) == 2 and lr["backend"] == "gloo" and lr["rccl_ranks"] is None
+    assert lr["collective_bytes_per_step"] == 12 * 12417          # 12 B per valid texel of the tiny workload (one all_gather of the compacted values)
+    assert line["material_step"]["mat_shard"] == "pixel" and line["material_step_view_mode"]["mat_shard"] == "view"
     # rank 0 re-traced a sample of both ranks' texel blocks alone: the all-reduced texture must hold exactly those values
     assert d["ranks"]["assembled_ok"] is True and len(d["ranks"]["kernel_ms"]) == 2 and d["ranks"]["kernel_ms_max"] >= d["ranks"]["kernel_ms_min"] > 0
     fp = d["ranks"]["footprint_per_rank"]
@@ -87,17 +105,19 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert v["collective_bytes_per_step"] > m["collective_bytes_per_step"]
 
 
-def test_bench_eight_ranks_on_one_gpu_over_gloo_c2_shape():
+def test_bench_eight_ranks_on_one_gpu_over_gloo_c2_shape(tmp_path):
     """the driver's 8-GPU command shape on the one GPU there is: 8 ranks over gloo trace the 8 block-cyclic shards of a c2-shaped workload (200 k triangles,
     2048^2 texels) at 64 spp, assemble them through the all_gather, and rank 0's re-trace of sampled blocks of every rank must equal the assembled texture"""
     r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29561",
               "bench.py", "--gpus", "8", "--workload", "c2", "--spp", "64", "--steps", "1", "--warmup", "1", "--no-cpu", "--no-mat"],
-             timeout=1500, env={"TEXIR_DIST_BACKEND": "gloo"})
+             timeout=1500, env={"TEXIR_DIST_BACKEND": "gloo", "TEXIR_BENCH_FULL": str(tmp_path / "full8.json")})
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    line, d = _line_and_full(r, str(tmp_path / "full8.json"))
     assert d["n_gpus"] == 8 and d["ranks"]["assembled_ok"] is True and len(d["ranks"]["kernel_ms"]) == 8
+    # the compact N = 8 line (VERDICT r5 next #7): per-rank kernel times, the assembly check and the collective's bytes are IN the printed line
+    lr = line["ranks"]
+    assert lr["assembled_ok"] is True and len(lr["kernel_ms"]) == 8 and min(lr["kernel_ms"]) > 0 and lr["collective_bytes_per_step"] > 0 and lr["backend"] == "gloo"
+    assert "8" in line["config"]["parallelism"] and line["scaling"] == "strong"
 
 
 def test_pixel_sharded_material_step_is_the_single_gpu_step_bit_for_bit(tmp_path):

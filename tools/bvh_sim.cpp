@@ -77,8 +77,8 @@ int main(int argc, char** argv)
     if (argc < 2) { fprintf(stderr, "usage: bvh_sim <dir> [groups=64] [passes=64] [variant flags: cull cull8 nosort]\n"); return 1; }
     std::string dir = argv[1];
     int n_groups = argc > 2 ? atoi(argv[2]) : 64, n_pass = argc > 3 ? atoi(argv[3]) : 64;
-    bool cull = false, cull8 = false, nosort = false, psort3 = false; int policy = 0; double alpha = 1.0, alpha2 = 1.0, tricost = 1.5; int refillK = 0; int spec = 0; int switch_after = 0; int parkK = 0, parkM = 0;
-    for (int i = 4; i < argc; i++) { if (!strcmp(argv[i], "cull")) cull = true; if (!strcmp(argv[i], "cull8")) cull = cull8 = true; if (!strcmp(argv[i], "nosort")) nosort = true; if (!strcmp(argv[i], "psort3")) psort3 = true; if (!strncmp(argv[i], "after:", 6)) switch_after = atoi(argv[i] + 6); if (!strcmp(argv[i], "spec")) spec = 1; if (!strcmp(argv[i], "spec2")) spec = 2; if (!strncmp(argv[i], "refill:", 7)) refillK = atoi(argv[i] + 7); if (!strncmp(argv[i], "arr", 3)) { policy = 2; if (argv[i][3] == ':') { alpha = alpha2 = atof(argv[i] + 4); const char* c2 = strchr(argv[i] + 4, ','); if (c2) alpha2 = atof(c2 + 1); } } if (!strncmp(argv[i], "maj", 3)) { policy = 1; if (argv[i][3] == ':') { alpha = alpha2 = atof(argv[i] + 4); const char* c2 = strchr(argv[i] + 4, ','); if (c2) alpha2 = atof(c2 + 1); } } if (!strncmp(argv[i], "tricost:", 8)) tricost = atof(argv[i] + 8); if (!strncmp(argv[i], "park:", 5)) { parkK = atoi(argv[i] + 5); const char* c2 = strchr(argv[i] + 5, ','); parkM = c2 ? atoi(c2 + 1) : 0; } }
+    bool cull = false, cull8 = false, nosort = false, psort3 = false; int policy = 0; double alpha = 1.0, alpha2 = 1.0, tricost = 1.5; int refillK = 0; int spec = 0; int switch_after = 0; int parkK = 0, parkM = 0; int regB = 0, regKey = 0; bool consec = false;
+    for (int i = 4; i < argc; i++) { if (!strcmp(argv[i], "cull")) cull = true; if (!strcmp(argv[i], "cull8")) cull = cull8 = true; if (!strcmp(argv[i], "nosort")) nosort = true; if (!strcmp(argv[i], "psort3")) psort3 = true; if (!strncmp(argv[i], "after:", 6)) switch_after = atoi(argv[i] + 6); if (!strcmp(argv[i], "spec")) spec = 1; if (!strcmp(argv[i], "spec2")) spec = 2; if (!strncmp(argv[i], "refill:", 7)) refillK = atoi(argv[i] + 7); if (!strncmp(argv[i], "arr", 3)) { policy = 2; if (argv[i][3] == ':') { alpha = alpha2 = atof(argv[i] + 4); const char* c2 = strchr(argv[i] + 4, ','); if (c2) alpha2 = atof(c2 + 1); } } if (!strncmp(argv[i], "maj", 3)) { policy = 1; if (argv[i][3] == ':') { alpha = alpha2 = atof(argv[i] + 4); const char* c2 = strchr(argv[i] + 4, ','); if (c2) alpha2 = atof(c2 + 1); } } if (!strncmp(argv[i], "tricost:", 8)) tricost = atof(argv[i] + 8); if (!strcmp(argv[i], "consec")) consec = true; if (!strncmp(argv[i], "regroup:", 8)) { regB = atoi(argv[i] + 8); const char* c2 = strchr(argv[i] + 8, ','); regKey = c2 ? atoi(c2 + 1) : 0; } if (!strncmp(argv[i], "park:", 5)) { parkK = atoi(argv[i] + 5); const char* c2 = strchr(argv[i] + 5, ','); parkM = c2 ? atoi(c2 + 1) : 0; } }
     auto verts = load<float>(dir + "/verts.f32"); auto tris = load<int32_t>(dir + "/tris.i32"); auto uvs = load<float>(dir + "/tri_uvs.f32");
     auto pos = load<float>(dir + "/pos.f32"); auto nrm = load<float>(dir + "/nrm.f32"); auto shift = load<float>(dir + "/shift.f32");
     auto ids = load<int32_t>(dir + "/ids.i32"); auto meta = load<int32_t>(dir + "/meta.i32");
@@ -183,6 +183,32 @@ int main(int argc, char** argv)
         (void)boxmiss; (void)mt;
         return 0;
     }
+    // regroup:B,key -- B consecutive wave groups (B x 64 Morton-neighbouring texels, one workgroup) re-deal their texels to their B waves before every pass, sorted by a
+    // key taken from the texel's PREVIOUS pass (the neighbouring direction cell): key 0 = no regrouping (the same blocks, for comparison), 1 = the subtree (top two levels
+    // of the 4-wide tree: <= 16 treelets + miss) of the previous hit, 2 = the previous pass's per-lane node visits (long rays together), 3 = (subtree, node visits)
+    std::vector<int> slot_subtree(h.tris.size(), 16);
+    if (regB) {
+        std::vector<std::pair<int, int>> st;          // (node code, subtree id)
+        const GpuNode4& root = h.nodes4[0];
+        int next_id = 0;
+        for (int k = 0; k < 4; k++) {
+            const int c1 = root.c[k];
+            if (c1 == kSent) continue;
+            if (c1 < 0) { st.push_back({c1, next_id++}); continue; }
+            for (int k2 = 0; k2 < 4; k2++) { const int c2 = h.nodes4[c1].c[k2]; if (c2 != kSent) st.push_back({c2, next_id++}); }
+        }
+        while (!st.empty()) {
+            auto [code, id] = st.back(); st.pop_back();
+            if (code == kSent) continue;
+            if (code >= 0) { for (int k = 0; k < 4; k++) st.push_back({h.nodes4[code].c[k], id}); continue; }
+            uint32_t lc = ~(uint32_t)code; int first = (int)(lc >> 3), cnt = (int)(lc & 7u) + 1;
+#if TEXIR_QUAD
+            first *= 2; cnt *= 2;
+#endif
+            for (int i = first; i < first + cnt && i < (int)slot_subtree.size(); i++) slot_subtree[i] = id;
+        }
+        printf("regroup: blocks of %d waves, key %d, %d treelets\n", regB, regKey, next_id);
+    }
     Counters tot;
     const int64_t n_ids = (int64_t)ids.size();
     const int64_t n_grp_total = n_ids / 64;
@@ -192,12 +218,16 @@ int main(int argc, char** argv)
         std::vector<Ray> R(64);
 #pragma omp for schedule(dynamic, 1)
         for (int gi = 0; gi < n_groups; gi++) {
-            const int64_t g = (int64_t)((double)gi / n_groups * n_grp_total);
+            const int B = regB ? regB : 1;
+            int64_t g = (int64_t)((double)gi / n_groups * n_grp_total);
+            if (regB) g = std::min<int64_t>((g / B) * B, n_grp_total - B);
+            std::vector<int> blk(B * 64), order(B * 64), lane_tex(64); std::vector<double> rkey(B * 64, 0.0);
+            for (int i = 0; i < B * 64; i++) { blk[i] = ids[g * 64 + i]; order[i] = i; }
             Frame fr[64];
-            for (int l = 0; l < 64; l++) { int t = ids[g * 64 + l]; fr[l] = make_frame(nrm[3 * t], nrm[3 * t + 1], nrm[3 * t + 2]); }
             int lane_pass[64];
             auto init_ray = [&](int l, uint32_t J) {
-                    int t = ids[g * 64 + l];
+                    int t = lane_tex[l];
+                    fr[l] = make_frame(nrm[3 * t], nrm[3 * t + 1], nrm[3 * t + 2]);
                     float sh0 = shift[2 * t], sh1 = shift[2 * t + 1];
                     uint32_t i = sample_index(cell_to_pass(J, sh0, sh1, log2N), log2N);
                     float s0 = swc((float)i / (float)N, sh0), s1 = swc((float)((double)brev(i) * 2.3283064365386963e-10), sh1);
@@ -213,7 +243,10 @@ int main(int argc, char** argv)
             const uint32_t Jbase = (uint32_t)((gi * 97) % 32) * (uint32_t)(N / 32);
             std::vector<Ray> queue; bool in_compact = false;
             for (int pj = 0; pj < (refillK ? 1 : n_pass) || !queue.empty(); pj++) {
-                const uint32_t J = refillK ? Jbase : (uint32_t)((double)pj / n_pass * N);
+                const uint32_t J = refillK ? Jbase : consec ? (Jbase + (uint32_t)pj) % (uint32_t)N : (uint32_t)((double)pj / n_pass * N);      // consec: the passes of ONE wedge, neighbouring cells in order (what a chunk of the kernel walks)
+                if (regB && regKey && pj > 0) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rkey[a] < rkey[b]; });
+              for (int wv = 0; wv < B; wv++) {
+                for (int l = 0; l < 64; l++) lane_tex[l] = blk[order[wv * 64 + l]];
                 in_compact = false;
                 const double w0n = c.wnode, w0t = c.wtri, n0 = c.nodes, t0 = c.tris;
                 if (parkK && (queue.size() >= 64 || pj >= n_pass)) {
@@ -361,8 +394,13 @@ int main(int argc, char** argv)
                 if (in_compact) { c.cwnode += c.wnode - w0n; c.cwtri += c.wtri - w0t; c.cnodes += c.nodes - n0; c.ctris += c.tris - t0; }
                 for (auto& r : R) if (r.slot >= 0) c.hits++;
                 { int mn = 0, mt = 0; for (int l = 0; l < 64; l++) { mn = std::max(mn, lane_nodes[l]); mt = std::max(mt, lane_tris[l]); } c.wmaxn += mn; c.wmaxt += mt; }
+                if (regB) for (int l = 0; l < 64; l++) {
+                    const int sub = R[l].slot >= 0 ? slot_subtree[R[l].slot] : 17;
+                    rkey[order[wv * 64 + l]] = regKey == 1 ? (double)sub : regKey == 2 ? (double)lane_nodes[l] : (double)sub * 4096.0 + (double)lane_nodes[l];
+                }
                 { std::sort(pass_nodes.begin(), pass_nodes.end()); c.un_nodes += (double)(std::unique(pass_nodes.begin(), pass_nodes.end()) - pass_nodes.begin());
                   std::sort(pass_leaves.begin(), pass_leaves.end()); c.un_leaves += (double)(std::unique(pass_leaves.begin(), pass_leaves.end()) - pass_leaves.begin()); }
+              }
             }
         }
 #pragma omp critical
