@@ -557,6 +557,8 @@ def compact_line(full, full_path):
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
     out = {k: full.get(k) for k in keep}
     out["config"] = {"workload": (_g(full, "config", "workload") or "")[:320], "parallelism": (_g(full, "config", "parallelism") or "")[:200]}
+    if _g(full, "config", "workload_make_or_load_s") is not None:
+        out["setup_s"] = round(float(_g(full, "config", "workload_make_or_load_s")) + float(_g(full, "config", "bvh_build_s") or 0.0), 2)
     rf = full.get("roofline")
     if rf is not None:
         bind = rf.get("binding")
@@ -760,7 +762,9 @@ def main():
         """time `steps` passes of the hot path over workload `name`; returns the measurements + what the later legs need"""
         if world > 1 and rank != 0 and os.environ.get("TEXIR_SYNTH_CACHE"):
             dist.barrier()                  # rank 0 generates into the cache, the others load it
+        t_make = time.perf_counter()
         sc0, pos, nrm, valid, shift, res, spp = make_workload(name)
+        t_make = time.perf_counter() - t_make         # rank 0: generate (+ write the cache at N > 1); other ranks: load the cache -- outside the timed region, inside the driver's wall clock
         if world > 1 and rank == 0 and os.environ.get("TEXIR_SYNTH_CACHE"):
             dist.barrier()
         if args.spp:
@@ -829,7 +833,7 @@ def main():
         if world == 1 and args.project:
             ranks = {"projected": project_scaling(sc, d_pos, d_nrm, d_shift, ids_all, spp, res, dev, kern_ms)}
         return {"sc": sc, "sc0": sc0, "pos": pos, "nrm": nrm, "valid": valid, "shift": shift, "res": res, "spp": spp, "irr": irr, "ids": ids,
-                "dt": dt, "kern_ms": kern_ms, "ranks": ranks, "n_valid": n_valid, "build_s": build_s, "kernel": sc.irt_kernel_name(int(ids.numel()), spp),
+                "dt": dt, "kern_ms": kern_ms, "ranks": ranks, "n_valid": n_valid, "build_s": build_s, "make_s": t_make, "kernel": sc.irt_kernel_name(int(ids.numel()), spp),
                 "value": n_valid * spp * steps / dt / 1e6,
                 "desc": "%s: IrT %d spp, %dx%d texels (%d valid), %d-tri synthetic %s mesh, %dx%d radiance texture (%s)"
                         % (name, spp, res, res, n_valid, T, {"room": "indoor", "scan": "scan-like (rotated clutter, slats, openings)", "house": "3x3-room house (doors, untessellated shell + dense clutter, windows)"}[style], tex_res, tex_res,
@@ -861,7 +865,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": r["desc"],
                        "parallelism": "texel-sharded x%d (block-cyclic %d) + RCCL all_gather of the compacted texel values" % (world, BLOCK) if world > 1 else "single GPU",
-                       "bvh_build_s": round(r["build_s"], 2), "scene": r["sc"].info()},
+                       "bvh_build_s": round(r["build_s"], 2), "workload_make_or_load_s": round(r["make_s"], 2), "scene": r["sc"].info()},
         }
         if mat is not None:
             out["material_step"] = mat
@@ -892,7 +896,8 @@ def main():
             out["cpu_baseline"] = cpu
     # further workloads (IrT only), never the headline
     if args.extra is None:          # the full default line (what the driver runs) carries the hostile sibling; tool invocations (--no-cpu / --no-mat) stay lean
-        args.extra = "c4_scan,house" if (args.workload == "c4" and not args.no_cpu and not args.no_mat) else ""
+        # (N > 1 stays lean: every extra workload costs rank 0 another ~25 s of generation + cache hand-off inside the driver's wall clock, and the siblings are never the headline)
+        args.extra = "c4_scan,house" if (args.workload == "c4" and not args.no_cpu and not args.no_mat and world == 1) else ""
     extras = [w for w in args.extra.split(",") if w and w != "none"]
     if extras:
         del r

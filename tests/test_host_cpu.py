@@ -372,7 +372,7 @@ def test_rle_hdr_decoder_on_a_hand_assembled_byte_string(tmp_path):
 def test_bvh_builder_keeps_every_triangle_point_reachable(tmp_path):
     """tests/native/bvh_cover.cpp: the product's host BVH builder compiled with the host compiler; point queries at corners, edge points and interior
     points of every triangle (small ones, long thin rotated slats, large flat ones) must reach a leaf that holds the triangle, in the binary and in the
-    4-wide float-box tree (whose leaves name quad records).  (Written for the reference pre-splitting experiment, tools/experiments/bvh_presplit.patch -- whose split pieces it also
+    4-wide float-box tree (whose leaves name quad records).  (Written for the reference pre-splitting experiment, the bvh_presplit patch of round 4, HISTORY.md -- whose split pieces it also
     covered, TEXIR_PRESPLIT = 30 / 150 -- and kept as the builder's own coverage check.)"""
     import subprocess
     csrc = os.path.join(ROOT, "texir_code_amd", "csrc")
