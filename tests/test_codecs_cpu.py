@@ -323,3 +323,35 @@ def test_four_byte_texels_hold_every_rgbe_born_value_exactly():
     ok = np.zeros(len(born), np.uint8)
     _lib.check(L.texir_texel_pack(_lib.ptr(born), len(born), _lib.ptr(np.zeros(len(born), np.uint32)), _lib.ptr(ok)))
     assert ok.all() and np.abs(born.reshape(sc0["hdr"].shape) - sc0["hdr"]).max() <= sc0["hdr"].max() / 128
+
+
+def test_obj_numbers_on_the_slow_path_follow_python_float(tmp_path):
+    """the OBJ parser's slow path (mantissas past 19 digits, |exponent| > 22) goes through strtod -- in the "C" locale, and without the hexadecimal
+    spellings strtod takes but Python's float() (the stated reference, io_formats.load_obj_py) refuses"""
+    import locale
+    from texir_code_amd import io_formats as IO
+    long_m = "0.1234567890123456789012345"          # 25 digits
+    txt = "v %s 1e-30 -2.5E+25\nv 1 0 0\nv 0 1 0\nf 1 2 3\n" % long_m
+    p = tmp_path / "slow.obj"
+    p.write_text(txt)
+    out = IO.load_obj(str(p), cache=False)
+    assert out["vertices"][0].tolist() == [np.float32(float(long_m)), np.float32(1e-30), np.float32(-2.5e25)]
+    for spelling in ("0x1p3", "0X10"):
+        bad = tmp_path / "hex.obj"
+        bad.write_text("v %s 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n" % spelling)
+        with pytest.raises(ValueError):
+            IO.load_obj(str(bad), cache=False)
+        with pytest.raises(ValueError):
+            float(spelling)
+    # a comma-decimal LC_NUMERIC of the embedding process must not change the parse (only testable where such a locale is installed)
+    old = locale.setlocale(locale.LC_NUMERIC)
+    try:
+        for name in ("de_DE.UTF-8", "de_DE.utf8", "fr_FR.UTF-8"):
+            try:
+                locale.setlocale(locale.LC_NUMERIC, name)
+            except locale.Error:
+                continue
+            assert IO.load_obj(str(p), cache=False)["vertices"][0].tolist() == out["vertices"][0].tolist()
+            break
+    finally:
+        locale.setlocale(locale.LC_NUMERIC, old)

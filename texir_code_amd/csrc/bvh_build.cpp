@@ -1,5 +1,7 @@
 // Binned-SAH BVH2 builder (host, multi-threaded over the top subtrees) emitting the 64-byte
 // two-child-box node layout consumed by the gfx950 traversal kernels (see bvh_build.h).
+#include <stdexcept>
+#include <string>
 #include <cstdio>
 #include <cstdlib>
 #include "bvh_build.h"
@@ -131,7 +133,8 @@ std::unique_ptr<Tmp> build(const Ctx& c, int first, int count, int depth, int pa
 // leaf codes (bvh_build.h): the binary tree names leaf-order slots, the 4-wide tree names quad records when the library has them
 inline int32_t leaf_code(const Tmp* t)
 {
-    if (t->slot_count < 1 || t->slot_count > 8) { fprintf(stderr, "texir bvh: leaf of %d slots does not fit its 3-bit count\n", t->slot_count); abort(); }
+    // (cannot fire with TEXIR_MAX_LEAF <= 8; thrown -- texir_scene_create turns it into TEXIR_ERR_INVALID -- rather than aborting the host process)
+    if (t->slot_count < 1 || t->slot_count > 8) throw std::runtime_error("texir bvh: leaf of " + std::to_string(t->slot_count) + " slots does not fit its 3-bit count");
     return ~(int32_t)(((uint32_t)t->slot_first << 3) | (uint32_t)(t->slot_count - 1));
 }
 inline int32_t leaf_code4(const Tmp* t)

@@ -136,7 +136,9 @@ int texir_scene_create(const float* verts, int32_t V, const int32_t* tris, int32
         if (tris[i] < 0 || tris[i] >= V) return fail(TEXIR_ERR_INVALID, "texir_scene_create: triangle index %d out of range", (int)tris[i]);
     HIP_TRY(hipSetDevice(device));
     BvhHost h;
-    try { build_bvh(verts, V, tris, T, tri_uvs, h); } catch (const std::bad_alloc&) { return fail(TEXIR_ERR_NOMEM, "BVH build: out of host memory"); }
+    try { build_bvh(verts, V, tris, T, tri_uvs, h); }
+    catch (const std::bad_alloc&) { return fail(TEXIR_ERR_NOMEM, "BVH build: out of host memory"); }
+    catch (const std::exception& ex) { return fail(TEXIR_ERR_INVALID, "BVH build: %s", ex.what()); }
     texir_scene* s = new (std::nothrow) texir_scene;
     if (!s) return fail(TEXIR_ERR_NOMEM, "out of host memory");
     s->n_slots = h.n_slots; s->n_quads = (int64_t)h.quads.size(); s->n_uv_recs = (int64_t)h.uvs.size();

@@ -2,6 +2,7 @@
 // "0.png" is a 16-bit PNG written by libpng with adaptive filters, tracer_o3d_irt.py:91) and Radiance new-style RLE scanlines (the
 // per-view ccm.hdr / hdr_texture.hdr files, datasets/dataset.py:480, tracer_o3d_irt.py:77).  Both are byte-serial recurrences, i.e.
 // 10^8 interpreter iterations per file if left in Python; here they are plain C++ behind two C-ABI entry points (host pointers).
+#include <locale.h>
 #include <cstdint>
 #include <cstdlib>
 
@@ -168,8 +169,12 @@ inline bool parse_f32(const char* b, const char* e, float& out)
     if (n == 0 || n >= sizeof(tmp)) return false;
     memcpy(tmp, b, n);
     tmp[n] = 0;
+    // strtod in the "C" locale whatever LC_NUMERIC the embedding application has set (a comma-decimal locale would otherwise reject every vertex that
+    // reaches this path), and without the spellings strtod takes but Python's float() refuses: hexadecimal floats
+    for (size_t i = 0; i < n; i++) if (tmp[i] == 'x' || tmp[i] == 'X') return false;
+    static const locale_t c_loc = newlocale(LC_ALL_MASK, "C", (locale_t)0);
     char* endp = nullptr;
-    const double d = strtod(tmp, &endp);
+    const double d = c_loc ? strtod_l(tmp, &endp, c_loc) : strtod(tmp, &endp);
     if (endp != tmp + n) return false;
     out = (float)d;
     return true;

@@ -21,7 +21,7 @@ def _json_float(v):
 class ScalarLog:
     def __init__(self, directory, name="scalars.jsonl", flush_every=64):
         self.path = os.path.join(directory, name) if directory and os.path.isdir(directory) else None
-        self._f = open(self.path, "a") if self.path else None
+        self._f = open(self.path, "a", buffering=1) if self.path else None          # line-buffered: a crash mid-stage keeps every scalar written so far
         self._n, self._every = 0, flush_every
 
     def add_scalar(self, tag, value, step):
@@ -42,6 +42,12 @@ class ScalarLog:
         if self._f is not None:
             self._f.close()
             self._f = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def read_scalars(path):

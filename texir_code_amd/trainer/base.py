@@ -44,7 +44,8 @@ class RunnerBase:
                     pass
         # the reference's `self.writer = SummaryWriter(os.path.join(self.expdir, self.timestamp))` (trainer/train_material.py:82): scalars.jsonl there
         from ..runlog import ScalarLog
-        self.writer = ScalarLog(os.path.join(self.expdir, self.timestamp) if make_dirs else None)
+        # (rank 0 only: several ranks appending to one scalars.jsonl would interleave duplicate lines; line-buffered, so an exception mid-stage loses nothing)
+        self.writer = ScalarLog(os.path.join(self.expdir, self.timestamp) if (make_dirs and int(os.environ.get("RANK", "0")) == 0) else None)
         print("shell command : {0}".format(" ".join(sys.argv)))
 
     def save_checkpoints(self, epoch):
