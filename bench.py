@@ -423,6 +423,22 @@ def mat_leg_pixel(sc, sc0, irr_tex, res, dev, rank, world, steps=50, warmup=5, c
                       % (tres, tres, 6 * cube * cube, S, world)}
 
 
+FINGERPRINT_TEXELS = 262144
+
+
+def irt_fingerprint(sc, d_pos, d_nrm, d_shift, ids_all, spp, dev):
+    """what the traversal DID on a fixed slice of the workload (the counting form of the kernel: rays, per-lane node fetches, triangle tests, hits, wave-level node /
+    triangle steps over 262 144 listed texels from the middle third of the Morton list): integers, deterministic for given sources + workload.  The committed PMC profile carries
+    the same six numbers from the box it was taken on (tools/pmc_to_json.py); equal numbers = the kernel this run timed walks the scene exactly as the profiled one did
+    (VERDICT r5 weak #6: the line's counters come from another box -- this is the live cross-check of that hybrid)"""
+    n = int(ids_all.numel())
+    first = ((n // 3) // 4096) * 4096
+    ids = ids_all[first:first + min(FINGERPRINT_TEXELS, n - first)].to(dev)
+    _, st = sc.irt_generate(d_pos, d_nrm, d_shift, spp, "uniform", texel_ids=ids, stats=True)
+    v = [int(x) for x in st[:6].tolist()]
+    return dict(zip(("rays", "node_fetches", "tri_tests", "hits", "wave_node_steps", "wave_tri_steps"), v))
+
+
 def load_pmc(workload, kernel):
     """per-launch PMC counters of the dominant kernel for this workload (written by tools/profile_round.sh); None -- with the
     reason -- when there is no profile of THESE kernel sources / this kernel form"""
@@ -450,8 +466,8 @@ def load_chain(workload, kernel):
     return tj, None
 
 
-def roofline(workload, kernel, kern_ms, rays_this_rank, world, alg):
-    """the two bounds of the module docstring; `alg` = (bytes/ray, nodes/ray, tris/ray, p_hit) of SURVEY 8(d) or None"""
+def roofline(workload, kernel, kern_ms, rays_this_rank, world, alg, fingerprint=None):
+    """the two bounds of the module docstring; `alg` = (bytes/ray, nodes/ray, tris/ray, p_hit) of SURVEY 8(d) or None; `fingerprint` = this run's irt_fingerprint"""
     t = kern_ms * 1e-3
     out = {"bound": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
            "kernel": kernel, "kernel_ms": round(kern_ms, 3), "rays_per_launch": rays_this_rank}
@@ -498,6 +514,10 @@ def roofline(workload, kernel, kern_ms, rays_this_rank, world, alg):
                     "scalar_path": None if pmc.get("smem_insts") is None else {"smem_insts_per_launch": float(pmc["smem_insts"]) * scale,
                                                                                "scalar_cache_hit_rate": pmc.get("scalar_cache_hit_rate")},
                     "profile": "profiles/pmc_%s.json (%s)" % (workload, pmc.get("source", ""))})
+        if fingerprint is not None:
+            # the counters above were collected on another box: do the two runs walk the scene identically?
+            out["live_fingerprint"] = fingerprint
+            out["profile_matches_live"] = (pmc["fingerprint"] == fingerprint) if pmc.get("fingerprint") else None
     chain, why_c = load_chain(workload, kernel)
     if chain is not None and out.get("limits") is not None:
         # the dependent-chain bound (tools/chain_probe.py -> profiles/chain_<workload>.json): every wave-level step of the launch at the latency it has with ONE wave
@@ -573,6 +593,7 @@ def compact_line(full, full_path):
         o["l2_hit"] = _g(rf, "limits", "hbm", "l2_hit_rate")
         o["valu_frac"], o["l1_frac"], o["chain_frac"] = _g(rf, "limits", "valu", "frac"), _g(rf, "limits", "l1", "frac"), _g(rf, "limits", "chain", "frac")
         o["profile"] = (rf.get("profile") or "").split(" ")[0] or None
+        o["profile_matches_live"] = rf.get("profile_matches_live")
         if rf.get("note"):
             o["note"] = rf["note"][:160]
         out["roofline"] = o
@@ -830,10 +851,11 @@ def main():
                      "assembled_ok": ok, "assembled_check": "rank 0 alone re-traced every 100th %d-texel block of the list; bit-equal to the assembled (all-gathered) texture" % BLOCK}
         T, _, tex_res, _, style = WORKLOADS[name]
         n_valid = int(ids_all.numel())
+        fp = irt_fingerprint(sc, d_pos, d_nrm, d_shift, ids_all, spp, dev) if world == 1 else None
         if world == 1 and args.project:
             ranks = {"projected": project_scaling(sc, d_pos, d_nrm, d_shift, ids_all, spp, res, dev, kern_ms)}
         return {"sc": sc, "sc0": sc0, "pos": pos, "nrm": nrm, "valid": valid, "shift": shift, "res": res, "spp": spp, "irr": irr, "ids": ids,
-                "dt": dt, "kern_ms": kern_ms, "ranks": ranks, "n_valid": n_valid, "build_s": build_s, "make_s": t_make, "kernel": sc.irt_kernel_name(int(ids.numel()), spp),
+                "dt": dt, "kern_ms": kern_ms, "ranks": ranks, "n_valid": n_valid, "build_s": build_s, "make_s": t_make, "fingerprint": fp, "kernel": sc.irt_kernel_name(int(ids.numel()), spp),
                 "value": n_valid * spp * steps / dt / 1e6,
                 "desc": "%s: IrT %d spp, %dx%d texels (%d valid), %d-tri synthetic %s mesh, %dx%d radiance texture (%s)"
                         % (name, spp, res, res, n_valid, T, {"room": "indoor", "scan": "scan-like (rotated clutter, slats, openings)", "house": "3x3-room house (doors, untessellated shell + dense clutter, windows)"}[style], tex_res, tex_res,
@@ -880,7 +902,7 @@ def main():
         if not args.no_cpu:
             cpu, counters = cpu_leg(r["sc0"], r["pos"], r["nrm"], r["valid"], r["shift"], r["spp"], timed=world == 1)
             alg = algorithmic_bytes_per_ray(counters, r["spp"])
-        out["roofline"] = roofline(args.workload, r["kernel"], r["kern_ms"], rays_this_rank, world, alg)
+        out["roofline"] = roofline(args.workload, r["kernel"], r["kern_ms"], rays_this_rank, world, alg, r["fingerprint"])
         # what one launch MUST move through HBM at least once: the scene it reads (tree in both forms, triangles, corner uvs, the hit shader's texture copy),
         # the texel G-buffers + id list, and the texture it writes -- everything beyond this in `traffic` is re-reading (cache misses), everything in
         # `algorithmic` beyond `traffic` was served by L1 / L2 / LDS / the scalar cache
@@ -912,7 +934,7 @@ def main():
                 if e["ranks"] is not None:
                     ex[w]["ranks"] = e["ranks"]
                 if load_pmc(w, e["kernel"])[0] is not None:         # (measured bounds where tools/profile_round.sh has profiled this workload too)
-                    ex[w]["roofline"] = roofline(w, e["kernel"], e["kern_ms"], int(e["ids"].numel()) * e["spp"], world, None)
+                    ex[w]["roofline"] = roofline(w, e["kernel"], e["kern_ms"], int(e["ids"].numel()) * e["spp"], world, None, e["fingerprint"])
             del e
             torch.cuda.empty_cache()
         if rank == 0:

@@ -58,5 +58,21 @@ try:
     res["rays_per_launch"] = int((valid_.reshape(-1) > 0).sum()) * spp_
 except Exception as e:      # (the json is still usable at N = 1)
     res["rays_per_launch_error"] = str(e)
+# the traversal's own counters on a fixed slice of the workload (bench.irt_fingerprint): bench.py recomputes them live and compares -- the cross-check between
+# the box these PMC counters come from and the box a bench line is timed on
+try:
+    import torch
+    from texir_code_amd import scene as S, dist_util
+    if torch.cuda.is_available():
+        sc0_, pos_, nrm_, valid_, shift_, res_, spp_ = bench.make_workload(wl)
+        dev = torch.device("cuda", 0)
+        sc_ = S.Scene(sc0_["verts"], sc0_["tris"], sc0_["tri_uvs"], sc0_["hdr"], device=0)
+        ids_ = dist_util.morton_order(torch.nonzero(torch.from_numpy(valid_.reshape(-1)) > 0)[:, 0].to(torch.int32), res_)
+        d_pos, d_nrm, d_shift = (torch.from_numpy(a).to(dev) for a in (pos_.reshape(-1, 3), nrm_.reshape(-1, 3), shift_))
+        sc_.irt_generate(d_pos, d_nrm, d_shift, spp_, "uniform", texel_ids=ids_.to(dev))        # (the full-list launch that tunes the scene's scheduler weight, exactly as bench.py's warm-up does)
+        res["fingerprint"] = bench.irt_fingerprint(sc_, d_pos, d_nrm, d_shift, ids_, spp_, dev)
+        res["tex_layout"] = sc_.texture_layout()
+except Exception as e:
+    res["fingerprint_error"] = "%s: %s" % (type(e).__name__, e)
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "counters"}))
