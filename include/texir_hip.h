@@ -350,6 +350,10 @@ typedef struct texir_adam_tex_job {
     const float* hyper;            /* dev [2] (texir_adam_tick) */
     float beta1, beta2, eps, clamp_lo, clamp_hi;
 } texir_adam_tex_job;
+/* g [n_texels][C] += g0 [n_texels][C] where bit t of mask (one bit per texel) is set: the sparse level-0 gradient of a trilinear fetch folded into the dense level-0
+ * gradient an un-mipmapped fetch of the SAME texture produced in the same backward pass (stage 1, models/mat_nvdiffrast.py:131-139: both fetches read materials_r).
+ * Errors: texir_batch_last_error(). */
+TEXIR_API int texir_grad_add_masked(float* g /*dev*/, const float* g0 /*dev*/, const uint32_t* mask /*dev*/, int64_t n_texels, int32_t C, void* stream);
 TEXIR_API int texir_adam_step_tex_dev_batch(const texir_adam_tex_job* jobs /*host*/, int32_t n_jobs, void* stream);
 
 /* ---- host-side codec loops of the file formats around the path (both take HOST pointers) ----------------------------

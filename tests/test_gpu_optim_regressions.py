@@ -246,3 +246,32 @@ def test_level1_stack_is_not_read_when_no_tap_touches_level1(tx):
             (RT.texture(a, uv.cpu(), da.cpu(), "linear-mipmap-linear", 13) * w.cpu()).sum().backward()
             oa.step()
         assert rel_l2(res[0][0].cpu().numpy(), a.detach().numpy()) < 1e-5
+
+
+def test_masked_gradient_add_equals_the_torch_form(tx):
+    """texir_grad_add_masked (round 6: the sparse level-0 gradient folded into a dense one in ONE launch, FusedAdam.step's stage-1 case) against the five elementwise
+    torch launches it replaced: identical bits, for 1 and 3 channels, a texel count that is not a multiple of 32, an all-zero and an all-ones mask"""
+    from texir_code_amd import _lib
+    L = _lib.lib()
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    for H, W, C in ((37, 29, 1), (64, 64, 3), (5, 7, 4)):
+        n = H * W
+        for kind in ("random", "zeros", "ones"):
+            words = (n + 31) // 32
+            mask = {"random": torch.randint(-2 ** 31, 2 ** 31 - 1, (words,), device="cuda", dtype=torch.int64, generator=gen).to(torch.int32),
+                    "zeros": torch.zeros(words, device="cuda", dtype=torch.int32), "ones": torch.full((words,), -1, device="cuda", dtype=torch.int32)}[kind]
+            g = torch.randn(H, W, C, device="cuda", generator=gen)
+            g0 = torch.randn(H, W, C, device="cuda", generator=gen)
+            g0[0, 0, 0] = float("nan")                        # a never-cleared buffer may hold anything outside the mask ...
+            if kind != "ones":
+                mask[0] &= ~1                                 # ... so texel 0 is outside it here
+            bits = ((mask.view(-1, 1) >> torch.arange(32, device="cuda", dtype=torch.int32)) & 1).bool().reshape(-1)[:n].reshape(H, W, 1)
+            want = g + torch.where(bits, g0, torch.zeros((), device="cuda"))
+            got = g.clone()
+            assert L.texir_grad_add_masked(_lib.ptr(got), _lib.ptr(g0), _lib.ptr(mask), n, C, _lib.stream_ptr()) == 0
+            torch.cuda.synchronize()
+            same = (got == want) | (torch.isnan(got) & torch.isnan(want))
+            assert bool(same.all()), (H, W, C, kind)
+            if kind != "ones":
+                assert not bool(torch.isnan(got).any())
+    assert L.texir_grad_add_masked(None, None, None, 4, 9, _lib.stream_ptr()) < 0 and b"bad size" in L.texir_batch_last_error()

@@ -74,6 +74,7 @@ def lib():
         sig["texir_adam_step_dev"] = [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, vp]
         sig["texir_adam_step_tex_dev"] = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, f32, f32, f32, f32, f32, vp]
         L.texir_batch_last_error.restype = C.c_char_p
+        sig["texir_grad_add_masked"] = [vp, vp, vp, i64, i32, vp]
         sig["texir_tex_fetch_forward_batch"] = [vp, i32, vp]
         sig["texir_tex_gather_backward_batch"] = [vp, i32, vp]
         sig["texir_adam_step_tex_dev_batch"] = [vp, i32, vp]

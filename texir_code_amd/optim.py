@@ -251,10 +251,12 @@ class FusedAdam(torch.optim.Optimizer):
                     else:
                         # (another fetch of the same parameter also produced a dense gradient in this backward pass: fold the sparse part in)
                         H, W, C = p.shape
-                        # (elementwise, no boolean indexing: index_put with a mask synchronises and cannot be recorded into a hipGraph -- this is the
-                        # stage-1 step of a view that samples level 0: un-mipmapped fetch = dense gradient, trilinear fetch = sparse part)
-                        bits = ((mask.view(-1, 1) >> torch.arange(32, device=p.device, dtype=torch.int32)) & 1).bool().reshape(-1)[:H * W].reshape(H, W, 1)
-                        g.add_(torch.where(bits, p._texir_g0, torch.zeros((), device=p.device)))
+                        # (one launch; the stage-1 step of a view that samples level 0: un-mipmapped fetch = dense gradient, trilinear fetch = sparse part.
+                        # Until round 6 five elementwise torch launches over the whole texture -- no boolean indexing: index_put with a mask synchronises
+                        # and cannot be recorded into a hipGraph -- 130 us of the 650 us stage-1 step at 4096^2)
+                        rc = L.texir_grad_add_masked(_lib.ptr(g), _lib.ptr(p._texir_g0), _lib.ptr(mask), H * W, C, _lib.stream_ptr())
+                        if rc:
+                            raise _lib.TexirError(L.texir_batch_last_error().decode())
                         mask = None
             if g1 is not None:
                 H, W, C = p.shape
