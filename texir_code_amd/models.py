@@ -304,7 +304,9 @@ class MaterialModel(nn.Module):
             finally:
                 self.scene.set_texture(src.contiguous())
         elif stage == 0:
-            res = {"rgb": irr * albedo / np.pi, "albedo": albedo, "normal": nrm, "position": pos + 1e-1 * nrm}
+            if "_position_out0" not in gb:                   # (a constant of the view: computed once, not twice per recorded step)
+                gb["_position_out0"] = pos + 1e-1 * nrm
+            res = {"rgb": irr * albedo / np.pi, "albedo": albedo, "normal": nrm, "position": gb["_position_out0"]}
         elif stage == 1:
             res = self.render(nrm, albedo.detach(), roughness_womipmap, gb["_points"], cam_position, irr, gb["_position_out"])
         elif stage == 2:

@@ -39,7 +39,7 @@ done
 # kernel-trace stats of the default bench run (the headline), with the PMC json in place so that the line carries the measured bounds
 mkdir -p $R/profiles; cp $out/pmc_*.json $R/profiles/ 2>/dev/null
 rm -rf /tmp/kt
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --steps 2 --warmup 1 --extra none --no-project --no-e2e > $out/bench_default_under_rocprof.json 2> $out/bench_default.err
+TEXIR_BENCH_FULL=$out/bench_default_under_rocprof_full.json timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --steps 2 --warmup 1 --extra none --no-project --no-e2e > $out/bench_default_under_rocprof.json 2> $out/bench_default.err
 f=$(find /tmp/kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $out/c4_kernel_stats.csv
 f=$(find /tmp/kt -name '*kernel_trace.csv' | head -1); [ -n "$f" ] && (head -1 "$f"; grep "irt_" "$f") > $out/c4_irt_kernel_trace_rows.csv
 tail -1 $out/bench_default_under_rocprof.json

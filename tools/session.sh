@@ -1,7 +1,7 @@
 #!/bin/bash
 # One parameterised GPU session (replaces the per-session r0N_session*.sh scripts; what each earlier session ran is listed in tools/SESSIONS.md).
 #   usage (on the GPU box, from the repo root):  tools/session.sh <tag> <step> [<step> ...]
-#   steps:  tests | tests-x | bench | bench-lean | gloo2 | ab:<label>:<lib.so>[:ENV=..,ENV=..] | chain:<workload> | profile:<wl>[,<wl>...] | matpmc | e2e:<workload>
+#   steps:  tests | tests-x | bench | driver | bench-lean | gloo2 | ab:<label>:<lib.so>[:ENV=..,ENV=..] | chain:<workload> | profile:<wl>[,<wl>...] | matpmc | e2e:<workload>
 # Everything lands under gpurun_out/<tag>/ ; summaries that are to be judged are copied to profiles/ by hand afterwards.
 tag=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -19,13 +19,14 @@ for step in "$@"; do
   case $step in
     tests)    timeout 3000 python -m pytest tests -m gpu -q > $out/pytest.txt 2>&1; echo "pytest rc $?" >> $out/pytest.txt; tail -4 $out/pytest.txt ;;
     tests-x)  timeout 3000 python -m pytest tests -m gpu -x -q > $out/pytest.txt 2>&1; echo "pytest rc $?" >> $out/pytest.txt; tail -4 $out/pytest.txt ;;
-    bench)    timeout 1800 python bench.py --steps 5 --warmup 1 > $out/bench.json 2> $out/bench.err; echo "bench rc $?"; tail -c 600 $out/bench.err ;;
-    bench-lean) timeout 900 python bench.py --steps 2 --warmup 1 --no-e2e --extra none > $out/bench_lean.json 2> $out/bench_lean.err; echo "bench rc $?" ;;
-    gloo2)    TEXIR_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 \
+    bench)    TEXIR_BENCH_FULL=$out/bench_full.json timeout 1800 python bench.py --steps 5 --warmup 1 > $out/bench.json 2> $out/bench.err; echo "bench rc $?"; tail -c 600 $out/bench.err ;;
+    driver)   TEXIR_BENCH_FULL=$out/bench_driver_full.json timeout 1800 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver.json 2> $out/bench_driver.err; echo "driver-shaped bench rc $?"; tail -c 3200 $out/bench_driver.json ;;
+    bench-lean) TEXIR_BENCH_FULL=$out/bench_lean_full.json timeout 900 python bench.py --steps 2 --warmup 1 --no-e2e --extra none > $out/bench_lean.json 2> $out/bench_lean.err; echo "bench rc $?" ;;
+    gloo2)    TEXIR_BENCH_FULL=$out/gloo2_full.json TEXIR_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 \
                 --workload tiny --steps 1 --warmup 1 --no-cpu --mat --mat-steps 4 --mat-res 512 --mat-cube 32 > $out/gloo2.json 2> $out/gloo2.err; echo "rc $?"
               python - $out/gloo2.json <<'PY'
 import json,sys
-d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+d=json.load(open(sys.argv[1].replace(".json", "_full.json")))
 for k in ("material_step","material_step_view_mode"):
     print(k, {a:b for a,b in d.get(k,{}).items() if a not in ("config","roofline")})
 PY

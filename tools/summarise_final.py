@@ -7,6 +7,9 @@ d = sys.argv[1]
 
 def line(name):
     p = os.path.join(d, name)
+    full = p.replace(".json", "_full.json")           # round 6: the printed line is compact, the whole record sits beside it
+    if os.path.exists(full):
+        return json.load(open(full))
     if not os.path.exists(p):
         return None
     rows = [x for x in open(p).read().strip().splitlines() if x.startswith("{")]
