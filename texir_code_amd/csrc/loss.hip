@@ -112,16 +112,29 @@ __global__ __launch_bounds__(kLB) void loss_scatter_kernel(const float* __restri
 __device__ __forceinline__ uint32_t fkey(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float fkey_inv(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
 
-// k-th smallest (0-based) of v[0..n) by 4 x 8-bit radix select; whole block cooperates; result valid on all threads
+// k-th smallest (0-based) of v[0..n) by 4 x 8-bit radix select; whole block (blockDim.x threads) cooperates; result valid on all threads.
+// The values of one class are roughness values in [0.01, 0.8]: their keys share the top byte and mostly the second, so a plain LDS atomicAdd per element
+// serialises a whole pass on ONE histogram bin.  A wave whose active lanes all fall into the same bin adds its lane count once (round 6: the kernel took
+// 75 us of the 650 us stage-1 step at 98 304 pixels); the counts, hence the selected value, are the same integers either way.
 __device__ float block_select(const float* v, uint32_t n, uint32_t k, uint32_t* hist /* LDS [256] */, uint32_t* bcast /* LDS [2] */)
 {
     uint32_t prefix = 0, mask = 0;
+    const uint32_t nround = (n + blockDim.x - 1) / blockDim.x * blockDim.x;
     for (int shift = 24; shift >= 0; shift -= 8) {
-        for (int i = threadIdx.x; i < 256; i += kLB) hist[i] = 0;
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += kLB) {
-            uint32_t key = fkey(v[i]);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        for (uint32_t i = threadIdx.x; i < nround; i += blockDim.x) {
+            uint32_t key = i < n ? fkey(v[i]) : 0u;
+            const bool in = i < n && (key & mask) == prefix;
+            const uint32_t bin = (key >> shift) & 255u;
+            const unsigned long long act = __ballot(in);
+            if (act) {                                                  // (wave-uniform: every thread of the block runs the same number of rounds)
+                const int fl = __ffsll((long long)act) - 1;
+                const uint32_t first_bin = (uint32_t)__shfl((int)bin, fl, 64);
+                const unsigned long long same = __ballot(in && bin == first_bin);
+                if (same == act) { if ((int)(threadIdx.x & 63) == fl) atomicAdd(&hist[first_bin], (uint32_t)__popcll(act)); }
+                else if (in) atomicAdd(&hist[bin], 1u);
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -136,9 +149,27 @@ __device__ float block_select(const float* v, uint32_t n, uint32_t k, uint32_t* 
     return fkey_inv(prefix);
 }
 
+// the (k + 1)-th smallest given a = the k-th smallest: a again if more than k + 1 elements are <= a, else the smallest element above a.  One pass instead of a second select.
+__device__ float block_next(const float* v, uint32_t n, uint32_t k1, float a, uint32_t* acc /* LDS [2]: count of elements <= a, smallest key above a */)
+{
+    if (threadIdx.x == 0) { acc[0] = 0u; acc[1] = 0xFFFFFFFFu; }
+    __syncthreads();
+    const uint32_t ka = fkey(a);
+    uint32_t cnt = 0, mn = 0xFFFFFFFFu;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { const uint32_t key = fkey(v[i]); if (key <= ka) cnt++; else mn = min(mn, key); }
+    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o, 64); mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&acc[0], cnt); atomicMin(&acc[1], mn); }
+    __syncthreads();
+    const float r = acc[0] > k1 ? a : fkey_inv(acc[1]);
+    __syncthreads();
+    return r;
+}
+
+constexpr int kQB = 1024;     // threads of the quantile kernel's block (one block per class: the largest class holds most of the view's highlight pixels)
+
 // SegLoss mode 1 target (loss.py:256-272): tau_c = 0.4-quantile (torch.quantile, linear interpolation) of the
 // detached no-mip roughness over the class's highlight pixels; 0 if the class has none; class 43 -> 0.8.
-__global__ __launch_bounds__(kLB) void loss_quantile_kernel(int C, LossWs ws)
+__global__ __launch_bounds__(kQB) void loss_quantile_kernel(int C, LossWs ws)
 {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t bc[2];
@@ -151,7 +182,7 @@ __global__ __launch_bounds__(kLB) void loss_quantile_kernel(int C, LossWs ws)
     float w = rank - lo;
     uint32_t k0 = (uint32_t)lo, k1 = min(k0 + 1u, n - 1u);
     float a = block_select(v, n, k0, hist, bc);
-    float b = (w > 0.f) ? block_select(v, n, k1, hist, bc) : a;
+    float b = (w > 0.f && k1 != k0) ? block_next(v, n, k1, a, bc) : a;
     if (threadIdx.x == 0) {
         // at::lerp
         float r = (w < 0.5f) ? a + w * (b - a) : b - (b - a) * (1.f - w);
@@ -336,7 +367,7 @@ hipError_t launch_loss(int stage, int l2, const float* gt, const float* rgb, con
         hipLaunchKernelGGL(loss_stats_kernel, dim3(grid), dim3(kLB), lds_stats, st, 1, rough_womip, seg, hl, room, P, C, R, ws);
         hipLaunchKernelGGL(loss_scan_kernel, dim3(1), dim3(64), 0, st, C, ws);
         hipLaunchKernelGGL(loss_scatter_kernel, dim3(grid), dim3(kLB), 0, st, rough_womip, seg, hl, P, ws);
-        hipLaunchKernelGGL(loss_quantile_kernel, dim3(C), dim3(kLB), 0, st, C, ws);
+        hipLaunchKernelGGL(loss_quantile_kernel, dim3(C), dim3(kQB), 0, st, C, ws);
     } else {
         hipLaunchKernelGGL(loss_stats_kernel, dim3(grid), dim3(kLB), lds_stats, st, 2, rough, seg, hl, room, P, C, a.R, ws);
     }
