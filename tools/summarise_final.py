@@ -37,7 +37,7 @@ for name in ("bench_default.json", "bench_c2.json", "bench_c1.json", "bench_2ran
         print("    cpu", round(c["value"], 2), c["unit"], "cores", c["cores"], "one_thread", c.get("one_thread"), "eff", c.get("parallel_efficiency"), c.get("host"))
     if "material_step" in b:
         m = b["material_step"]
-        print("    mat", m["ms"], "ms, views/step", m.get("views_per_step"), "roofline frac", m["roofline"]["frac"], "traffic", m["roofline"].get("traffic"), m["roofline"].get("traffic_note"))
+        print("    mat", m["ms"], "ms, views/step", m.get("views_per_step"), "roofline frac", (m.get("roofline") or {}).get("frac"), "traffic", (m.get("roofline") or {}).get("traffic"), (m.get("roofline") or {}).get("traffic_note"))
     for w, e in (b.get("extra_workloads") or {}).items():
         print("    extra", w, e["value"], e["ms_per_step"], rl(e["roofline"]) if "roofline" in e else "")
     if "ranks" in b:
