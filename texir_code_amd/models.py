@@ -160,6 +160,15 @@ class TracerO3d(nn.Module):
     # -- tracer_o3d_irt.py:145-180 ----------------------------------------------------------------------------------
     def forward(self):
         use_file = self.use_texel_gbuffer in (True, "file") or (self.use_texel_gbuffer == "auto" and os.path.exists(self.texel_gbuffer_path))
+        # The per-texel shifts (33.5 M floats from the CPU generator at 4096^2: 0.2 s) are drawn on a helper thread WHILE the texel G-buffer is loaded / ray-cast:
+        # nothing else touches the generator in between, so the stream is the reference's (one [nt,1,2] draw = its torch.rand(512,1,2) per 512-texel batch,
+        # sample_util.py:102).  The texel count is the index texture's; if the G-buffer turns out to have another size the generator is put back and the draw redone.
+        import threading
+        nt0 = int(self.index_texture.shape[0]) * int(self.index_texture.shape[1])
+        rng_before = torch.get_rng_state()
+        early = {}
+        th = threading.Thread(target=lambda: early.__setitem__("shift", torch.rand(nt0, 1, 2)), name="texir-irt-shifts", daemon=True)
+        th.start()
         with phases.phase("texel_gbuffer"):
             if use_file:
                 self._load_texel_gbuffer()
@@ -174,7 +183,11 @@ class TracerO3d(nn.Module):
             nt = pos.shape[0]
             # shifts: the reference draws torch.rand(512,1,2) per 512-texel batch from the CPU generator (sample_util.py:102);
             # one [nt,1,2] draw consumes the same stream in the same order
-            shift = torch.rand(nt, 1, 2).reshape(nt, 2).to(self.device, non_blocking=True)
+            th.join()
+            if nt != nt0 or "shift" not in early:
+                torch.set_rng_state(rng_before)
+                early["shift"] = torch.rand(nt, 1, 2)
+            shift = early.pop("shift").reshape(nt, 2).to(self.device, non_blocking=True)
             seam = torch.from_numpy(seam_texels(self.index_texture).reshape(-1)).to(self.device)
             ids = dist_util.morton_order(torch.nonzero(~seam)[:, 0].to(torch.int32), W)
             rank, world, _ = dist_util.world_info()
