@@ -103,7 +103,7 @@ class MatTrainRunner(RunnerBase):
         self.cur_iter = 0
         self.log = []
         # new optional key: with train.log_lag = n the loss values of a step are copied to pinned host memory asynchronously and logged / printed n steps
-        # later, so that the recorded steps are queued back to back; same values, same lines, same order (an epoch's last lines appear before its end).
+        # later, so that the recorded steps are queued back to back; same values, same lines, same order (the last n lines of a stage appear when the stage ends).
         # Default 1 (round 6): the step's line is printed while the NEXT step runs -- the GPU no longer idles through the host's report of every step;
         # 0 = the reference's own timing: `.item()` + print right after each step, one host synchronisation per step (train_material.py:459-468)
         self.log_lag = max(0, self.conf.get_int("train.log_lag", default=1))
