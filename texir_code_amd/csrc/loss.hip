@@ -101,11 +101,28 @@ __global__ void loss_scan_kernel(int C, LossWs ws)
 __global__ __launch_bounds__(kLB) void loss_scatter_kernel(const float* __restrict__ rw, const uint8_t* __restrict__ seg,
                                                            const uint8_t* __restrict__ hl, int64_t P, LossWs ws)
 {
-    for (int64_t p = (int64_t)blockIdx.x * kLB + threadIdx.x; p < P; p += (int64_t)gridDim.x * kLB) {
-        uint8_t c = seg[p];
-        if (c == kNoClass || !hl[p]) continue;
-        uint32_t slot = ws.hoff[c] + atomicAdd(&ws.hcur[c], 1u);
-        ws.hval[slot] = rw[p];
+    // (the order of a class's values in hval does not matter: the quantile is a selection.  The lanes of a wave that scatter into the SAME class take their slots with one
+    // atomicAdd -- neighbouring pixels mostly share their class, and 98 304 single atomics on a handful of addresses cost 21 us of the stage-1 step)
+    const int64_t Pround = (P + kLB - 1) / kLB * kLB;
+    for (int64_t p = (int64_t)blockIdx.x * kLB + threadIdx.x; p < Pround; p += (int64_t)gridDim.x * kLB) {
+        const uint8_t c = p < P ? seg[p] : kNoClass;
+        bool todo = p < P && c != kNoClass && hl[p];
+        const int lane = threadIdx.x & 63;
+        unsigned long long left = __ballot(todo);
+        while (left) {                                                   // wave-uniform loop: one round per distinct class among the wave's scattering lanes
+            const int lead = __ffsll((long long)left) - 1;
+            const int lc = __shfl((int)c, lead, 64);
+            const unsigned long long grp = __ballot(todo && (int)c == lc);
+            uint32_t base = 0;
+            if (lane == lead) base = atomicAdd(&ws.hcur[lc], (uint32_t)__popcll(grp));
+            base = (uint32_t)__shfl((int)base, lead, 64);
+            if (todo && (int)c == lc) {
+                const uint32_t rank = (uint32_t)__popcll(grp & ((1ull << lane) - 1ull));
+                ws.hval[ws.hoff[lc] + base + rank] = rw[p];
+                todo = false;
+            }
+            left &= ~grp;
+        }
     }
 }
 
