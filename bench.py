@@ -483,7 +483,7 @@ def roofline(workload, kernel, kern_ms, rays_this_rank, world, alg, fingerprint=
             out["note"] = "per-launch counters of the N = 1 profile scaled by this rank's share of the rays (%.4f)" % scale
         mem_frac = traffic / t / 1e9 / HBM_PEAK_GBS
         valu_frac = valu / (SIMDS * CLOCK_HZ / 2.0 * t)
-        # vector-L1 (TCP): the unit serves ONE cache access per clock (tools/tcp_rate.hip under the same counters: 1.00 per clock for
+        # vector-L1 (TCP): the unit serves ONE cache access per clock (tools/probes/tcp_rate.hip under the same counters: 1.00 per clock for
         # contiguous and for scattered wave-wide dwordx4 loads alike); the kernel's accesses over the TCP clocks of this run's duration
         l1 = None
         if pmc.get("tcp_cache_accesses") and pmc.get("tcp_clocks") and pmc.get("kernel_ms_under_pmc"):
@@ -507,7 +507,7 @@ def roofline(workload, kernel, kern_ms, rays_this_rank, world, alg, fingerprint=
                         "l1": None if l1 is None else {"frac": round(l1, 4), "achieved": round(float(pmc["tcp_cache_accesses"]) * scale / t / 1e9, 2),
                                                        "peak": round(tcp_hz / 1e9, 2), "unit": "G cache accesses/s", "accesses_per_launch": float(pmc["tcp_cache_accesses"]) * scale,
                                                        "note": "vector-L1 (TCP) tag lookups; the peak -- one access per clock per TCP, 256 TCPs at the clock TCP_GATE_EN1 reports -- is "
-                                                               "SELF-CALIBRATED (tools/tcp_rate.hip on this hardware, profiles/r02/tcp_rate.txt), not a documented figure; a build with a quarter fewer "
+                                                               "SELF-CALIBRATED (tools/probes/tcp_rate.hip on this hardware, profiles/r02/tcp_rate.txt), not a documented figure; a build with a quarter fewer "
                                                                "node-fetch loads (48-byte nodes, profiles/r03/ab_node48_s18.txt) was not faster: read the fraction as how busy the L1 is, not as proof that it binds"}},
                     "waves": {"wait_any_frac": pmc.get("sq_wait_any_frac"), "active_inst_any_frac": pmc.get("sq_active_inst_any_frac"),
                               "note": "share of the resident waves' cycles spent waiting / issuing (SQ_WAIT_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES)"},

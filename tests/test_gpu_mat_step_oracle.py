@@ -117,7 +117,7 @@ def _rel_l2_but_few(got, ref, frac=5e-4, at_least=8):
     emissive rectangle it jumps by three orders of magnitude.  The product and the oracle evaluate the SAME estimator on G-buffers that agree to ~1e-5 in uv
     (ray casting vs rasterisation), so their fetched roughness differs by ~1e-5 and, once in a while, ONE of the 98 304 sample rays of a view lands on the
     other side of such an edge: that pixel's d rgb / d roughness differs by the jump, and with it the handful of texels under the pixel's taps -- at 128^2
-    texels that handful carries 20 % of the gradient's norm.  Measured (round 5, tools/grad_edge_probe.py): two builds of the product whose G-buffer uvs differ by
+    texels that handful carries 20 % of the gradient's norm.  Measured (round 5, tools/probes/grad_edge_probe.py): two builds of the product whose G-buffer uvs differ by
     one float32 ulp (fma contraction) give roughness gradients that differ in exactly 2 of 16 384 texels, by 1e-5, all parked mip stacks equal to 1e-12 -- and
     one build is 2e-5 from the oracle, the other 0.195.  Both are right; the comparison must not hinge on which side of an edge a ray falls."""
     d = (np.asarray(got, np.float64) - np.asarray(ref, np.float64)).reshape(-1, got.shape[-1])

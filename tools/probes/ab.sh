@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/ab.sh "<label>|ENV=.. ENV=.." ...   -- runs bench c2 + c4 (IrT only) per configuration and prints Mrays/s
+# usage: tools/probes/ab.sh "<label>|ENV=.. ENV=.." ...   -- runs bench c2 + c4 (IrT only) per configuration and prints Mrays/s
 for spec in "$@"; do
   label=${spec%%|*}; envs=${spec#*|}
   for W in c2 c4; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/ab_layout.sh [workloads...]  -- IrT rate per hit-shader texture layout (2 = float32 3x3 tiles, 3 = 4-byte texels 5x5, 4 = 4-byte texels 8x4) on the RGBE-born texture
+# usage: tools/probes/ab_layout.sh [workloads...]  -- IrT rate per hit-shader texture layout (2 = float32 3x3 tiles, 3 = 4-byte texels 5x5, 4 = 4-byte texels 8x4) on the RGBE-born texture
 R=${GRAFT_REPO_ROOT:-/root/repo}
 export TEXIR_SYNTH_CACHE=${TEXIR_SYNTH_CACHE:-/tmp/texir_synth}
 WLS=("$@"); [ ${#WLS[@]} -eq 0 ] && WLS=(c4 c2 c4_scan house)

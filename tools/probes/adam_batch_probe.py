@@ -1,13 +1,13 @@
 """The batched Adam launch alone (texir_adam_step_tex_dev_batch over a 4096^2 x 3 and a 4096^2 x 1 texture, the material step's pair): microseconds per launch
 and bytes moved / time, in the step's own conditions -- level-0 gradient absent, level-1 stack read through a ~1 % mask, level-2 stack dense, mip level 1 written.
 The arrays (1.7 GB per launch) do not fit the 256 MB Infinity Cache, so repeated launches stream from HBM as the step does.
-usage: [TEXIR_HIP_LIB=...] [TEXIR_ADAM_GRID_Y=n] python tools/adam_batch_probe.py [reps]"""
+usage: [TEXIR_HIP_LIB=...] [TEXIR_ADAM_GRID_Y=n] python tools/probes/adam_batch_probe.py [reps]"""
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from texir_code_amd import _lib  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40

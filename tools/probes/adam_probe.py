@@ -1,8 +1,8 @@
 """isolated timing of the fused texture Adam kernels: host-argument entry (texir_adam_step_tex) vs device-record entry (texir_adam_step_tex_dev)
-usage: python tools/adam_probe.py"""
+usage: python tools/probes/adam_probe.py"""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from texir_code_amd import _lib
 
 L = _lib.lib()

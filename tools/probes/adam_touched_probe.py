@@ -1,14 +1,14 @@
 """How much of the 4k atlas ever receives a gradient?  (probe for a dense-equivalent Adam that skips texel blocks whose moments are still
 exactly zero: p -= lr * 0 / (sqrt(0) + eps) is the identity, so torch.optim.Adam's dense update leaves such texels unchanged bit for bit.)
 Runs the bench's material problem for a number of epochs over its views and reports, per block granularity, the share of blocks in
-which any first or second moment is non-zero.  usage: python tools/adam_touched_probe.py [epochs]"""
+which any first or second moment is non-zero.  usage: python tools/probes/adam_touched_probe.py [epochs]"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from texir_code_amd import scene as S  # noqa: E402

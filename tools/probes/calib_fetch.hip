@@ -3,7 +3,7 @@
 // kernels fetch BVH nodes -- from a buffer far larger than L2 + Infinity Cache, each record touched once.
 //   known bytes = records * 64      ->   compare with FETCH_SIZE(KB) * 1024 of `gather64`
 // `stream16` reads the same number of bytes as a coalesced 16 B/lane stream (the case the guide documents as tallied at half).
-//   hipcc --offload-arch=gfx950 -O3 tools/calib_fetch.hip -o /tmp/calib_fetch && rocprofv3 --pmc FETCH_SIZE --kernel-trace ... -- /tmp/calib_fetch
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/calib_fetch.hip -o /tmp/calib_fetch && rocprofv3 --pmc FETCH_SIZE --kernel-trace ... -- /tmp/calib_fetch
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

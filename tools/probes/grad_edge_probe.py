@@ -4,7 +4,7 @@ float32 ulp at a fifth of the pixels, fma contraction) with and without NaN-pois
 Result (profiles/r05/grad_edge_probe.txt): no uninitialised read; stacks equal to 1e-12; the dense gradients differ in 2 of 16 384 texels by 1e-5 -- one specular sample ray
 of one pixel lands on the other side of an emissive rectangle's edge.  The test now sets such texels aside (_rel_l2_but_few)."""
 import os, sys, subprocess, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch

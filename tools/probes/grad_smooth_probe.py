@@ -1,11 +1,11 @@
 """probe (tool, round 6): the one untrimmed gradient of tests/test_gpu_mat_step_oracle.py that sits at 8.5e-4 (smooth radiance, 64^2 / 128^2 textures, stage 2, roughness) while every
 other case is at 1e-6 ... 5e-5 -- and did not move when the texture's contrast went from +-20 % to +-5 %.  Feeds the product's specular forward and the C oracle's with the SAME per-pixel
 inputs (the oracle's rasterised G-buffer, its fetched materials) and compares the traced radiance sample by sample; then lists the texels that carry the gradient difference.
-usage: python tools/grad_smooth_probe.py   (GPU box)"""
+usage: python tools/probes/grad_smooth_probe.py   (GPU box)"""
 import os, sys
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_mat_step_oracle as T
 from texir_code_amd import scene as S

@@ -1,7 +1,7 @@
 """Which kernel form (1 / 64 texels per wave) is fastest for a given texel-list length?  (tunes the launcher's thresholds)"""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from texir_code_amd import scene as S, synth, dist_util
 

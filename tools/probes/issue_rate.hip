@@ -2,7 +2,7 @@
 // For every pattern: 8 independent register chains, 64 instructions per loop body, run at 1 and at 8 waves per SIMD on every
 // CU.  Prints time per wave-instruction per SIMD relative to v_fma_f32 (= 1.00 by definition) -- the missing column of the
 // guide's per-instruction table for integer / conversion / select ops.
-//   hipcc --offload-arch=gfx950 -O2 tools/issue_rate.hip -o /tmp/issue_rate && /tmp/issue_rate
+//   hipcc --offload-arch=gfx950 -O2 tools/probes/issue_rate.hip -o /tmp/issue_rate && /tmp/issue_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

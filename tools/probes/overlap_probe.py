@@ -1,8 +1,8 @@
 """Can the (compute-bound) specular trace of the next step overlap the (HBM-bound) albedo Adam of this step?  Times both alone, back to back on
-one stream, and concurrently on two streams.   usage: python tools/overlap_probe.py"""
+one stream, and concurrently on two streams.   usage: python tools/probes/overlap_probe.py"""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from texir_code_amd import _lib, scene as S
 

@@ -3,7 +3,7 @@ Times texir_spec_forward alone on the c4 scene's view 0 (98 304 px x 16 GGX rays
   warm   back to back (caches hold the BVH from the previous launch)
   cold   after a 2 GB device-to-device copy (what the fused Adam leaves behind in a real step)
   cold + texir_scene_prefetch variants before the launch (serial) -- upper bound of what a prefetch on a parallel graph branch can give
-usage: python tools/spec_probe.py [--workload c4]"""
+usage: python tools/probes/spec_probe.py [--workload c4]"""
 import argparse
 import os
 import sys
@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 

@@ -2,7 +2,7 @@
 Times the fused spec_kernel against texir_trace_shade on the SAME reflection rays (c4 scene, 98 304 pixels x 16 GGX samples)."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from texir_code_amd import cameras, gbuffer as GB, scene as S
 

@@ -1,7 +1,7 @@
 // Micro-benchmark (tool): how many distinct cache lines per cycle a CU's vector L1 (TCP) serves on gfx950, for the access shapes of
 // the traversal loop: a wave-wide global_load_dwordx4 whose 64 lanes touch 1 / 8 / 32 / 64 distinct 128-byte lines of an L1-resident
 // 16 KiB window.  Prints time per wave-instruction per CU and lines per cycle (at the clock measured with a v_fma loop).
-//   hipcc --offload-arch=gfx950 -O2 tools/tcp_rate.hip -o tools/tcp_rate && tools/tcp_rate
+//   hipcc --offload-arch=gfx950 -O2 tools/probes/tcp_rate.hip -o tools/probes/tcp_rate && tools/probes/tcp_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
