@@ -12,9 +12,11 @@ G-buffers, shifts) are resident in HBM before the timed region.
 
 Multi-GPU: one process per GPU; the compacted valid-texel list is dealt block-cyclically to the ranks
 (strong scaling of ONE texture), each rank writes its texels into a zero-initialised full texture and a single
-RCCL all_reduce(SUM) assembles it (disjoint support) -- inside the timed region.
+RCCL all_gather of the ranks' compacted values assembles it (disjoint support: the same bits as an all_reduce(SUM) at a twelfth of the bytes) -- inside the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline` carries three bounds that hold (all <= 1), each = a per-launch counter of the
+Prints ONE compact JSON line (rank 0; <= 3 KB by construction, `compact_line`) and writes the whole record -- every limit with its numerator and denominator, the
+occupancy sweep, the per-shard projection, the sibling workloads, the stages end to end -- to gpurun_out/bench_full.json ($TEXIR_BENCH_FULL overrides; `"full"` in
+the line names it).  In the full record `roofline` carries the bounds that hold (all <= 1), each = a per-launch counter of the
 dominant kernel (rocprofv3 --pmc, committed under profiles/pmc_<workload>.json together with a hash of the kernel sources
 -- a profile of other sources is refused) divided by the kernel time measured live with HIP events:
   * memory: fabric-side bytes (L2 <-> Infinity Cache/HBM read requests x 128 B + writes) / time / 8 TB/s,
@@ -25,6 +27,9 @@ tightest of the three, `limits` carries each one's numerator, denominator and fr
 `algorithmic` -- they are served by L1/L2 hits of a 4x more compact tree and exceed the HBM peak, so they bound nothing.
 `cpu_baseline` = the CPU oracle (a port of the reference algorithm; Open3D/Embree is not installable here) timed
 on this box's host cores on a bounded sample of the same workload.
+In the printed line: roofline.{bound, achieved, peak, frac, traffic} = the memory side; binding / binding_frac = the largest measured limit; algorithmic_frac = SURVEY 8(d)'s
+bytes / the live kernel time / 8 TB/s (> 1: cache-served, not a bound); profile_matches_live = the traversal's own counters on a fixed slice of the workload, recomputed by
+this run, equal the ones stored beside the PMC counters (the counters come from the profile session's box, the time from this one).
 """
 import argparse
 import hashlib
