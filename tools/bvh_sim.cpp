@@ -77,8 +77,8 @@ int main(int argc, char** argv)
     if (argc < 2) { fprintf(stderr, "usage: bvh_sim <dir> [groups=64] [passes=64] [variant flags: cull cull8 nosort]\n"); return 1; }
     std::string dir = argv[1];
     int n_groups = argc > 2 ? atoi(argv[2]) : 64, n_pass = argc > 3 ? atoi(argv[3]) : 64;
-    bool cull = false, cull8 = false, nosort = false, psort3 = false; int policy = 0; double alpha = 1.0, alpha2 = 1.0, tricost = 1.5; int refillK = 0; int spec = 0; int switch_after = 0; int parkK = 0, parkM = 0; int regB = 0, regKey = 0; bool consec = false;
-    for (int i = 4; i < argc; i++) { if (!strcmp(argv[i], "cull")) cull = true; if (!strcmp(argv[i], "cull8")) cull = cull8 = true; if (!strcmp(argv[i], "nosort")) nosort = true; if (!strcmp(argv[i], "psort3")) psort3 = true; if (!strncmp(argv[i], "after:", 6)) switch_after = atoi(argv[i] + 6); if (!strcmp(argv[i], "spec")) spec = 1; if (!strcmp(argv[i], "spec2")) spec = 2; if (!strncmp(argv[i], "refill:", 7)) refillK = atoi(argv[i] + 7); if (!strncmp(argv[i], "arr", 3)) { policy = 2; if (argv[i][3] == ':') { alpha = alpha2 = atof(argv[i] + 4); const char* c2 = strchr(argv[i] + 4, ','); if (c2) alpha2 = atof(c2 + 1); } } if (!strncmp(argv[i], "maj", 3)) { policy = 1; if (argv[i][3] == ':') { alpha = alpha2 = atof(argv[i] + 4); const char* c2 = strchr(argv[i] + 4, ','); if (c2) alpha2 = atof(c2 + 1); } } if (!strncmp(argv[i], "tricost:", 8)) tricost = atof(argv[i] + 8); if (!strcmp(argv[i], "consec")) consec = true; if (!strncmp(argv[i], "regroup:", 8)) { regB = atoi(argv[i] + 8); const char* c2 = strchr(argv[i] + 8, ','); regKey = c2 ? atoi(c2 + 1) : 0; } if (!strncmp(argv[i], "park:", 5)) { parkK = atoi(argv[i] + 5); const char* c2 = strchr(argv[i] + 5, ','); parkM = c2 ? atoi(c2 + 1) : 0; } }
+    bool cull = false, cull8 = false, nosort = false, psort3 = false; int policy = 0; double alpha = 1.0, alpha2 = 1.0, tricost = 1.5; int refillK = 0; int spec = 0; int switch_after = 0; int parkK = 0, parkM = 0; int regB = 0, regKey = 0; bool consec = false; int texK = 64;
+    for (int i = 4; i < argc; i++) { if (!strcmp(argv[i], "cull")) cull = true; if (!strcmp(argv[i], "cull8")) cull = cull8 = true; if (!strcmp(argv[i], "nosort")) nosort = true; if (!strcmp(argv[i], "psort3")) psort3 = true; if (!strncmp(argv[i], "after:", 6)) switch_after = atoi(argv[i] + 6); if (!strcmp(argv[i], "spec")) spec = 1; if (!strcmp(argv[i], "spec2")) spec = 2; if (!strncmp(argv[i], "refill:", 7)) refillK = atoi(argv[i] + 7); if (!strncmp(argv[i], "arr", 3)) { policy = 2; if (argv[i][3] == ':') { alpha = alpha2 = atof(argv[i] + 4); const char* c2 = strchr(argv[i] + 4, ','); if (c2) alpha2 = atof(c2 + 1); } } if (!strncmp(argv[i], "maj", 3)) { policy = 1; if (argv[i][3] == ':') { alpha = alpha2 = atof(argv[i] + 4); const char* c2 = strchr(argv[i] + 4, ','); if (c2) alpha2 = atof(c2 + 1); } } if (!strncmp(argv[i], "tricost:", 8)) tricost = atof(argv[i] + 8); if (!strcmp(argv[i], "consec")) consec = true; if (!strncmp(argv[i], "texk:", 5)) texK = atoi(argv[i] + 5); if (!strncmp(argv[i], "regroup:", 8)) { regB = atoi(argv[i] + 8); const char* c2 = strchr(argv[i] + 8, ','); regKey = c2 ? atoi(c2 + 1) : 0; } if (!strncmp(argv[i], "park:", 5)) { parkK = atoi(argv[i] + 5); const char* c2 = strchr(argv[i] + 5, ','); parkM = c2 ? atoi(c2 + 1) : 0; } }
     auto verts = load<float>(dir + "/verts.f32"); auto tris = load<int32_t>(dir + "/tris.i32"); auto uvs = load<float>(dir + "/tri_uvs.f32");
     auto pos = load<float>(dir + "/pos.f32"); auto nrm = load<float>(dir + "/nrm.f32"); auto shift = load<float>(dir + "/shift.f32");
     auto ids = load<int32_t>(dir + "/ids.i32"); auto meta = load<int32_t>(dir + "/meta.i32");
@@ -245,8 +245,12 @@ int main(int argc, char** argv)
             for (int pj = 0; pj < (refillK ? 1 : n_pass) || !queue.empty(); pj++) {
                 const uint32_t J = refillK ? Jbase : consec ? (Jbase + (uint32_t)pj) % (uint32_t)N : (uint32_t)((double)pj / n_pass * N);      // consec: the passes of ONE wedge, neighbouring cells in order (what a chunk of the kernel walks)
                 if (regB && regKey && pj > 0) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rkey[a] < rkey[b]; });
-              for (int wv = 0; wv < B; wv++) {
-                for (int l = 0; l < 64; l++) lane_tex[l] = blk[order[wv * 64 + l]];
+              const int CPW = 64 / texK;
+              for (int wv = 0; wv < (regB ? B : CPW); wv++) {
+                for (int l = 0; l < 64; l++) lane_tex[l] = texK < 64 ? blk[wv * texK + l % texK] : blk[order[wv * 64 + l]];
+                // texk:K -- a wave = K texels x (64 / K) NEIGHBOURING cells per pass instead of 64 texels x 1 cell: 64 / K such waves share a group's texels (sub-wave `sw` of the
+                // pass takes texels [sw K, sw K + K)); lane l traces texel (l % K) in cell J (64 / K) + l / K.  Same rays in total, fewer origins and more directions per wave.
+
                 in_compact = false;
                 const double w0n = c.wnode, w0t = c.wtri, n0 = c.nodes, t0 = c.tris;
                 if (parkK && (queue.size() >= 64 || pj >= n_pass)) {
@@ -257,7 +261,7 @@ int main(int argc, char** argv)
                     queue.resize(queue.size() - take);
                     c.cpass++; c.rays -= 64;          // (not new rays)
                 } else
-                for (int l = 0; l < 64; l++) { init_ray(l, J); lane_pass[l] = 0; }
+                for (int l = 0; l < 64; l++) { init_ray(l, texK < 64 ? (J * (uint32_t)CPW + (uint32_t)(l / texK)) % (uint32_t)N : J); lane_pass[l] = 0; }
                 if (refillK) { c.refills++; c.refill_lanes += 64; }
                 c.rays += 64;
                 int lane_nodes[64] = {0}, lane_tris[64] = {0};
@@ -394,7 +398,7 @@ int main(int argc, char** argv)
                 if (in_compact) { c.cwnode += c.wnode - w0n; c.cwtri += c.wtri - w0t; c.cnodes += c.nodes - n0; c.ctris += c.tris - t0; }
                 for (auto& r : R) if (r.slot >= 0) c.hits++;
                 { int mn = 0, mt = 0; for (int l = 0; l < 64; l++) { mn = std::max(mn, lane_nodes[l]); mt = std::max(mt, lane_tris[l]); } c.wmaxn += mn; c.wmaxt += mt; }
-                if (regB) for (int l = 0; l < 64; l++) {
+                if (regB && texK == 64) for (int l = 0; l < 64; l++) {
                     const int sub = R[l].slot >= 0 ? slot_subtree[R[l].slot] : 17;
                     rkey[order[wv * 64 + l]] = regKey == 1 ? (double)sub : regKey == 2 ? (double)lane_nodes[l] : (double)sub * 4096.0 + (double)lane_nodes[l];
                 }
