@@ -158,8 +158,8 @@ def run(workload="c4", root=None, mat_epochs=40, keep=False, style="room", do_ma
             with _quiet():
                 D.render_gt_views(root, C.parse_file(conf_mat), sc, mres, mres)
             out["gt_views_prep_s"] = round(time.perf_counter() - t0, 2)
-            out["mat"] = time_mat(conf_mat, os.path.join(root, "exps"), mat_epochs, log_lag)
-            if profile:
+            out["mat"] = time_mat(conf_mat, os.path.join(root, "exps"), mat_epochs, log_lag, profile=(profile == "first"))
+            if profile and profile != "first":
                 out["mat_profiled"] = time_mat(conf_mat, os.path.join(root, "exps_prof"), mat_epochs, log_lag, profile=True)
             if log_lag is None:
                 # the same stage with train.log_lag = 0: `.item()` + print right after every step, the reference's own timing (one host synchronisation per step)
@@ -181,9 +181,10 @@ def main():
     ap.add_argument("--log-lag", type=int, default=None, help="train.log_lag of the Mat run (default: the product's default, then once more with 0)")
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--profile", action="store_true", help="run the Mat stage once more under cProfile: `mat_profiled.cprofile_tottime`")
+    ap.add_argument("--profile-first", action="store_true", help="cProfile the FIRST Mat run of the process instead (first-use costs): `mat.cprofile_tottime`")
     ap.add_argument("--no-pano", action="store_true", help="skip the IrrT run through the panorama G-buffer flow")
     a = ap.parse_args()
-    print(json.dumps(run(a.workload, a.root, a.mat_epochs, a.keep, a.style, not a.no_mat, a.log_lag, not a.no_pano, a.profile)))
+    print(json.dumps(run(a.workload, a.root, a.mat_epochs, a.keep, a.style, not a.no_mat, a.log_lag, not a.no_pano, "first" if a.profile_first else a.profile)))
 
 
 if __name__ == "__main__":
