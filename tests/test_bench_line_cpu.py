@@ -152,7 +152,7 @@ def _contract_keys():
 
 def test_compact_line_fits_the_drivers_capture_and_keeps_the_contract_keys():
     """BENCH_r05.json had parsed = null because the printed line had grown to 20 KB.  The printed line is built by bench.compact_line from the full record;
-    canned inputs = the full records of round 5 (N = 1 driver command; 2 gloo ranks on one GPU)"""
+    canned inputs = committed full records (round 5's 20 KB line, N = 1 driver command; round 6's 2 gloo ranks on one GPU and N = 1 record as the current code writes them)"""
     import bench
     full = json.load(open(os.path.join(ROOT, "profiles", "r05", "bench_driver_command.json")))
     assert len(json.dumps(full)) > 15000
@@ -178,12 +178,17 @@ def test_compact_line_fits_the_drivers_capture_and_keeps_the_contract_keys():
     assert abs(o["e2e_s"]["mat_stage_ms_per_step"] - 1e3 * (ph["stage0"] + ph["stage1"] + ph["stage2"]) / full["e2e"]["mat"]["steps"]) < 1e-3
     assert o["full"] == "gpurun_out/bench_full.json"
     # N > 1 record: same cap, the per-rank block in place of the projection
-    full2 = json.loads([l for l in open(os.path.join(ROOT, "profiles", "r05", "bench_2rank_gloo_one_gpu.json")) if l.startswith("{")][-1])
-    full2.setdefault("ranks", {}).update({"rccl_ranks": None, "backend": "gloo", "collective_bytes_per_step": 12345})
+    full2 = json.load(open(os.path.join(ROOT, "profiles", "r06", "bench_2rank_gloo_one_gpu_full.json")))
     line2 = bench.compact_line(full2, "x.json")
     o2 = json.loads(line2)
     assert len(line2) <= bench.LINE_CAP and (_contract_keys() - {"cpu_baseline"}) <= set(o2)
     assert o2["n_gpus"] == 2 and len(o2["ranks"]["kernel_ms"]) == 2 and o2["ranks"]["assembled_ok"] is True and o2["ranks"]["backend"] == "gloo"
+    assert o2["ranks"]["rccl_ranks"] is None and o2["ranks"]["collective_bytes_per_step"] == 12 * 12417 and "projected_speedup" not in o2
+    # the printed line of the committed driver-shaped run IS what compact_line makes of its full record
+    full6 = json.load(open(os.path.join(ROOT, "profiles", "r06", "bench_driver_command_full.json")))
+    printed = open(os.path.join(ROOT, "profiles", "r06", "bench_driver_command.json")).read().strip().splitlines()[-1]
+    assert json.loads(bench.compact_line(full6, json.loads(printed)["full"])) == json.loads(printed)
+    assert json.loads(printed)["roofline"]["profile_matches_live"] is True and json.loads(printed)["e2e_s"]["mat_stage_ms_per_step"] < 0.80
     # an unexpected long string cannot push the line past the cap: optional blocks go first
     full3 = json.loads(json.dumps(full))
     full3["config"]["workload"] = "w" * 2500
